@@ -1,0 +1,445 @@
+"""CPU restatement of the vgiwae objectives (test infrastructure; see oracle/__init__.py).
+
+Everything is written with plain tensor ops so it runs in fp32 or fp64 and under
+autograd.  Noise is always passed in.  Shapes follow the reference:
+  X [B, D] float, M [B, D] bool, eps [nz, I, B, Zd] (IWAE), [nz, I, B, C, Zd] (stratified),
+  [nz, B, K, Zd] (DeMissVAE).
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from .recipes import NetSpec
+
+EPSILON = 1e-5  # vgiwae/shared/vae_enums.py:3
+LOG_SQRT_2PI = math.log(math.sqrt(2 * math.pi))
+
+_ACT = {
+    "relu": F.relu,
+    "leaky_relu": F.leaky_relu,
+    "tanh": torch.tanh,
+    "sigmoid": torch.sigmoid,
+}
+
+
+# --------------------------------------------------------------------------------------
+# Residual MLP  (vgiwae/shared/neural_nets.py:67-72, 127-133)
+# --------------------------------------------------------------------------------------
+def mlp_forward(params, x, spec: NetSpec, dropout_masks=None):
+    """out = final(act(block_n(... act(block_1(act(initial(x)))))))
+
+    block(a) = a + L1(drop(act(L0(a)))).  `dropout_masks[b]` is the 0/1 keep mask applied
+    (with 1/(1-p) scaling) inside block b; None means no dropout.
+    """
+    act = _ACT[spec.act]
+    a = act(F.linear(x, params["initial_layer.weight"], params["initial_layer.bias"]))
+    for b in range(spec.nb):
+        t = act(F.linear(a, params[f"blocks.{b}.linear_layers.0.weight"],
+                         params[f"blocks.{b}.linear_layers.0.bias"]))
+        if dropout_masks is not None and spec.dropout > 0:
+            t = t * dropout_masks[b].to(t.dtype) / (1.0 - spec.dropout)
+        a = act(a + F.linear(t, params[f"blocks.{b}.linear_layers.1.weight"],
+                             params[f"blocks.{b}.linear_layers.1.bias"]))
+    return F.linear(a, params["final_layer.weight"], params["final_layer.bias"])
+
+
+# --------------------------------------------------------------------------------------
+# Model description
+# --------------------------------------------------------------------------------------
+@dataclass
+class ModelSpec:
+    D: int
+    Zd: int
+    enc: NetSpec
+    dec: NetSpec
+    gen_dist: str = "normal_with_eps"     # normal | normal_with_eps | bern | bern_m1_p1
+    q_dist: str = "normal_with_eps"       # normal | normal_with_eps | stratified | stratified_with_eps
+    C: int = 1                            # mixture components for stratified q
+    encoder_use_mis_mask: bool = False
+
+    @property
+    def q_eps(self):
+        return EPSILON if self.q_dist.endswith("with_eps") else 0.0
+
+    @property
+    def gen_eps(self):
+        return EPSILON if self.gen_dist.endswith("with_eps") else 0.0
+
+    @property
+    def q_is_mixture(self):
+        return self.q_dist.startswith("stratified")
+
+
+def encoder_input(spec: ModelSpec, X, M):
+    """vgiwae/models/vae.py:80-91: all of X, then all of M, on the last axis."""
+    if spec.encoder_use_mis_mask:
+        return torch.cat([X, M.to(X.dtype)], dim=-1)
+    return X
+
+
+def q_heads(spec: ModelSpec, p):
+    """vgiwae/models/vae.py:113-125, 155-208.  Returns (mu, sigma, logits|None).
+
+    Single Gaussian: mu, sigma [..., Zd].  Stratified: mu, sigma [..., C, Zd], logits [..., C]
+    (unnormalised)."""
+    if not spec.q_is_mixture:
+        mu, raw = p[..., :spec.Zd], p[..., spec.Zd:2 * spec.Zd]
+        return mu, F.softplus(raw) + spec.q_eps, None
+    C, Zd = spec.C, spec.Zd
+    comp, logits = p[..., :-C], p[..., -C:]
+    mu = comp[..., :C * Zd].reshape(*comp.shape[:-1], C, Zd)
+    raw = comp[..., C * Zd:].reshape(*comp.shape[:-1], C, Zd)
+    return mu, F.softplus(raw) + spec.q_eps, logits
+
+
+def log_normal(x, mu, sigma):
+    """torch.distributions.Normal.log_prob restated."""
+    return -((x - mu) ** 2) / (2 * sigma ** 2) - torch.log(sigma) - LOG_SQRT_2PI
+
+
+def log_std_normal(z):
+    return -(z ** 2) / 2 - LOG_SQRT_2PI
+
+
+def log_bern_logits(v01, logits):
+    """Bernoulli(logits).log_prob(v) = -BCEWithLogits(logits, v)."""
+    return -((1 - v01) * logits - F.logsigmoid(logits))
+
+
+def gen_logprob(spec: ModelSpec, g, X):
+    """Elementwise log p(x_d | z) from decoder output g (vgiwae/models/vae.py:113-129)."""
+    D = spec.D
+    if spec.gen_dist in ("normal", "normal_with_eps"):
+        m, s = g[..., :D], F.softplus(g[..., D:2 * D]) + spec.gen_eps
+        return log_normal(X, m, s)
+    if spec.gen_dist == "bern":
+        return log_bern_logits(X, g[..., :D])
+    if spec.gen_dist == "bern_m1_p1":
+        # vgiwae/shared/bernoulli_between_m1_and_p1.py:24-26
+        return log_bern_logits((X + 1) / 2, g[..., :D])
+    raise NotImplementedError(spec.gen_dist)
+
+
+def gen_sample(spec: ModelSpec, g, noise):
+    """Draw x ~ p(.|z): Normal -> m + s*eps (noise = standard normal);
+    Bernoulli -> 1[u < sigmoid(logit)] (noise = uniform), mapped to {-1,+1} for bern_m1_p1."""
+    D = spec.D
+    if spec.gen_dist in ("normal", "normal_with_eps"):
+        m, s = g[..., :D], F.softplus(g[..., D:2 * D]) + spec.gen_eps
+        return m + noise * s
+    b = (noise < torch.sigmoid(g[..., :D])).to(g.dtype)
+    if spec.gen_dist == "bern":
+        return b
+    return b * 2 - 1
+
+
+# --------------------------------------------------------------------------------------
+# Bounds
+# --------------------------------------------------------------------------------------
+def _encode(spec, enc_params, X_in, M, enc_masks=None):
+    return mlp_forward(enc_params, encoder_input(spec, X_in, M), spec.enc, enc_masks)
+
+
+def estimate_elbo(spec: ModelSpec, enc_params, dec_params, X, M, eps, *, kl_analytic, STL=False,
+                  enc_masks=None, dec_masks=None):
+    """vgiwae/models/vae.py:393-473.  eps [nz, B, Zd].  Returns (scalar, per-datapoint [B])."""
+    Mf = M.to(X.dtype)
+    p = _encode(spec, enc_params, X * Mf, M, enc_masks)
+    mu, sigma, _ = q_heads(spec, p)
+    Z = mu + sigma * eps
+    g = mlp_forward(dec_params, Z, spec.dec, dec_masks)
+    gen = (gen_logprob(spec, g, X) * Mf).sum(-1)            # [nz, B]
+    if kl_analytic:
+        kl = 0.5 * (sigma ** 2 + mu ** 2 - 1 - torch.log(sigma ** 2))
+        per_b = gen.mean(0) - kl.sum(-1)
+    else:
+        prior = log_std_normal(Z).sum(-1)
+        if STL:
+            lq = log_normal(Z, mu.detach(), sigma.detach()).sum(-1)
+        else:
+            lq = log_normal(Z, mu, sigma).sum(-1)
+        per_b = (gen + prior - lq).mean(0)
+    return per_b.mean(), per_b
+
+
+def smis_log_weights(spec: ModelSpec, g, X, M, Z, mu, sigma, logits=None):
+    """vgiwae/shared/iwae.py:9-55 with prior N(0,1); q single Gaussian or mixture over the
+    components of the same datapoint (MixtureSameFamily.log_prob)."""
+    gen = (gen_logprob(spec, g, X) * M.to(X.dtype)).sum(-1)
+    prior = log_std_normal(Z).sum(-1)
+    if logits is None:
+        lq = log_normal(Z, mu, sigma).sum(-1)
+    else:
+        comp = log_normal(Z.unsqueeze(-2), mu, sigma).sum(-1)          # [..., B, C]
+        lq = torch.logsumexp(comp + torch.log_softmax(logits, -1), dim=-1)
+    return gen + prior - lq
+
+
+def estimate_iwelbo(spec: ModelSpec, enc_params, dec_params, X, M, eps, *, STL=False, DREG=False,
+                    enc_masks=None, dec_masks=None, return_aux=False):
+    """vgiwae/models/iwae.py:70-154.  eps [nz, I, B, Zd].  DREG scales the gradient that
+    reaches Z by softmax_i(log_w)."""
+    assert not (STL and DREG)
+    Mf = M.to(X.dtype)
+    p = _encode(spec, enc_params, X * Mf, M, enc_masks)
+    mu, sigma, _ = q_heads(spec, p)
+    Z = mu + sigma * eps
+    hook_w = []
+    if DREG and Z.requires_grad:
+        Z.register_hook(lambda grad: hook_w[0].unsqueeze(-1) * grad)
+    g = mlp_forward(dec_params, Z, spec.dec, dec_masks)
+    if STL or DREG:
+        log_w = smis_log_weights(spec, g, X, M, Z, mu.detach(), sigma.detach())
+    else:
+        log_w = smis_log_weights(spec, g, X, M, Z, mu, sigma)
+    I = log_w.shape[1]
+    if DREG:
+        hook_w.append(torch.softmax(log_w.detach(), dim=1))
+    per_zb = torch.logsumexp(log_w, dim=1) - math.log(I)
+    per_b = per_zb.mean(0)
+    if return_aux:
+        return per_b.mean(), per_b, dict(log_w=log_w, Z=Z, enc_out=p, dec_out=g)
+    return per_b.mean(), per_b
+
+
+def stratified_mixture_logprob(Z, mu, sigma, logits):
+    """vgiwae/shared/iwae.py:106-118: log sum_c' pi_{b,c'} N(z_{..., b, c}; mu_{b,c'}, sigma_{b,c'}).
+    Z [..., B, C, Zd]; mu, sigma [B, C, Zd]; logits [B, C] -> [..., B, C]."""
+    comp = log_normal(Z.unsqueeze(-2), mu.unsqueeze(-3), sigma.unsqueeze(-3)).sum(-1)  # [...,B,C,C']
+    return torch.logsumexp(comp + torch.log_softmax(logits, -1).unsqueeze(-2), dim=-1)
+
+
+def imputation_mixture_logprob(Z, mu, sigma):
+    """vgiwae/shared/iwae.py:119-130: log (1/K) sum_k' prod_j N(z_{..., b, k, j}; mu_{b,k',j}, sigma_{b,k',j}).
+    Z [..., B, K, Zd]; mu, sigma [B, K, Zd] -> [..., B, K]."""
+    K = Z.shape[-2]
+    comp = log_normal(Z.unsqueeze(-2), mu.unsqueeze(-3), sigma.unsqueeze(-3)).sum(-1)  # [...,B,K,K']
+    return torch.logsumexp(comp, dim=-1) - math.log(K)
+
+
+def estimate_multiple_iwelbo(spec: ModelSpec, enc_params, dec_params, X, M, eps, *, STL=False,
+                             looser=False, enc_masks=None, dec_masks=None):
+    """vgiwae/models/multiple_iwae.py:124-237.  eps [nz, I, B, C, Zd] (one draw per component)."""
+    Mf = M.to(X.dtype)
+    p = _encode(spec, enc_params, X * Mf, M, enc_masks)
+    mu, sigma, logits = q_heads(spec, p)
+    Z = mu + sigma * eps                                              # [nz, I, B, C, Zd]
+    g = mlp_forward(dec_params, Z, spec.dec, dec_masks)
+    gen = (gen_logprob(spec, g, X.unsqueeze(1)) * Mf.unsqueeze(1)).sum(-1)
+    prior = log_std_normal(Z).sum(-1)
+    if STL:
+        lq = stratified_mixture_logprob(Z, mu.detach(), sigma.detach(), logits.detach())
+    else:
+        lq = stratified_mixture_logprob(Z, mu, sigma, logits)
+    log_w = gen + prior - lq                                          # [nz, I, B, C]
+    I = log_w.shape[1]
+    log_pi = torch.log_softmax(logits, -1)                            # live (not detached)
+    if not looser:
+        lw = log_w + log_pi - math.log(I)
+        per_zb = torch.logsumexp(lw.permute(0, 1, 3, 2).reshape(lw.shape[0], -1, lw.shape[2]), dim=1)
+    else:
+        per_zb = (torch.logsumexp(log_w - math.log(I), dim=1) * torch.exp(log_pi)).sum(-1)
+    per_b = per_zb.mean(0)
+    return per_b.mean(), per_b
+
+
+def estimate_multiple_elbo(spec: ModelSpec, enc_params, dec_params, X, M, eps, *, STL=False,
+                           enc_masks=None, dec_masks=None):
+    """vgiwae/models/multiple_vae.py:109-195.  eps [nz, B, C, Zd]."""
+    Mf = M.to(X.dtype)
+    p = _encode(spec, enc_params, X * Mf, M, enc_masks)
+    mu, sigma, logits = q_heads(spec, p)
+    Z = mu + sigma * eps                                              # [nz, B, C, Zd]
+    g = mlp_forward(dec_params, Z, spec.dec, dec_masks)
+    gen = (gen_logprob(spec, g, X.unsqueeze(1)) * Mf.unsqueeze(1)).sum(-1)
+    prior = log_std_normal(Z).sum(-1)
+    if STL:
+        lq = stratified_mixture_logprob(Z, mu.detach(), sigma.detach(), logits.detach())
+    else:
+        lq = stratified_mixture_logprob(Z, mu, sigma, logits)
+    ratio = gen + prior - lq
+    per_b = (ratio * torch.softmax(logits, -1)).sum(-1).mean(0)
+    return per_b.mean(), per_b
+
+
+def mvb2_objectives(spec: ModelSpec, enc_params, dec_params, Xt, M, eps, *, STL=False,
+                    kl_analytic=False, enc_masks=None, dec_masks=None):
+    """vgiwae/models/mvbvae.py:67-139.  Xt [B,K,D] imputed data, M [B,K,D], eps [nz,B,K,Zd].
+    Returns (generator_obj [B,K], encoder_obj [B,K])."""
+    Mf = M.to(Xt.dtype)
+    p = _encode(spec, enc_params, Xt, M, enc_masks)                   # encoder sees imputed data
+    mu, sigma, _ = q_heads(spec, p)
+    Z = mu + sigma * eps
+    g = mlp_forward(dec_params, Z, spec.dec, dec_masks)
+    lp = gen_logprob(spec, g, Xt)                                     # [nz,B,K,D]
+    prior = log_std_normal(Z).sum(-1)
+    with torch.no_grad():
+        lmix = imputation_mixture_logprob(Z, mu, sigma)
+    gen_obj = ((lp * Mf).sum(-1) + prior - lmix).mean(0)
+    full = lp.sum(-1).mean(0)
+    if kl_analytic:
+        kl_neg = -(0.5 * (sigma ** 2 + mu ** 2 - 1 - torch.log(sigma ** 2))).sum(-1)
+    else:
+        if STL:
+            lq = log_normal(Z, mu.detach(), sigma.detach()).sum(-1)
+        else:
+            lq = log_normal(Z, mu, sigma).sum(-1)
+        kl_neg = (prior - lq).mean(0)
+    return gen_obj, kl_neg + full
+
+
+def cvi_objective(spec: ModelSpec, enc_params, dec_params, Xt, M, eps, *, STL=False,
+                  enc_masks=None, dec_masks=None):
+    """vgiwae/models/mvbvae.py:141-172."""
+    Mf = M.to(Xt.dtype)
+    p = _encode(spec, enc_params, Xt, M, enc_masks)
+    mu, sigma, _ = q_heads(spec, p)
+    Z = mu + sigma * eps
+    g = mlp_forward(dec_params, Z, spec.dec, dec_masks)
+    lp = gen_logprob(spec, g, Xt)
+    prior = log_std_normal(Z).sum(-1)
+    if STL:
+        lmix = imputation_mixture_logprob(Z, mu.detach(), sigma.detach())
+    else:
+        lmix = imputation_mixture_logprob(Z, mu, sigma)
+    return ((lp * Mf).sum(-1) + prior - lmix).mean(0)
+
+
+def mvb_objective(spec: ModelSpec, enc_params, dec_params, Xt, M, eps, *, STL=False,
+                  kl_analytic=False, enc_masks=None, dec_masks=None):
+    """Intended semantics of vgiwae/models/mvbvae.py:174-190 (complete-data ELBO per (b,k), M == 1).
+    The reference's own function raises AttributeError, so this one has no golden vector:
+    parity unpinned."""
+    p = _encode(spec, enc_params, Xt, M, enc_masks)
+    mu, sigma, _ = q_heads(spec, p)
+    Z = mu + sigma * eps
+    g = mlp_forward(dec_params, Z, spec.dec, dec_masks)
+    full = gen_logprob(spec, g, Xt).sum(-1)
+    if kl_analytic:
+        return full.mean(0) - (0.5 * (sigma ** 2 + mu ** 2 - 1 - torch.log(sigma ** 2))).sum(-1)
+    prior = log_std_normal(Z).sum(-1)
+    lq = log_normal(Z, mu.detach() if STL else mu, sigma.detach() if STL else sigma).sum(-1)
+    return (full + prior - lq).mean(0)
+
+
+# --------------------------------------------------------------------------------------
+# Imputation samplers
+# --------------------------------------------------------------------------------------
+def pseudo_gibbs_iteration(spec: ModelSpec, enc_params, dec_params, X, M, eps_z, noise_x,
+                           clip_min=None, clip_max=None, enc_masks=None, dec_masks=None):
+    """vgiwae/shared/vae_imputation.py:26-52.  X [B,K,D] current imputations, M [B,K,D]."""
+    with torch.no_grad():
+        p = _encode(spec, enc_params, X, M, enc_masks)
+        mu, sigma, _ = q_heads(spec, p)
+        Z = mu + eps_z * sigma
+        g = mlp_forward(dec_params, Z, spec.dec, dec_masks)
+        X_m = gen_sample(spec, g, noise_x)
+        if clip_min is not None:
+            X_m = torch.max(X_m, clip_min)
+        if clip_max is not None:
+            X_m = torch.min(X_m, clip_max)
+        bad = ~torch.isfinite(X_m)
+        X_m = torch.where(bad, X, X_m)
+        Mf = M.to(X.dtype)
+        return X * Mf + X_m * (1 - Mf)
+
+
+def softplus_inverse(x):
+    """vgiwae/utils/softplus_inverse.py:3-7."""
+    return x + torch.log(-torch.expm1(-x))
+
+
+def lair_iteration(spec: ModelSpec, enc_params, dec_params, X, M, eps_z, idx, noise_x, *,
+                   num_prior_replenish=0, enc_masks=None, dec_masks=None):
+    """One LAIR step with DMIS weights and global multinomial resampling
+    (vgiwae/shared/vae_imputation.py:177-201, 401-563).
+
+    X [B,K,D], M [B,K,D]; eps_z [I,B,K+r,Zd]; idx [K+r,B] int64 = the categorical draws over
+    the I*(K+r) proposals of each datapoint (proposal index i*(K+r)+k); noise_x [B,K,D].
+    Returns dict(X_out, log_w [I,B,K+r], Z [I,B,K+r,Zd], mis_params [B,K,P])."""
+    with torch.no_grad():
+        B, K, D = X.shape
+        r = num_prior_replenish
+        p = _encode(spec, enc_params, X, M, enc_masks)                # [B,K,P]
+        M1 = M[:, :1]
+        Xe = X
+        if r > 0:
+            Zd = spec.Zd
+            rep_mu = torch.zeros(B, r, Zd, dtype=X.dtype)
+            rep_raw = softplus_inverse(torch.ones(B, r, Zd, dtype=X.dtype) - spec.q_eps)
+            p = torch.cat([p[..., :2 * Zd], torch.cat([rep_mu, rep_raw], -1)], dim=1)
+            Xe = torch.cat([X, X[:, :1].expand(B, r, D)], dim=1)
+        mu, sigma, _ = q_heads(spec, p)
+        Z = mu + eps_z * sigma                                        # [I,B,K+r,Zd]
+        g = mlp_forward(dec_params, Z, spec.dec, dec_masks)           # [I,B,K+r,P]
+        gen = (gen_logprob(spec, g, Xe) * M1.to(X.dtype)).sum(-1)
+        prior = log_std_normal(Z).sum(-1)
+        lmix = imputation_mixture_logprob(Z, mu, sigma)
+        log_w = gen + prior - lmix                                    # [I,B,K+r]
+        I, Kp = log_w.shape[0], log_w.shape[2]
+        flat = g.permute(1, 0, 2, 3).reshape(B, I * Kp, -1)           # 'i b k p -> b (i k) p'
+        mis = flat[torch.arange(B), idx]                              # [K+r, B, P]
+        mis = mis.permute(1, 0, 2)[:, :K]
+        X_m = gen_sample(spec, mis, noise_x)
+        Mf = M.to(X.dtype)
+        X_out = X * Mf + X_m * (1 - Mf)
+        return dict(X_out=X_out, log_w=log_w, Z=Z, mis_params=mis)
+
+
+def inverse_cdf_categorical(log_w, u):
+    """Index draw used by the device sampler: smallest j with cumsum(softmax(log_w))[j] > u.
+    log_w [B, N], u [B, S] in [0,1) -> idx [B, S] int64.  (The reference draws with
+    torch.multinomial, whose random stream cannot be reproduced; the distribution is the same.)"""
+    p = torch.softmax(log_w.double(), dim=-1)
+    c = torch.cumsum(p, dim=-1)
+    idx = torch.searchsorted(c, u.double().clamp(max=1 - 1e-12), right=True)
+    return idx.clamp(max=log_w.shape[-1] - 1)
+
+
+# --------------------------------------------------------------------------------------
+# Imputation buffer (vgiwae/utils/imputation_distribution.py:77-79, 139-187)
+# --------------------------------------------------------------------------------------
+def buffer_init(data, K):
+    """data [N,D] -> data_imp [(N K), D], idx_imp [N,K] = n*K+k."""
+    N = data.shape[0]
+    return data.repeat_interleave(K, dim=0).clone(), torch.arange(N * K).reshape(N, K)
+
+
+def buffer_gather(data_imp, idx_imp, index, sampled_i=None):
+    """Rows of the buffer for dataset indices `index` [B] -> ([B,K',D], idx [B,K'])."""
+    idx = idx_imp[index]
+    if sampled_i is not None:
+        idx = idx[torch.arange(index.shape[0])[:, None], sampled_i]
+    return data_imp[idx.reshape(-1)].reshape(idx.shape[0], idx.shape[1], -1), idx
+
+
+def buffer_scatter(data_imp, idx, X_imp):
+    data_imp[idx.reshape(-1)] = X_imp.reshape(-1, X_imp.shape[-1])
+    return data_imp
+
+
+# --------------------------------------------------------------------------------------
+# K-sample log-likelihood estimate (vgiwae/test/refit_...py:189-222)
+# --------------------------------------------------------------------------------------
+def loglik_eval(spec: ModelSpec, enc_params, dec_params, X, M, eps, comp_idx=None):
+    """Per-datapoint log (1/K) sum_k w_k.  Standard: eps [1,K,B,Zd].  Stratified q sampled
+    without stratification (vgiwae/models/vae.py:298-301): comp_idx [1,K,B] int64 chooses
+    the component each z is drawn from, eps [1,K,B,Zd] is that component's noise."""
+    with torch.no_grad():
+        Mf = M.to(X.dtype)
+        p = _encode(spec, enc_params, X * Mf, M)
+        mu, sigma, logits = q_heads(spec, p)
+        if logits is None:
+            Z = mu + sigma * eps
+        else:
+            B = X.shape[0]
+            ar = torch.arange(B)
+            Z = mu[ar, comp_idx] + sigma[ar, comp_idx] * eps
+        g = mlp_forward(dec_params, Z, spec.dec)
+        log_w = smis_log_weights(spec, g, X, M, Z, mu, sigma, logits)
+        K = log_w.shape[1]
+        per_b = (torch.logsumexp(log_w, dim=1) - math.log(K)).mean(0)
+        return per_b.mean(), per_b

@@ -1,0 +1,121 @@
+"""Load a golden case (tests/golden/*.npz) back into specs, parameters and inputs.
+
+Small cases carry their inputs; full-width cases carry only a seed and are rebuilt with the
+recipes in oracle/recipes.py (the same recipes tools/golden_gen/make_golden.py used)."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from oracle.recipes import NetSpec, make_params, make_batch, make_noise
+from oracle.core import ModelSpec
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def names(prefix):
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith(prefix) and f.endswith(".npz"))
+
+
+def net_spec(arr, dropout=0.0):
+    i, o, nb, h = (int(v) for v in arr)
+    return NetSpec(i, o, nb, h, dropout=float(dropout))
+
+
+def stored_params(g, prefix, spec, seed):
+    key = f"{prefix}.initial_layer.weight"
+    if key in g:
+        out = OrderedDict()
+        for n in spec.layer_names():
+            out[n + ".weight"] = torch.from_numpy(g[f"{prefix}.{n}.weight"])
+            out[n + ".bias"] = torch.from_numpy(g[f"{prefix}.{n}.bias"])
+        return out
+    return make_params(spec, seed)
+
+
+def model_case(g):
+    """(ModelSpec, enc_params, dec_params) of an objective case."""
+    seed = int(g["seed"])
+    enc = net_spec(g["enc_spec"], g["enc_dropout"] if "enc_dropout" in g else 0.0)
+    dec = net_spec(g["dec_spec"], g["dec_dropout"] if "dec_dropout" in g else 0.0)
+    C = int(g["C"]) if "C" in g else 1
+    q = str(g["q_dist"]) if "q_dist" in g else ("stratified_with_eps" if "C" in g and "kind" not in g else "normal_with_eps")
+    if "kind" in g:
+        q = "stratified_with_eps" if str(g["kind"]) == "stratified" else "normal_with_eps"
+    spec = ModelSpec(D=int(g["D"]), Zd=int(g["Zd"]), enc=enc, dec=dec,
+                     gen_dist=str(g["gen_dist"]) if "gen_dist" in g else "normal_with_eps",
+                     q_dist=q, C=C,
+                     encoder_use_mis_mask=bool(g["mask_concat"]) if "mask_concat" in g else (enc.in_dim == 2 * int(g["D"])))
+    return spec, stored_params(g, "enc", enc, seed), stored_params(g, "dec", dec, seed + 1)
+
+
+def batch_of(g, binary=None):
+    seed = int(g["seed"])
+    if "X" in g:
+        return torch.from_numpy(g["X"]), torch.from_numpy(g["M"])
+    if binary is None:
+        binary = bool(g["binary"]) if "binary" in g else False
+    return make_batch(seed + 2, int(g["B"]), int(g["D"]), binary=binary)
+
+
+def eps_of(g, *shape):
+    if "eps" in g and g["eps"].size:
+        return torch.from_numpy(g["eps"])
+    return make_noise(int(g["seed"]) + 3, *shape)
+
+
+def dropout_masks(seed, spec: NetSpec, rows_shape):
+    if spec.dropout <= 0:
+        return None
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return [torch.from_numpy((rng.random(tuple(rows_shape) + (spec.hidden,)) >= spec.dropout))
+            for _ in range(spec.nb)]
+
+
+def imputed_batch(g, binary=None):
+    """Xt [B,K,D], Mk [B,K,D] of a DeMissVAE case."""
+    if "Xt" in g:
+        Xt = torch.from_numpy(g["Xt"])
+        M = torch.from_numpy(g["M"])
+        if M.dim() == 2:
+            M = M[:, None, :].expand_as(Xt).contiguous()
+        return Xt, M
+    seed, B, K, D = int(g["seed"]), int(g["B"]), int(g["K"]), int(g["D"])
+    if binary is None:
+        binary = bool(g["binary"]) if "binary" in g else False
+    X, M = make_batch(seed + 2, B, D, binary=binary)
+    fill, _ = make_batch(seed + 6, B * K, D, binary=binary)
+    Mk = M[:, None, :].expand(B, K, D).contiguous()
+    Xt = torch.where(Mk, X[:, None, :].expand(B, K, D), fill.reshape(B, K, D)).contiguous()
+    return Xt, Mk
+
+
+def check_grads(g, prefix, grads, rtol, atol, floor=2e-5):
+    """Compare a dict name -> gradient tensor with the digests stored under `prefix`.
+
+    Elementwise |got - ref| <= rtol*|ref| + max(atol, floor*max|ref|): entries that are sums of
+    cancelling fp32 terms cannot agree to a relative tolerance of their own (tiny) magnitude, so
+    the absolute part scales with the tensor's largest entry."""
+    checked = 0
+
+    def close(t, ref, what, scale=1.0):
+        ref = torch.from_numpy(ref).double()
+        a = max(atol, floor * float(ref.abs().max())) * scale
+        torch.testing.assert_close(t, ref, rtol=rtol, atol=a, msg=lambda m: f"{what}: {m}")
+
+    for n, t in grads.items():
+        t = t.detach().cpu().to(torch.float64)
+        if f"{prefix}.{n}.full" in g:
+            close(t, g[f"{prefix}.{n}.full"], f"{prefix}.{n}")
+            checked += 1
+        elif f"{prefix}.{n}.sub" in g:
+            close(t[::7, ::5], g[f"{prefix}.{n}.sub"], f"{prefix}.{n}.sub")
+            close(t.sum(1), g[f"{prefix}.{n}.rowsum"], f"{prefix}.{n}.rowsum")
+            close(t.sum(0), g[f"{prefix}.{n}.colsum"], f"{prefix}.{n}.colsum")
+            checked += 1
+    return checked

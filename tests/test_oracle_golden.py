@@ -1,0 +1,236 @@
+"""Pins the CPU oracle (oracle/core.py) to the golden vectors produced by running the reference.
+
+fp32 oracle vs fp32 reference outputs: bounds rel 1e-5, gradients rel 1e-4 (the tolerances the
+north-star states), with a small absolute floor for entries that are sums of cancelling terms.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import core
+from oracle.recipes import make_noise
+
+RT_B, RT_G, AT_G = 1e-5, 1e-4, 2e-6
+
+
+def _as_params(p, grad=True):
+    return {k: v.clone().requires_grad_(grad) for k, v in p.items()}
+
+
+def _grads(p):
+    return {k: v.grad for k, v in p.items() if v.grad is not None}
+
+
+# ------------------------------------------------------------------------------------- A2
+@pytest.mark.parametrize("name", gu.names("mlp_"))
+def test_mlp(name):
+    g = gu.load(name)
+    spec = gu.net_spec(g["spec"], g["dropout"])
+    seed, rows = int(g["seed"]), int(g["rows"])
+    params = _as_params(gu.stored_params(g, "p", spec, seed))
+    x = (torch.from_numpy(g["x"]) if "x" in g else make_noise(seed + 1, rows, spec.in_dim)).requires_grad_(True)
+    gy = torch.from_numpy(g["gy"]) if "gy" in g else make_noise(seed + 2, rows, spec.out_dim)
+    masks = gu.dropout_masks(seed + 3, spec, (rows,))
+    y = core.mlp_forward(params, x, spec, masks)
+    y.backward(gy)
+    torch.testing.assert_close(y.detach(), torch.from_numpy(g["y"]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(x.grad, torch.from_numpy(g["dx"]), rtol=RT_G, atol=AT_G)
+    assert gu.check_grads(g, "g", _grads(params), RT_G, AT_G) == 2 * (2 * spec.nb + 2)
+
+
+# ------------------------------------------------------------------------------------- A7
+@pytest.mark.parametrize("name", gu.names("iwae_"))
+def test_iwae(name):
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(g)
+    enc_p, dec_p = _as_params(enc_p), _as_params(dec_p)
+    X, M = gu.batch_of(g)
+    B, I, nz = int(g["B"]), int(g["I"]), int(g["nz"])
+    eps = gu.eps_of(g, nz, I, B, spec.Zd)
+    seed = int(g["seed"])
+    em = gu.dropout_masks(seed + 4, spec.enc, (B,))
+    dm = gu.dropout_masks(seed + 5, spec.dec, (nz, I, B))
+    bound, _ = core.estimate_iwelbo(spec, enc_p, dec_p, X, M, eps, STL=bool(g["STL"]), DREG=bool(g["DREG"]),
+                                    enc_masks=em, dec_masks=dm)
+    (-bound).backward()
+    np.testing.assert_allclose(bound.item(), float(g["bound"]), rtol=RT_B)
+    assert gu.check_grads(g, "genc", _grads(enc_p), RT_G, AT_G) > 0
+    assert gu.check_grads(g, "gdec", _grads(dec_p), RT_G, AT_G) > 0
+
+
+# ------------------------------------------------------------------------------------- A9
+@pytest.mark.parametrize("name", gu.names("vae_"))
+def test_vae(name):
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(g)
+    enc_p, dec_p = _as_params(enc_p), _as_params(dec_p)
+    X, M = gu.batch_of(g)
+    eps = gu.eps_of(g)
+    bound, _ = core.estimate_elbo(spec, enc_p, dec_p, X, M, eps, kl_analytic=bool(g["kl_analytic"]), STL=bool(g["STL"]))
+    (-bound).backward()
+    np.testing.assert_allclose(bound.item(), float(g["bound"]), rtol=RT_B)
+    assert gu.check_grads(g, "genc", _grads(enc_p), RT_G, AT_G) > 0
+    assert gu.check_grads(g, "gdec", _grads(dec_p), RT_G, AT_G) > 0
+
+
+# ------------------------------------------------------------------------------------- A8, A9
+@pytest.mark.parametrize("name", gu.names("miwae_") + gu.names("mvae_"))
+def test_multiple(name):
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(g)
+    enc_p, dec_p = _as_params(enc_p), _as_params(dec_p)
+    X, M = gu.batch_of(g)
+    B, I, nz, C = int(g["B"]), int(g["I"]), int(g["nz"]), int(g["C"])
+    if name.startswith("miwae"):
+        eps = gu.eps_of(g, nz, I, B, C, spec.Zd)
+        bound, _ = core.estimate_multiple_iwelbo(spec, enc_p, dec_p, X, M, eps, STL=bool(g["STL"]), looser=bool(g["looser"]))
+    else:
+        eps = gu.eps_of(g, nz, B, C, spec.Zd)
+        bound, _ = core.estimate_multiple_elbo(spec, enc_p, dec_p, X, M, eps, STL=bool(g["STL"]))
+    (-bound).backward()
+    np.testing.assert_allclose(bound.item(), float(g["bound"]), rtol=RT_B)
+    assert gu.check_grads(g, "genc", _grads(enc_p), RT_G, AT_G) > 0
+    assert gu.check_grads(g, "gdec", _grads(dec_p), RT_G, AT_G) > 0
+
+
+# ------------------------------------------------------------------------------------- A10, A11
+@pytest.mark.parametrize("name", gu.names("mvb_"))
+def test_mvb(name):
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(g)
+    enc_p, dec_p = _as_params(enc_p), _as_params(dec_p)
+    Xt, Mk = gu.imputed_batch(g)
+    B, K, nz = int(g["B"]), int(g["K"]), int(g["nz"])
+    eps = gu.eps_of(g, nz, B, K, spec.Zd)
+    STL = bool(g["STL"])
+    if str(g["objective"]) == "mvb2":
+        gen_obj, enc_obj = core.mvb2_objectives(spec, enc_p, dec_p, Xt, Mk, eps, STL=STL, kl_analytic=bool(g["kl_analytic"]))
+        torch.testing.assert_close(enc_obj.detach(), torch.from_numpy(g["enc_obj"]), rtol=RT_B, atol=1e-5)
+        (-gen_obj.mean()).backward(retain_graph=True, inputs=list(dec_p.values()))
+        (-enc_obj.mean()).backward(inputs=list(enc_p.values()))
+    else:
+        gen_obj = core.cvi_objective(spec, enc_p, dec_p, Xt, Mk, eps, STL=STL)
+        (-gen_obj.mean()).backward()
+    torch.testing.assert_close(gen_obj.detach(), torch.from_numpy(g["gen_obj"]), rtol=RT_B, atol=1e-5)
+    assert gu.check_grads(g, "genc", _grads(enc_p), RT_G, AT_G) > 0
+    assert gu.check_grads(g, "gdec", _grads(dec_p), RT_G, AT_G) > 0
+
+
+# ------------------------------------------------------------------------------------- A12
+@pytest.mark.parametrize("name", gu.names("pgibbs_normal"))
+def test_pseudo_gibbs_normal(name):
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(dict(g, gen_dist="normal", q_dist="normal", mask_concat=False))
+    clip = bool(g["clip"])
+    out = core.pseudo_gibbs_iteration(spec, enc_p, dec_p, torch.from_numpy(g["Xt"]), torch.from_numpy(g["M"]),
+                                      torch.from_numpy(g["eps_z"]), torch.from_numpy(g["eps_x"]),
+                                      clip_min=torch.from_numpy(g["clip_min"]) if clip else None,
+                                      clip_max=torch.from_numpy(g["clip_max"]) if clip else None)
+    torch.testing.assert_close(out, torch.from_numpy(g["X_new"]), rtol=1e-5, atol=1e-6)
+    M = torch.from_numpy(g["M"])
+    assert torch.equal(out[M], torch.from_numpy(g["Xt"])[M])          # observed entries untouched, bit-exact
+
+
+def test_pseudo_gibbs_bernoulli():
+    g = gu.load("pgibbs_bern_m1_p1")
+    spec, enc_p, dec_p = gu.model_case(dict(g, gen_dist="bern_m1_p1", q_dist="normal_with_eps", mask_concat=True))
+    X, M = torch.from_numpy(g["Xt"]), torch.from_numpy(g["M"])
+    for t in range(int(g["T"])):
+        X = core.pseudo_gibbs_iteration(spec, enc_p, dec_p, X, M, torch.from_numpy(g["eps_z"][t]),
+                                        torch.from_numpy(g["u_x"][t]))
+    assert torch.equal(X, torch.from_numpy(g["X_new"]))
+
+
+# ------------------------------------------------------------------------------------- A13
+@pytest.mark.parametrize("name", gu.names("lair_"))
+def test_lair(name):
+    g = gu.load(name)
+    q = str(g["q_dist"])
+    spec, enc_p, dec_p = gu.model_case(dict(g, gen_dist=q, q_dist=q, mask_concat=False))
+    X, M = torch.from_numpy(g["Xt"]), torch.from_numpy(g["M"])
+    T, r, K, B = int(g["T"]), int(g["r"]), int(g["K"]), int(g["B"])
+    Zs, lws = [], []
+    for t in range(T):
+        out = core.lair_iteration(spec, enc_p, dec_p, X, M, torch.from_numpy(g["eps_z"][t]),
+                                  torch.from_numpy(g[f"idx{t}"]), torch.from_numpy(g["eps_x"][t]),
+                                  num_prior_replenish=r)
+        X = out["X_out"]
+        Zs.append(out["Z"])
+        lws.append(out["log_w"])
+    if bool(g["final"]):
+        # vgiwae/shared/vae_imputation.py:675-694: re-draw K latents from all T*I*(K+r) proposals
+        Zall = torch.stack(Zs).permute(2, 0, 1, 3, 4).reshape(B, -1, spec.Zd)       # 't i b k d -> b (t i k) d'
+        idx = torch.from_numpy(g[f"idx{T}"])                                        # [K, B]
+        Z = Zall[torch.arange(B), idx].permute(1, 0, 2)
+        gp = core.mlp_forward(dec_p, Z, spec.dec)
+        X_m = core.gen_sample(spec, gp, torch.from_numpy(g["eps_x"][T]))
+        Mf = M.float()
+        X = X * Mf + X_m * (1 - Mf)
+    torch.testing.assert_close(X, torch.from_numpy(g["X_new"]), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------- A14
+def test_imputation_buffer():
+    g = gu.load("impbuffer")
+    K = int(g["K"])
+    X = torch.from_numpy(g["X"])
+    data_imp, idx_imp = core.buffer_init(X, K)
+    assert torch.equal(idx_imp, torch.from_numpy(g["idx_imp_table"]))
+    # the empirical initialisation draws with numpy's global RNG: take the reference's result as the state
+    data_imp = torch.from_numpy(g["after_init"]).clone()
+    bidx = torch.from_numpy(g["bidx"])
+    gx, gi = core.buffer_gather(data_imp, idx_imp, bidx)
+    assert torch.equal(gx, torch.from_numpy(g["gather_X"]))
+    assert torch.equal(gi, torch.from_numpy(g["gather_idx_imp"]))
+    Mk = torch.from_numpy(g["gather_M"])
+    X_imp = torch.where(Mk, gx, torch.from_numpy(g["new_vals"]))
+    data_imp = core.buffer_scatter(data_imp, gi, X_imp)
+    assert torch.equal(data_imp, torch.from_numpy(g["after_set"]))
+    # sub-sampled gather: indices are the reference's multinomial draws; rows must be the matching buffer rows
+    sub_idx = torch.from_numpy(g["sub_idx_imp"])
+    assert torch.equal(data_imp[sub_idx.reshape(-1)].reshape(sub_idx.shape[0], sub_idx.shape[1], -1),
+                       torch.from_numpy(g["sub_X"]))
+
+
+# ------------------------------------------------------------------------------------- A15
+@pytest.mark.parametrize("name", gu.names("loglik_"))
+def test_loglik(name):
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(g)
+    X, M = torch.from_numpy(g["X"]), torch.from_numpy(g["M"])
+    B, K, C = int(g["B"]), int(g["K"]), int(g["C"])
+    seed = int(g["seed"])
+    if str(g["kind"]) == "standard":
+        eps = gu.eps_of(g, 1, K, B, spec.Zd)
+        val, _ = core.loglik_eval(spec, enc_p, dec_p, X, M, eps)
+    else:
+        comp = torch.from_numpy(g["comp_idx"])
+        if g["eps"].size:
+            eps = torch.from_numpy(g["eps"])
+        else:
+            eps_all = make_noise(seed + 3, 1, K, B, C, spec.Zd)
+            eps = torch.gather(eps_all, 3, comp[..., None, None].expand(1, K, B, 1, spec.Zd)).squeeze(3)
+        val, _ = core.loglik_eval(spec, enc_p, dec_p, X, M, eps, comp_idx=comp)
+    # final log-likelihoods must agree within 0.01 nats; the restatement is far tighter than that
+    np.testing.assert_allclose(val.item(), float(g["est_loglik"]), rtol=RT_B, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------- A6 known answer
+def test_dmis_known_answer():
+    g = gu.load("dmis_known_answer")
+    X, Z = torch.from_numpy(g["X"]), torch.from_numpy(g["Z"])
+    gm, gs = torch.from_numpy(g["gen_mean"]), torch.from_numpy(g["gen_scale"])
+    vm, vs = torch.from_numpy(g["var_mean"]), torch.from_numpy(g["var_scale"])
+    gen = core.log_normal(X, gm, gs).sum(-1)
+    prior = core.log_std_normal(Z).sum(-1)
+    lw = gen + prior - core.imputation_mixture_logprob(Z, vm, vs)
+    torch.testing.assert_close(lw, torch.from_numpy(g["log_w"]), rtol=1e-5, atol=1e-5)
+    # independent brute force over (z, i, b, k), the pattern of vgiwae/shared/iwae.py:157-181, in fp64
+    NZ, I, B, K, _ = Z.shape
+    Zd, Xd = Z.double(), X.double()
+    for z, i, b, k in [(0, 0, 0, 0), (2, 5, 6, 4), (1, 3, 2, 1)]:
+        comps = torch.stack([core.log_normal(Zd[z, i, b, k], vm[b, k2].double(), vs[b, k2].double()).sum() for k2 in range(K)])
+        ref = (core.log_normal(Xd[b, k], gm[z, i, b, k].double(), gs[z, i, b, k].double()).sum()
+               + core.log_std_normal(Zd[z, i, b, k]).sum() - (torch.logsumexp(comps, 0) - np.log(K)))
+        np.testing.assert_allclose(lw[z, i, b, k].item(), ref.item(), rtol=2e-5, atol=2e-5)

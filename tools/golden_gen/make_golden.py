@@ -1,0 +1,682 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Build-container only: needs the reference checkout (default /root/reference), which is
+imported, never copied.  `pytorch_lightning` is not installed, so the plumbing-only
+stand-in under tools/golden_gen/pl_stub is put on sys.path; every number written here is
+computed by the reference's own functions (vgiwae.models.*, vgiwae.shared.*,
+vgiwae.utils.imputation_distribution, vgiwae.data.*_missingness_provider).
+
+Random draws are injected rather than recorded: the three sampling primitives that
+torch.distributions uses (`_standard_normal` for rsample, `torch.normal` for sample,
+`torch.bernoulli`) and `F.dropout` are replaced for the duration of a case by functions
+that consume prepared noise tensors, with the same arithmetic the stock primitive applies
+to its own noise (loc + eps*scale, u < p, x*mask/(1-p)).  Categorical draws are taken from
+torch itself and recorded.
+
+Usage:  python tools/golden_gen/make_golden.py [--ref /root/reference] [--out tests/golden]
+"""
+import argparse
+import contextlib
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+from oracle.recipes import NetSpec, make_params, make_batch, make_noise, make_uniform  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- noise injection
+class Noise:
+    """Queues of prepared noise; installed over torch's sampling primitives."""
+
+    def __init__(self):
+        self.normal = []      # standard normal tensors, consumed by rsample / sample
+        self.uniform = []     # U[0,1) tensors, consumed by torch.bernoulli
+        self.dropout = []     # 0/1 keep masks
+        self.cat_draws = []   # recorded Categorical.sample outputs
+        self.normal_shapes = []
+
+    def _pop_normal(self, shape):
+        t = self.normal.pop(0)
+        assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+        self.normal_shapes.append(tuple(shape))
+        return t
+
+
+@contextlib.contextmanager
+def injected(noise: Noise):
+    import torch.distributions.normal as tdn
+    import torch.nn.functional as F
+    from torch.distributions import Categorical
+
+    orig = (tdn._standard_normal, torch.normal, torch.bernoulli, F.dropout, Categorical.sample)
+
+    def std_normal(shape, dtype, device):
+        return noise._pop_normal(shape).to(dtype)
+
+    def normal(mean, std, *a, **k):
+        return mean + std * noise._pop_normal(mean.shape).to(mean.dtype)
+
+    def bernoulli(p, *a, **k):
+        u = noise.uniform.pop(0)
+        assert u.shape == p.shape, (u.shape, p.shape)
+        return (u < p).to(p.dtype)
+
+    def dropout(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        m = noise.dropout.pop(0)
+        assert m.shape == x.shape, (m.shape, x.shape)
+        return x * m.to(x.dtype) / (1.0 - p)
+
+    def cat_sample(self, sample_shape=torch.Size()):
+        out = orig[4](self, sample_shape)
+        noise.cat_draws.append(out.clone())
+        return out
+
+    tdn._standard_normal = std_normal
+    torch.normal = normal
+    torch.bernoulli = bernoulli
+    F.dropout = dropout
+    Categorical.sample = cat_sample
+    try:
+        yield noise
+    finally:
+        tdn._standard_normal, torch.normal, torch.bernoulli, F.dropout, Categorical.sample = orig
+
+
+# ----------------------------------------------------------------------------- helpers
+def ref_net(spec: NetSpec, params):
+    from vgiwae.shared.neural_nets import ResidualFCNetwork
+    net = ResidualFCNetwork(spec.in_dim, spec.out_dim, spec.nb, spec.hidden,
+                            activation=spec.act, dropout_probability=spec.dropout)
+    net.load_state_dict({k: v.clone() for k, v in params.items()})
+    return net
+
+
+def dist_enum(name, C=1):
+    from vgiwae.shared.vae_enums import DISTRIBUTION
+    if name.startswith("stratified"):
+        suffix = "_with_eps" if name.endswith("with_eps") else ""
+        return DISTRIBUTION[f"stratified_mixture{C}_normal{suffix}"]
+    return DISTRIBUTION[name]
+
+
+def digest(g: torch.Tensor):
+    """Full tensor when small, otherwise row/column sums plus a strided sub-sample."""
+    g = g.detach()
+    if g.numel() <= 8192:
+        return {"full": g.numpy()}
+    return {"rowsum": g.sum(1).numpy(), "colsum": g.sum(0).numpy(), "sub": g[::7, ::5].numpy()}
+
+
+def grads_to_dict(prefix, net):
+    out = {}
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        for k, v in digest(p.grad).items():
+            out[f"{prefix}.{n}.{k}"] = v
+    return out
+
+
+def params_to_dict(prefix, params):
+    return {f"{prefix}.{k}": v.numpy() for k, v in params.items()}
+
+
+def save(out_dir, name, **arrays):
+    path = os.path.join(out_dir, name + ".npz")
+    clean = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        clean[k] = np.asarray(v)
+    np.savez_compressed(path, **clean)
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def build_model(cls_name, enc_spec, dec_spec, enc_p, dec_p, gen_dist, q_dist, C=1, **kw):
+    import vgiwae.models as models
+    cls = getattr(models, cls_name)
+    model = cls(generator_network=ref_net(dec_spec, dec_p),
+                generator_distribution=dist_enum(gen_dist),
+                var_latent_network=ref_net(enc_spec, enc_p),
+                var_latent_distribution=dist_enum(q_dist, C),
+                num_latent_samples=kw.pop("num_latent_samples", 1),
+                lr_generator=1e-3, lr_latent=1e-3, **kw)
+    model.train()
+    return model
+
+
+def dropout_masks(seed, spec: NetSpec, rows_shape):
+    if spec.dropout <= 0:
+        return []
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return [torch.from_numpy((rng.random(tuple(rows_shape) + (spec.hidden,)) >= spec.dropout))
+            for _ in range(spec.nb)]
+
+
+# ----------------------------------------------------------------------------- cases
+def case_mlp(out, name, spec: NetSpec, rows, seed, store_params=True):
+    """A2: ResidualFCNetwork forward + backward against a fixed upstream gradient."""
+    params = make_params(spec, seed)
+    net = ref_net(spec, params)
+    net.train()
+    x = make_noise(seed + 1, rows, spec.in_dim).requires_grad_(True)
+    gy = make_noise(seed + 2, rows, spec.out_dim)
+    noise = Noise()
+    masks = dropout_masks(seed + 3, spec, (rows,))
+    noise.dropout = [m.clone() for m in masks]
+    with injected(noise):
+        y = net(x)
+    y.backward(gy)
+    arrays = dict(seed=seed, rows=rows, spec=np.array([spec.in_dim, spec.out_dim, spec.nb, spec.hidden]),
+                  dropout=spec.dropout, y=y, dx=x.grad)
+    if store_params:
+        arrays.update(params_to_dict("p", params))
+        arrays.update(x=x, gy=gy)
+        for b, m in enumerate(masks):
+            arrays[f"mask{b}"] = m
+    arrays.update(grads_to_dict("g", net))
+    save(out, name, **arrays)
+
+
+def _iwae_like(out, name, *, D, Zd, enc_spec, dec_spec, B, I, nz, seed, gen_dist, q_dist,
+               mask_concat, STL, DREG, binary=False, store_inputs=True):
+    from vgiwae.models.iwae import estimate_iwelbo
+    enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+    model = build_model("IWAE", enc_spec, dec_spec, enc_p, dec_p, gen_dist, q_dist,
+                        encoder_use_mis_mask=mask_concat, var_latent_STL=STL, var_latent_DREG=DREG,
+                        num_importance_samples=I, num_latent_samples=nz)
+    X, M = make_batch(seed + 2, B, D, binary=binary)
+    eps = make_noise(seed + 3, nz, I, B, Zd)
+    noise = Noise()
+    noise.normal = [eps.clone()]
+    noise.dropout = ([m for m in dropout_masks(seed + 4, enc_spec, (B,))]
+                     + [m for m in dropout_masks(seed + 5, dec_spec, (nz, I, B))])
+    with injected(noise):
+        bound = estimate_iwelbo(model, (X, M), var_latent_STL=STL, var_latent_DREG=DREG,
+                                num_latent_samples=nz, num_importance_samples=I)
+    (-bound).backward()
+    arrays = dict(seed=seed, B=B, I=I, nz=nz, D=D, Zd=Zd, STL=STL, DREG=DREG, mask_concat=mask_concat,
+                  gen_dist=gen_dist, q_dist=q_dist, binary=binary,
+                  enc_spec=np.array([enc_spec.in_dim, enc_spec.out_dim, enc_spec.nb, enc_spec.hidden]),
+                  dec_spec=np.array([dec_spec.in_dim, dec_spec.out_dim, dec_spec.nb, dec_spec.hidden]),
+                  enc_dropout=enc_spec.dropout, dec_dropout=dec_spec.dropout,
+                  bound=bound)
+    if store_inputs:
+        arrays.update(X=X, M=M, eps=eps)
+        arrays.update(params_to_dict("enc", enc_p))
+        arrays.update(params_to_dict("dec", dec_p))
+    arrays.update(grads_to_dict("genc", model.var_latent_network))
+    arrays.update(grads_to_dict("gdec", model.generator_network))
+    save(out, name, **arrays)
+
+
+def cases_iwae(out):
+    enc_s = lambda i, o, h=32, nb=2, p=0.0: NetSpec(i, o, nb, h, dropout=p)
+    k = 0
+    for STL, DREG, tag in [(True, False, "stl"), (False, True, "dreg"), (False, False, "plain")]:
+        for q in ["normal", "normal_with_eps"]:
+            for mc in [True, False]:
+                D, Zd = 8, 16
+                _iwae_like(out, f"iwae_{tag}_{q}_{'mc' if mc else 'nomc'}", D=D, Zd=Zd,
+                           enc_spec=enc_s(2 * D if mc else D, 2 * Zd), dec_spec=enc_s(Zd, 2 * D),
+                           B=16, I=5, nz=2 if tag == "plain" else 1, seed=1000 + 10 * k,
+                           gen_dist=q, q_dist=q, mask_concat=mc, STL=STL, DREG=DREG)
+                k += 1
+    # dropout inside the residual blocks (every MiniBooNE network uses p = 0.5)
+    _iwae_like(out, "iwae_stl_dropout", D=8, Zd=16, enc_spec=enc_s(16, 32, p=0.5), dec_spec=enc_s(16, 16, p=0.5),
+               B=16, I=5, nz=1, seed=1300, gen_dist="normal_with_eps", q_dist="normal_with_eps",
+               mask_concat=True, STL=True, DREG=False)
+    # Bernoulli decoders, 784-d
+    _iwae_like(out, "iwae_stl_bern_m1_p1_784", D=784, Zd=50, enc_spec=enc_s(784 * 2, 100), dec_spec=enc_s(50, 784),
+               B=6, I=5, nz=1, seed=1400, gen_dist="bern_m1_p1", q_dist="normal_with_eps",
+               mask_concat=True, STL=True, DREG=False, binary=True, store_inputs=False)
+    # UCI-gas shapes at full width (B=512, h=256): inputs rebuilt from the seed recipe
+    _iwae_like(out, "iwae_gas_full", D=8, Zd=16, enc_spec=NetSpec(16, 32, 2, 256), dec_spec=NetSpec(16, 16, 2, 256),
+               B=512, I=5, nz=1, seed=20220118, gen_dist="normal_with_eps", q_dist="normal_with_eps",
+               mask_concat=True, STL=True, DREG=False, store_inputs=False)
+
+
+def cases_vae(out):
+    from vgiwae.models.vae import estimate_elbo
+    D, Zd, B = 8, 16, 16
+    k = 0
+    for kl_analytic, STL, nz, tag in [(True, False, 3, "analytic"), (False, False, 2, "mc"), (False, True, 2, "mc_stl")]:
+        seed = 2000 + 10 * k
+        k += 1
+        enc_spec, dec_spec = NetSpec(2 * D, 2 * Zd, 2, 32), NetSpec(Zd, 2 * D, 2, 32)
+        enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+        model = build_model("VAE", enc_spec, dec_spec, enc_p, dec_p, "normal_with_eps", "normal_with_eps",
+                            encoder_use_mis_mask=True, var_latent_STL=STL, kl_analytic=kl_analytic,
+                            num_latent_samples=nz)
+        X, M = make_batch(seed + 2, B, D)
+        eps = make_noise(seed + 3, nz, B, Zd)
+        noise = Noise()
+        noise.normal = [eps.clone()]
+        with injected(noise):
+            bound = estimate_elbo(model, (X, M), kl_analytic=kl_analytic, var_latent_STL=STL, num_latent_samples=nz)
+        (-bound).backward()
+        arrays = dict(seed=seed, B=B, nz=nz, D=D, Zd=Zd, STL=STL, kl_analytic=kl_analytic, bound=bound,
+                      X=X, M=M, eps=eps, enc_spec=np.array([2 * D, 2 * Zd, 2, 32]), dec_spec=np.array([Zd, 2 * D, 2, 32]))
+        arrays.update(params_to_dict("enc", enc_p))
+        arrays.update(params_to_dict("dec", dec_p))
+        arrays.update(grads_to_dict("genc", model.var_latent_network))
+        arrays.update(grads_to_dict("gdec", model.generator_network))
+        save(out, f"vae_{tag}", **arrays)
+
+
+def _multiple(out, name, *, cls, D, Zd, C, enc_spec, dec_spec, B, I, nz, seed, STL, looser=False, store_inputs=True):
+    enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+    kw = dict(encoder_use_mis_mask=True, var_latent_STL=STL, num_latent_samples=nz)
+    if cls == "MultipleIWAE":
+        kw.update(num_importance_samples_for_each_component=I, use_looser_bound=looser)
+    else:
+        kw.update(kl_analytic=False)
+    model = build_model(cls, enc_spec, dec_spec, enc_p, dec_p, "normal_with_eps", "stratified_with_eps", C=C, **kw)
+    X, M = make_batch(seed + 2, B, D)
+    noise = Noise()
+    if cls == "MultipleIWAE":
+        from vgiwae.models.multiple_iwae import estimate_multiple_iwelbo
+        eps = make_noise(seed + 3, nz, I, B, C, Zd)
+        noise.normal = [eps.clone()]
+        with injected(noise):
+            bound = estimate_multiple_iwelbo(model, (X, M), var_latent_STL=STL, num_latent_samples=nz,
+                                             num_importance_samples_for_each_component=I, use_looser_bound=looser)
+    else:
+        from vgiwae.models.multiple_vae import estimate_multiple_elbo
+        eps = make_noise(seed + 3, nz, B, C, Zd)
+        noise.normal = [eps.clone()]
+        model.hparams["log_var_distribution_mixture_component_weights_epoch_frequency"] = -1
+        with injected(noise):
+            bound = estimate_multiple_elbo(model, (X, M), kl_analytic=False, var_latent_STL=STL, num_latent_samples=nz)
+    (-bound).backward()
+    arrays = dict(seed=seed, B=B, I=I, nz=nz, D=D, Zd=Zd, C=C, STL=STL, looser=looser, bound=bound,
+                  enc_spec=np.array([enc_spec.in_dim, enc_spec.out_dim, enc_spec.nb, enc_spec.hidden]),
+                  dec_spec=np.array([dec_spec.in_dim, dec_spec.out_dim, dec_spec.nb, dec_spec.hidden]))
+    if store_inputs:
+        arrays.update(X=X, M=M, eps=eps)
+        arrays.update(params_to_dict("enc", enc_p))
+        arrays.update(params_to_dict("dec", dec_p))
+    arrays.update(grads_to_dict("genc", model.var_latent_network))
+    arrays.update(grads_to_dict("gdec", model.generator_network))
+    save(out, name, **arrays)
+
+
+def cases_multiple(out):
+    D, Zd = 21, 16
+    k = 0
+    for C in (1, 5):
+        P = 2 * Zd * C + C
+        for STL in (True, False):
+            for looser in (False, True):
+                _multiple(out, f"miwae_C{C}_{'stl' if STL else 'plain'}_{'looser' if looser else 'tight'}",
+                          cls="MultipleIWAE", D=D, Zd=Zd, C=C, enc_spec=NetSpec(2 * D, P, 2, 32),
+                          dec_spec=NetSpec(Zd, 2 * D, 2, 32), B=12, I=2 if looser else 1, nz=1,
+                          seed=3000 + 10 * k, STL=STL, looser=looser)
+                k += 1
+            _multiple(out, f"mvae_C{C}_{'stl' if STL else 'plain'}", cls="MultipleVAE", D=D, Zd=Zd, C=C,
+                      enc_spec=NetSpec(2 * D, P, 2, 32), dec_spec=NetSpec(Zd, 2 * D, 2, 32), B=12, I=1, nz=2,
+                      seed=3000 + 10 * k, STL=STL)
+            k += 1
+    # HEPMASS shapes at full width
+    _multiple(out, "miwae_hepmass_full", cls="MultipleIWAE", D=21, Zd=16, C=5,
+              enc_spec=NetSpec(42, 165, 2, 256), dec_spec=NetSpec(16, 42, 2, 256), B=512, I=1, nz=1,
+              seed=20220119, STL=True, store_inputs=False)
+
+
+def _mvb(out, name, *, D, Zd, K, enc_spec, dec_spec, B, nz, seed, objective, STL, kl_analytic=False,
+         gen_dist="normal", q_dist="normal", mask_concat=False, binary=False, store_inputs=True):
+    from vgiwae.models.mvbvae import MVB_OBJECTIVE
+    enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+    model = build_model("MVBVAE", enc_spec, dec_spec, enc_p, dec_p, gen_dist, q_dist,
+                        encoder_use_mis_mask=mask_concat, var_latent_STL=STL, kl_analytic=kl_analytic,
+                        num_latent_samples=nz, mvb_objective=MVB_OBJECTIVE[objective])
+    X, M = make_batch(seed + 2, B, D, binary=binary)
+    # imputed copies: observed entries kept, missing ones filled per imputation
+    fill, _ = make_batch(seed + 6, B * K, D, binary=binary)
+    Mk = M[:, None, :].expand(B, K, D).contiguous()
+    Xt = torch.where(Mk, X[:, None, :].expand(B, K, D), fill.reshape(B, K, D)).contiguous()
+    eps = make_noise(seed + 3, nz, B, K, Zd)
+    noise = Noise()
+    noise.normal = [eps.clone()]
+    arrays = dict(seed=seed, B=B, K=K, nz=nz, D=D, Zd=Zd, STL=STL, kl_analytic=kl_analytic, objective=objective,
+                  gen_dist=gen_dist, q_dist=q_dist, mask_concat=mask_concat, binary=binary,
+                  enc_spec=np.array([enc_spec.in_dim, enc_spec.out_dim, enc_spec.nb, enc_spec.hidden]),
+                  dec_spec=np.array([dec_spec.in_dim, dec_spec.out_dim, dec_spec.nb, dec_spec.hidden]))
+    enc, dec = model.var_latent_network, model.generator_network
+    with injected(noise):
+        if objective == "mvb2":
+            gen_obj, enc_obj = model.estimate_mvb2_objectives(Xt, Mk)
+        else:
+            gen_obj = model.estimate_cvi_objective(Xt, Mk)
+            enc_obj = None
+    arrays["gen_obj"] = gen_obj
+    if objective == "mvb2":
+        arrays["enc_obj"] = enc_obj
+        # the two backward calls of vgiwae/shared/mvb2_manual_optimisation.py:6-8
+        (-gen_obj.mean()).backward(retain_graph=True, inputs=list(dec.parameters()))
+        (-enc_obj.mean()).backward(inputs=list(enc.parameters()))
+    else:
+        (-gen_obj.mean()).backward()
+    if store_inputs:
+        arrays.update(X=X, M=M, Xt=Xt, eps=eps)
+        arrays.update(params_to_dict("enc", enc_p))
+        arrays.update(params_to_dict("dec", dec_p))
+    arrays.update(grads_to_dict("genc", enc))
+    arrays.update(grads_to_dict("gdec", dec))
+    save(out, name, **arrays)
+
+
+def cases_mvb(out):
+    D, Zd = 5, 2
+    k = 0
+    for objective in ("mvb2", "cvi"):
+        for K in (1, 5):
+            for STL in (True, False):
+                _mvb(out, f"mvb_{objective}_K{K}_{'stl' if STL else 'plain'}", D=D, Zd=Zd, K=K,
+                     enc_spec=NetSpec(D, 2 * Zd, 2, 32), dec_spec=NetSpec(Zd, 2 * D, 2, 32), B=10, nz=2,
+                     seed=4000 + 10 * k, objective=objective, STL=STL)
+                k += 1
+    _mvb(out, "mvb_mvb2_K5_analytic", D=D, Zd=Zd, K=5, enc_spec=NetSpec(D, 2 * Zd, 2, 32),
+         dec_spec=NetSpec(Zd, 2 * D, 2, 32), B=10, nz=1, seed=4200, objective="mvb2", STL=False, kl_analytic=True)
+    # Bernoulli{-1,+1} decoder with mask-concat encoder (MNIST / Omniglot objective shapes)
+    _mvb(out, "mvb_mvb2_K5_bern784", D=784, Zd=50, K=5, enc_spec=NetSpec(2 * 784, 100, 1, 32),
+         dec_spec=NetSpec(50, 784, 1, 32), B=4, nz=1, seed=4300, objective="mvb2", STL=True,
+         gen_dist="bern_m1_p1", q_dist="normal_with_eps", mask_concat=True, binary=True, store_inputs=False)
+    # toy MoG2-large shapes at full width
+    _mvb(out, "mvb_toy_full", D=5, Zd=2, K=5, enc_spec=NetSpec(5, 4, 3, 200), dec_spec=NetSpec(2, 10, 3, 200),
+         B=64, nz=1, seed=20220120, objective="mvb2", STL=True, store_inputs=False)
+
+
+class _Duck:
+    """What the reference's samplers need from `model` is exactly these five names."""
+    pass
+
+
+def _sampler_model(enc_spec, dec_spec, enc_p, dec_p, gen_dist, q_dist, mask_concat):
+    # a real reference VAE object: the samplers call its predict_var_latent_params /
+    # create_distribution / generator_network / get_prior / hparams
+    return build_model("VAE", enc_spec, dec_spec, enc_p, dec_p, gen_dist, q_dist,
+                       encoder_use_mis_mask=mask_concat, kl_analytic=False)
+
+
+def cases_samplers(out):
+    from vgiwae.shared.vae_imputation import VAESampler_PseudoGibbs, VAESampler_LAIR, pseudo_gibbs_iteration
+    # ---- pseudo-Gibbs, Gaussian decoder, with clamping and a forced non-finite draw
+    D, Zd, B, K = 5, 2, 12, 5
+    seed = 5000
+    enc_spec, dec_spec = NetSpec(D, 2 * Zd, 2, 32), NetSpec(Zd, 2 * D, 2, 32)
+    enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+    model = _sampler_model(enc_spec, dec_spec, enc_p, dec_p, "normal", "normal", False)
+    X, M = make_batch(seed + 2, B, D)
+    fill, _ = make_batch(seed + 6, B * K, D)
+    Mk = M[:, None, :].expand(B, K, D).contiguous()
+    Xt = torch.where(Mk, X[:, None, :].expand(B, K, D), fill.reshape(B, K, D)).contiguous()
+    for tag, clip in (("noclip", False), ("clip", True)):
+        eps_z = make_noise(seed + 3, B, K, Zd)
+        eps_x = make_noise(seed + 4, B, K, D)
+        if clip:
+            eps_x[0, 0, :] = float("inf")          # forces the non-finite fallback
+            eps_x[1, 2, 3] = float("nan")
+        cmin = torch.full((D,), -0.75)
+        cmax = torch.full((D,), 0.5)
+        noise = Noise()
+        noise.normal = [eps_z.clone(), eps_x.clone()]
+        with injected(noise), torch.inference_mode():
+            X_new = pseudo_gibbs_iteration(model, Xt.clone(), Mk, clip_values_min=cmin if clip else None,
+                                           clip_values_max=cmax if clip else None)
+        arrays = dict(seed=seed, D=D, Zd=Zd, B=B, K=K, clip=clip, Xt=Xt, M=Mk, eps_z=eps_z, eps_x=eps_x,
+                      clip_min=cmin, clip_max=cmax, X_new=X_new,
+                      enc_spec=np.array([D, 2 * Zd, 2, 32]), dec_spec=np.array([Zd, 2 * D, 2, 32]))
+        arrays.update(params_to_dict("enc", enc_p))
+        arrays.update(params_to_dict("dec", dec_p))
+        save(out, f"pgibbs_normal_{tag}", **arrays)
+
+    # ---- pseudo-Gibbs, Bernoulli{-1,+1} decoder with mask-concat encoder, 2 iterations via the sampler class
+    D2, Zd2, B2, K2 = 36, 8, 6, 5
+    seed = 5100
+    enc_spec2, dec_spec2 = NetSpec(2 * D2, 2 * Zd2, 1, 32), NetSpec(Zd2, D2, 1, 32)
+    enc_p2, dec_p2 = make_params(enc_spec2, seed), make_params(dec_spec2, seed + 1)
+    model2 = _sampler_model(enc_spec2, dec_spec2, enc_p2, dec_p2, "bern_m1_p1", "normal_with_eps", True)
+    X2, M2 = make_batch(seed + 2, B2, D2, binary=True)
+    fill2, _ = make_batch(seed + 6, B2 * K2, D2, binary=True)
+    Mk2 = M2[:, None, :].expand(B2, K2, D2).contiguous()
+    Xt2 = torch.where(Mk2, X2[:, None, :].expand(B2, K2, D2), fill2.reshape(B2, K2, D2)).contiguous()
+    T = 2
+    eps_z = [make_noise(seed + 10 + t, B2, K2, Zd2) for t in range(T)]
+    u_x = [make_uniform(seed + 20 + t, B2, K2, D2) for t in range(T)]
+    noise = Noise()
+    noise.normal = [e.clone() for e in eps_z]
+    noise.uniform = [u.clone() for u in u_x]
+    sampler = VAESampler_PseudoGibbs(num_iterations=T)
+    with injected(noise), torch.inference_mode():
+        X_new = sampler(Xt2.clone(), Mk2, model=model2)
+    arrays = dict(seed=seed, D=D2, Zd=Zd2, B=B2, K=K2, T=T, Xt=Xt2, M=Mk2, X_new=X_new,
+                  eps_z=torch.stack(eps_z), u_x=torch.stack(u_x),
+                  enc_spec=np.array([2 * D2, 2 * Zd2, 1, 32]), dec_spec=np.array([Zd2, D2, 1, 32]))
+    arrays.update(params_to_dict("enc", enc_p2))
+    arrays.update(params_to_dict("dec", dec_p2))
+    save(out, "pgibbs_bern_m1_p1", **arrays)
+
+    # ---- LAIR: dmis weights, global multinomial resampling
+    for tag, I, r, T, final in (("r0_T1", 1, 0, 1, False), ("r1_T3_final", 2, 1, 3, True)):
+        seed = 5200 if r == 0 else 5300
+        q = "normal" if r == 0 else "normal_with_eps"
+        enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+        model = _sampler_model(enc_spec, dec_spec, enc_p, dec_p, q, q, False)
+        X, M = make_batch(seed + 2, B, D)
+        fill, _ = make_batch(seed + 6, B * K, D)
+        Mk = M[:, None, :].expand(B, K, D).contiguous()
+        Xt = torch.where(Mk, X[:, None, :].expand(B, K, D), fill.reshape(B, K, D)).contiguous()
+        eps_z = [make_noise(seed + 10 + t, I, B, K + r, Zd) for t in range(T)]
+        eps_x = [make_noise(seed + 20 + t, B, K, D) for t in range(T + (1 if final else 0))]
+        noise = Noise()
+        for t in range(T):
+            noise.normal += [eps_z[t].clone(), eps_x[t].clone()]
+        if final:
+            noise.normal.append(eps_x[T].clone())
+        sampler = VAESampler_LAIR(num_iterations=T, num_imp_samples=I, num_prior_replenish_proposals=r,
+                                  is_weights="dmis", resampling_scheme="global_resampling",
+                                  resample_final_imps=final)
+        with injected(noise), torch.inference_mode():
+            X_new = sampler(Xt.clone(), Mk, model=model)
+        arrays = dict(seed=seed, D=D, Zd=Zd, B=B, K=K, I=I, r=r, T=T, final=final, q_dist=q, Xt=Xt, M=Mk,
+                      X_new=X_new, eps_z=torch.stack(eps_z), eps_x=torch.stack(eps_x),
+                      enc_spec=np.array([D, 2 * Zd, 2, 32]), dec_spec=np.array([Zd, 2 * D, 2, 32]))
+        for t, d in enumerate(noise.cat_draws):
+            arrays[f"idx{t}"] = d
+        arrays.update(params_to_dict("enc", enc_p))
+        arrays.update(params_to_dict("dec", dec_p))
+        save(out, f"lair_{tag}", **arrays)
+
+
+def cases_buffer(out):
+    """A14: gather / scatter / sub-sampled gather on the reference's ImputationDistribution."""
+    from vgiwae.utils.imputation_distribution import ImputationDistribution, IMPUTATION_INIT
+    N, D, K, B = 23, 4, 5, 7
+    seed = 6000
+    X, M = make_batch(seed, N, D)
+    index = np.arange(N, dtype=np.int64)
+    # the reference's datasets hand numpy arrays to ImputationDistribution
+    dist = ImputationDistribution((X.numpy(), M.numpy(), index), target_idx=0, mis_idx=1, index_idx=2,
+                                  num_imputations=K, imputation_init=IMPUTATION_INIT("empirical"))
+    np.random.seed(seed)
+    dist.init_imputations()
+    after_init = dist.data_imp.clone()
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    bidx = torch.from_numpy(rng.permutation(N)[:B].astype(np.int64))
+    batch = (X[bidx], M[bidx], bidx)
+    g = dist.get_imputed_datapoints(batch)
+    new_vals = make_noise(seed + 2, B, K, D)
+    Mk = g[1]
+    X_imp = torch.where(Mk, g[0], new_vals)
+    dist.set_imputed_datapoints((X_imp,) + g[1:])
+    after_set = dist.data_imp.clone()
+    noise_seed = seed + 3
+    torch.manual_seed(noise_seed)
+    g2 = dist.get_imputed_datapoints(batch, num_imputations=3)
+    save(out, "impbuffer", N=N, D=D, K=K, B=B, X=X, M=M, bidx=bidx, after_init=after_init,
+         gather_X=g[0], gather_M=g[1], gather_index=g[2], gather_idx_imp=g[3], new_vals=new_vals,
+         after_set=after_set, sub_X=g2[0], sub_idx_imp=g2[3], idx_imp_table=dist.idx_imp)
+
+
+def cases_loglik(out):
+    """A15: RefitEncoderUsingIWAE.test_step, standard and stratified (sampled without stratification)."""
+    from vgiwae.test.refit_encoder_using_iwae_and_estimate_loglik import RefitEncoderUsingIWAE, RefitEncoderClass
+    for tag, K in (("K64", 64), ("K4096", 4096)):
+        for kind in ("standard", "stratified"):
+            D, Zd, B, C = 8, 16, 10, 5
+            seed = 7000 + (0 if kind == "standard" else 100) + K
+            if kind == "standard":
+                enc_spec, q, Cc = NetSpec(2 * D, 2 * Zd, 2, 32), "normal_with_eps", 1
+                cls = "IWAE"
+                kw = dict(num_importance_samples=5)
+            else:
+                enc_spec, q, Cc = NetSpec(2 * D, 2 * Zd * C + C, 2, 32), "stratified_with_eps", C
+                cls = "MultipleIWAE"
+                kw = dict(num_importance_samples_for_each_component=1)
+            dec_spec = NetSpec(Zd, 2 * D, 2, 32)
+            enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+            model = build_model(cls, enc_spec, dec_spec, enc_p, dec_p, "normal_with_eps", q, C=Cc,
+                                encoder_use_mis_mask=True, **kw)
+            model.eval()
+            refit = RefitEncoderUsingIWAE(RefitEncoderClass[kind], num_test_latent_samples=1,
+                                          num_test_importance_samples=K)
+            refit.set_model(model)
+            X, _ = make_batch(seed + 2, B, D)
+            M = torch.ones(B, D, dtype=torch.bool)      # total_miss_test: 0.0
+            logged = {}
+            refit.log = lambda name, v, **k: logged.__setitem__(name, v)
+            noise = Noise()
+            if kind == "standard":
+                eps = make_noise(seed + 3, 1, K, B, Zd)
+                noise.normal = [eps.clone()]
+            else:
+                eps_all = make_noise(seed + 3, 1, K, B, C, Zd)
+                noise.normal = [eps_all.clone()]
+            with injected(noise):
+                refit.test_step((X, M), 0)
+            arrays = dict(seed=seed, D=D, Zd=Zd, B=B, K=K, C=Cc, kind=kind, X=X, M=M,
+                          est_loglik=logged["est_loglik/test"],
+                          enc_spec=np.array([enc_spec.in_dim, enc_spec.out_dim, 2, 32]),
+                          dec_spec=np.array([Zd, 2 * D, 2, 32]))
+            if kind == "standard":
+                arrays["eps"] = eps if K <= 64 else np.zeros(0)
+            else:
+                comp = noise.cat_draws[0]                                   # [1,K,B]
+                gathered = torch.gather(eps_all, 3, comp[..., None, None].expand(1, K, B, 1, Zd)).squeeze(3)
+                arrays["comp_idx"] = comp
+                arrays["eps"] = gathered if K <= 64 else np.zeros(0)
+            arrays.update(params_to_dict("enc", enc_p))
+            arrays.update(params_to_dict("dec", dec_p))
+            save(out, f"loglik_{kind}_{tag}", **arrays)
+
+
+def cases_masks(out, ref):
+    """A0: missingness masks, fully-missing filter and index wrapper (loaded by file path because the
+    reference's vgiwae.data package __init__ needs torchvision)."""
+    def load(fname, mod):
+        spec = importlib.util.spec_from_file_location(mod, os.path.join(ref, "vgiwae", "data", fname))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    uni = load("uniform_missingness_provider.py", "ref_uniform")
+    quad = load("quadrant_missingness_provider.py", "ref_quadrant")
+    filt = load("fully_missing_filter_dataset.py", "ref_filter")
+    widx = load("dataset_with_indices.py", "ref_with_idx")
+
+    class Plain(torch.utils.data.Dataset):
+        def __init__(self, data):
+            self.data = data
+
+        def __getitem__(self, i):
+            return self.data[i]
+
+        def __len__(self):
+            return len(self.data)
+
+    arrays = {}
+    N, D = 37, 5
+    data = np.arange(N * D, dtype=np.float32).reshape(N, D)
+    for miss in (0.2, 0.5, 0.8):
+        g = torch.Generator()
+        g.manual_seed(20220118)
+        ds = uni.UniformMissingnessDataset(Plain(data), total_miss=miss, rng=g)
+        arrays[f"uniform_{int(miss * 100)}"] = ds.miss_mask
+        f = filt.FullyMissingDataFilter(ds)
+        arrays[f"kept_{int(miss * 100)}"] = np.asarray(f.not_fully_missing_idx)
+        w = widx.DatasetWithIndices(f)
+        arrays[f"index_{int(miss * 100)}"] = w[:][-1]
+    img = np.zeros((19, 28 * 28), dtype=np.float32)
+    for miss in (0.25, 0.5, 0.75):
+        g = torch.Generator()
+        g.manual_seed(20220118)
+        ds = quad.QuadrantMissingnessDataset(Plain(img), total_miss=miss, img_dims=[28, 28], rng=g)
+        arrays[f"quadrant_{int(miss * 100)}"] = ds.miss_mask
+    save(out, "masks", N=N, D=D, seed=20220118, **arrays)
+
+
+def cases_dmis_known_answer(out):
+    """The reference's own self-check shapes (vgiwae/shared/iwae.py:135-181): DMIS weights for
+    arbitrary Gaussian decoder / encoder parameters, stored so the HIP kernel can be checked on them."""
+    from vgiwae.shared.iwae import compute_dmis_log_unnormalised_importance_weights
+    B, I, K, D, NZ, DZ = 7, 6, 5, 4, 3, 2
+    X = make_noise(8000, B, K, D)
+    Z = make_noise(8001, NZ, I, B, K, DZ)
+    gen_mean = make_noise(8002, NZ, I, B, K, D)
+    gen_scale = (make_noise(8003, NZ, I, B, K, D) * 3) ** 2 + 1e-3
+    var_mean = make_noise(8004, B, K, DZ)
+    var_scale = (make_noise(8005, B, K, DZ) * 2) ** 2 + 1e-3
+    lw = compute_dmis_log_unnormalised_importance_weights(
+        X, torch.ones_like(X), Z, var_latent_distr=torch.distributions.Normal(var_mean, var_scale),
+        var_comp_neg_idx=-2, prior_distr=torch.distributions.Normal(0., 1.),
+        generator_distr=torch.distributions.Normal(gen_mean, gen_scale))
+    save(out, "dmis_known_answer", X=X, Z=Z, gen_mean=gen_mean, gen_scale=gen_scale, var_mean=var_mean,
+         var_scale=var_scale, log_w=lw)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    sys.path.insert(0, os.path.join(HERE, "pl_stub"))
+    sys.path.insert(0, args.ref)
+    os.makedirs(args.out, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    groups = {
+        "mlp": lambda: [case_mlp(args.out, "mlp_h32", NetSpec(16, 32, 2, 32), 40, 100),
+                        case_mlp(args.out, "mlp_toy_h200", NetSpec(5, 4, 3, 200), 70, 110, store_params=False),
+                        case_mlp(args.out, "mlp_gas_h256", NetSpec(16, 16, 2, 256), 100, 120, store_params=False),
+                        case_mlp(args.out, "mlp_dropout", NetSpec(16, 32, 2, 32, dropout=0.5), 40, 130),
+                        case_mlp(args.out, "mlp_odd_dims", NetSpec(43, 86, 1, 64), 33, 140, store_params=False)],
+        "iwae": lambda: cases_iwae(args.out),
+        "vae": lambda: cases_vae(args.out),
+        "multiple": lambda: cases_multiple(args.out),
+        "mvb": lambda: cases_mvb(args.out),
+        "samplers": lambda: cases_samplers(args.out),
+        "buffer": lambda: cases_buffer(args.out),
+        "loglik": lambda: cases_loglik(args.out),
+        "masks": lambda: cases_masks(args.out, args.ref),
+        "dmis": lambda: cases_dmis_known_answer(args.out),
+    }
+    for name, fn in groups.items():
+        if args.only and name not in args.only.split(","):
+            continue
+        print(f"[{name}]")
+        fn()
+
+
+if __name__ == "__main__":
+    main()
