@@ -1,0 +1,111 @@
+"""ctypes binding of libdmv.so (the C ABI declared in include/dmv.h).
+
+The library is built in-tree by `make -C demiss_vae_amd/csrc` (see __graft_entry__.build) and is
+required: there is no fallback path.  Loading fails loudly when it is missing.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdmv.so")
+_lib = None
+
+# enums (include/dmv.h)
+ACT = {"relu": 0, "leaky_relu": 1, "tanh": 2, "sigmoid": 3}
+IN_PLAIN, IN_MASKED, IN_CONCAT, IN_CONCAT_MASKED = 0, 1, 2, 3
+GEN = {"normal": 0, "normal_with_eps": 1, "bern": 2, "bern_m1_p1": 3}
+Q_OWN, Q_STRATIFIED, Q_IMPUTATION = 0, 1, 2
+BOUND_LSE, BOUND_WEIGHTED = 0, 1
+
+
+class DmvNet(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("out_dim", C.c_int32), ("hidden", C.c_int32), ("nb", C.c_int32),
+                ("act", C.c_int32), ("dropout_p", C.c_float)]
+
+
+class DmvObjCfg(C.Structure):
+    _fields_ = [("B", C.c_int32), ("G", C.c_int32), ("nz", C.c_int32), ("I", C.c_int32),
+                ("D", C.c_int32), ("Zd", C.c_int32), ("gen_dist", C.c_int32), ("q_eps", C.c_int32),
+                ("x_per_component", C.c_int32),
+                ("enc_sb", C.c_int64), ("enc_sg", C.c_int64), ("raw_off", C.c_int64), ("logit_off", C.c_int64)]
+
+
+class DmvLatentBwd(C.Structure):
+    _fields_ = [("base_prior", C.c_float), ("base_qown", C.c_float), ("base_qmix", C.c_float),
+                ("base_w", C.c_float), ("kl_coef", C.c_float),
+                ("own_live", C.c_int32), ("mix_live", C.c_int32), ("use_zscale", C.c_int32),
+                ("mix_kind", C.c_int32)]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_I32 = C.c_int32
+_U64 = C.c_uint64
+_F = C.c_float
+_SZ = C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/dmv.h declares
+SIGNATURES = {
+    "dmv_version": (C.c_int, []),
+    "dmv_strerror": (C.c_char_p, [C.c_int]),
+    "dmv_pad32": (_I32, [_I32]),
+    "dmv_mlp_packed_floats": (_SZ, [C.POINTER(DmvNet)]),
+    "dmv_mlp_pack": (C.c_int, [C.POINTER(DmvNet), C.POINTER(_P), C.POINTER(_P), _P, _P]),
+    "dmv_mlp_saved_floats": (_SZ, [C.POINTER(DmvNet), _I64]),
+    "dmv_mlp_forward": (C.c_int, [C.POINTER(DmvNet), _P, _I32, _I32, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _P, _P]),
+    "dmv_mlp_backward_ws_bytes": (_SZ, [C.POINTER(DmvNet), _I64]),
+    "dmv_mlp_backward": (C.c_int, [C.POINTER(DmvNet), _P, _P, _P, _P, _I64, _I64, _P, _I64,
+                                   C.POINTER(_P), C.POINTER(_P), _F, _P, _SZ, _P]),
+    "dmv_latent_sample": (C.c_int, [C.POINTER(DmvObjCfg), _P, _P, _U64, _U64, _I64, _P, _P, _P, _P]),
+    "dmv_obj_terms": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "dmv_obj_bound": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dmv_obj_combine": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(_F), _P, _P, _P, _P]),
+    "dmv_kl_std_normal": (C.c_int, [C.POINTER(DmvObjCfg), _P, _P, _P]),
+    "dmv_obj_backward_dec": (C.c_int, [C.POINTER(DmvObjCfg), _P, _I64, _P, _P, _P, _P, _F, _F, _P, _I64, _P]),
+    "dmv_obj_backward_latent": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvLatentBwd), _P, _P, _P, _I64, _P, _I64,
+                                          _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dmv_lse_update": (C.c_int, [_I32, _I64, _P, _I32, _P, _P, _P]),
+}
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """The loaded library.  Raises if libdmv.so has not been built: there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C demiss_vae_amd/csrc)")
+        l = C.CDLL(_LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)   # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"libdmv error {rc}: {lib().dmv_strerror(rc).decode()}")
+
+
+def ptr(t):
+    """Device address of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    arr = (_P * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,743 @@
+// Masked VAE / IWAE / mixture objectives: latent sampling, per-sample log-weight terms, bounds with
+// wavefront logsumexp, and the hand-derived backward.  HBM-bound elementwise / reduction kernels.
+//
+// Sample rows are ordered n = (s*B + b)*G + g, s = z*I + i (the reference's [nz, I, B, (G,) .] tensors
+// flattened).  See include/dmv.h for the encoder-output addressing.
+#include "dmv_common.h"
+#include "dmv_rng.h"
+
+#define LOG_SQRT_2PI 0.9189385332046727f
+
+struct QAddr {
+  int64_t sb, sg, raw_off, logit_off;
+  float eps;
+};
+
+__device__ __forceinline__ float q_mu(const float* enc, const QAddr& q, int64_t b, int g, int j) {
+  return enc[b * q.sb + g * q.sg + j];
+}
+__device__ __forceinline__ float q_sigma(const float* enc, const QAddr& q, int64_t b, int g, int j) {
+  return dmv_softplus(enc[b * q.sb + g * q.sg + q.raw_off + j]) + q.eps;
+}
+__device__ __forceinline__ float log_normal(float x, float mu, float sigma) {
+  const float d = x - mu;
+  return -(d * d) / (2.f * sigma * sigma) - logf(sigma) - LOG_SQRT_2PI;
+}
+// -BCEWithLogits(l, v) = -((1 - v) l - logsigmoid(l)),  logsigmoid(l) = min(l, 0) - log1p(exp(-|l|))
+__device__ __forceinline__ float log_bern(float v, float l) {
+  const float ls = fminf(l, 0.f) - log1pf(expf(-fabsf(l)));
+  return -((1.f - v) * l - ls);
+}
+
+// sub-wave sum over R consecutive lanes (R power of two <= 64)
+template <int R>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = R / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+template <int R>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = R / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// z = mu + sigma * eps
+// ------------------------------------------------------------------------------------------
+struct SampleArgs {
+  int64_t N;       // sample rows
+  int B, G, Zd;
+  QAddr q;
+  const float* enc;
+  const float* eps;        // [N][ldz] or null (Philox)
+  float* eps_out;          // nullable: noise actually used
+  const int64_t* comp_idx; // nullable: component per row (G must be 1)
+  int64_t ldz;
+  float* Z;
+  uint64_t seed, offset;
+};
+
+__global__ void k_latent_sample(SampleArgs a) {
+  const int64_t total = a.N * a.ldz;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / a.ldz;
+    const int j = (int)(i - n * a.ldz);
+    if (j >= a.Zd) { a.Z[i] = 0.f; if (a.eps_out) a.eps_out[i] = 0.f; continue; }
+    int g = (int)(n % a.G);
+    const int64_t b = (n / a.G) % a.B;
+    if (a.comp_idx) g = (int)a.comp_idx[n];
+    const float e = a.eps ? a.eps[i] : dmv_philox_normal(a.seed, a.offset + (uint64_t)i);
+    if (a.eps_out) a.eps_out[i] = e;
+    a.Z[i] = q_mu(a.enc, a.q, b, g, j) + q_sigma(a.enc, a.q, b, g, j) * e;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-sample terms
+// ------------------------------------------------------------------------------------------
+struct TermsArgs {
+  int64_t N;
+  int B, G, D, Zd;
+  int gen_dist;
+  int x_per_component;
+  int q_kind, mix_C;
+  QAddr q;
+  const float* dec;
+  int64_t ld_dec;
+  const float* X;
+  const uint8_t* M;
+  const float* Z;
+  int64_t ldz;
+  const float* enc;
+  float* terms;     // [5][N]
+  float* comp_lp;   // nullable [N][mix_C]: log N(z_n; mu_{b,c}, sigma_{b,c}) summed over j
+};
+
+template <int R>
+__global__ void k_obj_terms(TermsArgs a) {
+  const int r = threadIdx.x % R;
+  const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / R;
+  const bool live = n < a.N;
+  const int64_t nn = live ? n : a.N - 1;
+  const int g = (int)(nn % a.G);
+  const int64_t b = (nn / a.G) % a.B;
+  const int64_t xrow = a.x_per_component ? (b * a.G + g) : b;
+  const float* dec = a.dec + nn * a.ld_dec;
+  const float* X = a.X + xrow * a.D;
+  const uint8_t* M = a.M + xrow * a.D;
+
+  float gm = 0.f, gf = 0.f;
+  for (int d = r; d < a.D; d += R) {
+    float lp;
+    const float x = X[d];
+    if (a.gen_dist <= DMV_GEN_NORMAL_EPS) {
+      const float s = dmv_softplus(dec[a.D + d]) + (a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f);
+      lp = log_normal(x, dec[d], s);
+    } else if (a.gen_dist == DMV_GEN_BERN) {
+      lp = log_bern(x, dec[d]);
+    } else {
+      lp = log_bern((x + 1.f) * 0.5f, dec[d]);
+    }
+    gf += lp;
+    gm += M[d] ? lp : 0.f;   // the reference multiplies by float(M): identical unless lp is not finite
+  }
+  const float* z = a.Z + nn * a.ldz;
+  float pr = 0.f, qo = 0.f;
+  for (int j = r; j < a.Zd; j += R) {
+    const float zj = z[j];
+    pr += -(zj * zj) * 0.5f - LOG_SQRT_2PI;
+    if (a.q_kind != DMV_Q_STRATIFIED || a.G > 1)  // rows sampled from the mixture itself have no own component
+      qo += log_normal(zj, q_mu(a.enc, a.q, b, g, j), q_sigma(a.enc, a.q, b, g, j));
+  }
+  gm = group_sum<R>(gm); gf = group_sum<R>(gf); pr = group_sum<R>(pr); qo = group_sum<R>(qo);
+
+  float qm = qo;
+  if (a.q_kind != DMV_Q_OWN) {
+    // online logsumexp over the mixture components
+    float mx = -INFINITY, se = 0.f, lse_logit = 0.f;
+    if (a.q_kind == DMV_Q_STRATIFIED) {
+      float lm = -INFINITY;
+      for (int c = 0; c < a.mix_C; ++c) lm = fmaxf(lm, a.enc[b * a.q.sb + a.q.logit_off + c]);
+      float ss = 0.f;
+      for (int c = 0; c < a.mix_C; ++c) ss += expf(a.enc[b * a.q.sb + a.q.logit_off + c] - lm);
+      lse_logit = lm + logf(ss);
+    }
+    for (int c = 0; c < a.mix_C; ++c) {
+      float lp = 0.f;
+      for (int j = r; j < a.Zd; j += R) lp += log_normal(z[j], q_mu(a.enc, a.q, b, c, j), q_sigma(a.enc, a.q, b, c, j));
+      lp = group_sum<R>(lp);
+      if (a.comp_lp && live && r == 0) a.comp_lp[nn * a.mix_C + c] = lp;
+      const float t = lp + (a.q_kind == DMV_Q_STRATIFIED ? a.enc[b * a.q.sb + a.q.logit_off + c] - lse_logit : 0.f);
+      const float nm = fmaxf(mx, t);
+      se = se * expf(mx - nm) + expf(t - nm);
+      mx = nm;
+    }
+    qm = mx + logf(se) - (a.q_kind == DMV_Q_IMPUTATION ? logf((float)a.mix_C) : 0.f);
+  }
+  if (live && r == 0) {
+    a.terms[0 * a.N + n] = gm;
+    a.terms[1 * a.N + n] = gf;
+    a.terms[2 * a.N + n] = pr;
+    a.terms[3 * a.N + n] = qo;
+    a.terms[4 * a.N + n] = qm;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// bounds: one wavefront per datapoint, logsumexp over the importance axis with wave shuffles
+// ------------------------------------------------------------------------------------------
+struct BoundArgs {
+  int B, G, nz, I;
+  int kind;        // DMV_BOUND_*
+  int q_term;      // 3: own, 4: mixture  (index into terms)
+  int use_logpi;   // LSE kind: add log pi_g of the stratified mixture
+  int dreg;        // also emit zscale = softmax over i (G == 1)
+  QAddr q;
+  const float* enc;
+  const float* terms;   // [5][N]
+  int64_t N;
+  float* log_w;         // nullable [N]
+  float* bound;         // [B]  (per-datapoint bound; PER_COMPONENT: unused)
+  float* wgt;           // nullable [N]: d(sum_b bound_b)/d log_w_n
+  float* zscale;        // nullable [N]
+  float* dlogit;        // nullable [B][G]: d(sum_b bound_b)/d logit_{b,g} through the log pi / pi factors
+};
+
+__device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+
+__global__ void k_obj_bound(BoundArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const float* tgm = a.terms;
+  const float* tpr = a.terms + 2 * a.N;
+  const float* tq = a.terms + (int64_t)a.q_term * a.N;
+  const int IG = a.I * a.G;
+  const float logI = logf((float)a.I);
+
+  // normalised log mixture weights of this datapoint (lane c holds component c, G <= 64)
+  float logpi = 0.f;
+  const bool need_pi = a.use_logpi || a.kind == DMV_BOUND_WEIGHTED;
+  if (need_pi) {
+    const float lg = lane < a.G ? a.enc[b * a.q.sb + a.q.logit_off + lane] : -INFINITY;
+    const float mx = wave_max(lg);
+    const float se = wave_sum(lane < a.G ? expf(lg - mx) : 0.f);
+    logpi = lg - (mx + logf(se));
+  }
+  float bound_acc = 0.f;
+  float dlog_acc = 0.f;   // lane c: gradient w.r.t. logit c
+
+  // every loop below has a wave-uniform trip count (lanes past the end are predicated, not exited),
+  // so the cross-lane broadcasts of log pi always read an active lane
+  auto logw = [&](int64_t n) { return tgm[n] + tpr[n] - tq[n]; };
+  for (int z = 0; z < a.nz; ++z) {
+    if (a.kind == DMV_BOUND_LSE) {
+      // logsumexp over (i, g)
+      float mx = -INFINITY;
+      for (int t0 = 0; t0 < IG; t0 += 64) {
+        const int t = t0 + lane;
+        const bool ok = t < IG;
+        const int i = ok ? t / a.G : 0, g = ok ? t % a.G : 0;
+        const int64_t n = ((int64_t)(z * a.I + i) * a.B + b) * a.G + g;
+        const float lp = __shfl(logpi, g);
+        if (ok) {
+          float w = logw(n);
+          if (a.log_w) a.log_w[n] = w;
+          if (a.use_logpi) w += lp;
+          mx = fmaxf(mx, w);
+        }
+      }
+      mx = wave_max(mx);
+      float se = 0.f;
+      for (int t0 = 0; t0 < IG; t0 += 64) {
+        const int t = t0 + lane;
+        const bool ok = t < IG;
+        const int i = ok ? t / a.G : 0, g = ok ? t % a.G : 0;
+        const int64_t n = ((int64_t)(z * a.I + i) * a.B + b) * a.G + g;
+        const float lp = __shfl(logpi, g);
+        if (ok) se += expf(logw(n) + (a.use_logpi ? lp : 0.f) - mx);
+      }
+      se = wave_sum(se);
+      const float lse = mx + logf(se);
+      bound_acc += lse - logI;
+      if (a.wgt || a.zscale || a.dlogit) {
+        float pc_acc = 0.f;  // lane c: sum of the weights of component c's samples
+        for (int t0 = 0; t0 < IG; t0 += 64) {
+          const int t = t0 + lane;
+          const bool ok = t < IG;
+          const int i = ok ? t / a.G : 0, g = ok ? t % a.G : 0;
+          const int64_t n = ((int64_t)(z * a.I + i) * a.B + b) * a.G + g;
+          const float lp = __shfl(logpi, g);
+          const float p = ok ? expf(logw(n) + (a.use_logpi ? lp : 0.f) - lse) : 0.f;
+          if (ok) {
+            if (a.wgt) a.wgt[n] = p / (float)a.nz;
+            if (a.zscale) a.zscale[n] = a.dreg ? p : 1.f;
+          }
+          if (a.dlogit && a.use_logpi) {
+            for (int c = 0; c < a.G; ++c) {
+              const float s = wave_sum((ok && g == c) ? p : 0.f);
+              if (lane == c) pc_acc += s;
+            }
+          }
+        }
+        // d/d logit_c of sum_n p_n log pi_{g(n)} = (sum_{n: g(n) = c} p_n) - pi_c
+        if (a.dlogit && a.use_logpi && lane < a.G) dlog_acc += (pc_acc - expf(logpi)) / (float)a.nz;
+      }
+    } else if (a.kind == DMV_BOUND_WEIGHTED) {
+      // sum_g pi_g (logsumexp_i log_w - log I)
+      float tot = 0.f;
+      float Lc = 0.f;   // lane c keeps L_c
+      for (int g = 0; g < a.G; ++g) {
+        const float pig = expf(__shfl(logpi, g));
+        float mx = -INFINITY;
+        for (int i = lane; i < a.I; i += 64) {
+          const int64_t n = ((int64_t)(z * a.I + i) * a.B + b) * a.G + g;
+          const float w = logw(n);
+          if (a.log_w) a.log_w[n] = w;
+          mx = fmaxf(mx, w);
+        }
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int i = lane; i < a.I; i += 64) {
+          const int64_t n = ((int64_t)(z * a.I + i) * a.B + b) * a.G + g;
+          se += expf(logw(n) - mx);
+        }
+        se = wave_sum(se);
+        const float lse = mx + logf(se);
+        tot += pig * (lse - logI);
+        if (lane == g) Lc = lse - logI;
+        if (a.wgt) {
+          for (int i = lane; i < a.I; i += 64) {
+            const int64_t n = ((int64_t)(z * a.I + i) * a.B + b) * a.G + g;
+            a.wgt[n] = pig * expf(logw(n) - lse) / (float)a.nz;
+            if (a.zscale) a.zscale[n] = 1.f;
+          }
+        }
+      }
+      bound_acc += tot;
+      if (a.dlogit && lane < a.G) dlog_acc += expf(logpi) * (Lc - tot) / (float)a.nz;
+    }
+  }
+  if (lane == 0) a.bound[b] = bound_acc / (float)a.nz;
+  if (a.dlogit && lane < a.G) a.dlogit[b * a.G + lane] = dlog_acc;
+}
+
+// mean over B of bound -> out[0]  (single block; B is at most a few hundred thousand)
+__global__ void k_mean(const float* v, int64_t n, float scale, float* out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
+  s = group_sum<64>(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1] + sh[2] + sh[3]) * scale;
+}
+
+// PER_COMPONENT objectives (DeMissVAE): obj[b*G+g] = mean_z( cm*gen_m + cf*gen_f + cp*prior + co*q_own + cx*q_mix )
+struct CombineArgs {
+  int64_t N;
+  int B, G, nz;
+  float c[5];
+  const float* terms;
+  float* obj;  // [B*G]
+};
+__global__ void k_obj_combine(CombineArgs a) {
+  const int64_t bg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t BG = (int64_t)a.B * a.G;
+  if (bg >= BG) return;
+  float s = 0.f;
+  for (int z = 0; z < a.nz; ++z) {
+    const int64_t n = (int64_t)z * BG + bg;
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+      if (a.c[t] != 0.f) v += a.c[t] * a.terms[(int64_t)t * a.N + n];
+    s += v;
+  }
+  a.obj[bg] = s / (float)a.nz;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, decoder side: d_dec[n][:] = gs * wgt[n] * (base_m * M_d + base_f) * d log p(x_d|z) / d params
+// ------------------------------------------------------------------------------------------
+struct BwdDecArgs {
+  int64_t N;
+  int B, G, D;
+  int gen_dist, x_per_component;
+  const float* dec;
+  int64_t ld_dec;
+  const float* X;
+  const uint8_t* M;
+  const float* wgt;     // nullable
+  const float* gscale;  // nullable device scalar
+  float base_m, base_f;
+  float* d_dec;
+  int64_t ld_ddec;
+};
+
+__global__ void k_obj_bwd_dec(BwdDecArgs a) {
+  const float gs = a.gscale ? a.gscale[0] : 1.f;
+  const int64_t total = a.N * a.ld_ddec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / a.ld_ddec;
+    const int c = (int)(i - n * a.ld_ddec);
+    const bool normal = a.gen_dist <= DMV_GEN_NORMAL_EPS;
+    const int P = normal ? 2 * a.D : a.D;
+    if (c >= P) { a.d_dec[i] = 0.f; continue; }
+    const int d = c < a.D ? c : c - a.D;
+    const int g = (int)(n % a.G);
+    const int64_t b = (n / a.G) % a.B;
+    const int64_t xrow = a.x_per_component ? (b * a.G + g) : b;
+    const float x = a.X[xrow * a.D + d];
+    const float coef = gs * (a.wgt ? a.wgt[n] : 1.f) * ((a.M[xrow * a.D + d] ? a.base_m : 0.f) + a.base_f);
+    const float* dec = a.dec + n * a.ld_dec;
+    float gr;
+    if (normal) {
+      const float raw = dec[a.D + d];
+      const float s = dmv_softplus(raw) + (a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f);
+      const float df = x - dec[d];
+      if (c < a.D) gr = df / (s * s);
+      else gr = (df * df / (s * s * s) - 1.f / s) * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
+    } else {
+      const float v = a.gen_dist == DMV_GEN_BERN ? x : (x + 1.f) * 0.5f;
+      gr = v - dmv_sigmoid(dec[d]);
+    }
+    a.d_dec[i] = coef * gr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, latent side: gradient w.r.t. the encoder output (mu, raw sigma, mixture logits)
+// one thread per (b, g', j) plus one per (b, g') logit
+// ------------------------------------------------------------------------------------------
+struct BwdLatArgs {
+  int B, G, S, Zd;            // S = nz*I
+  int64_t N;
+  QAddr q;
+  int mix_kind;               // DMV_Q_STRATIFIED / DMV_Q_IMPUTATION (used when base_qmix != 0)
+  float base_prior, base_qown, base_qmix, base_w;
+  int own_live, mix_live, use_zscale;
+  float kl_coef;              // loss += kl_coef * sum_{b,g} kl_wgt[b,g] * KL(N(mu,sigma) || N(0,1))
+  const float* kl_wgt;        // nullable [B][G] (1 when null)
+  const float* enc;
+  const float* Z;
+  const float* eps;
+  int64_t ldz;
+  const float* dZ;            // nullable, decoder input gradient [N][ld_dz]
+  int64_t ld_dz;
+  const float* wgt;           // nullable
+  const float* zscale;        // nullable
+  const float* comp_lp;       // [N][G] when base_qmix != 0
+  const float* qmix;          // terms[4]
+  const float* dlogit;        // nullable [B][G]
+  const float* gscale;        // nullable
+  float* d_enc;               // same addressing as enc
+};
+
+__global__ void k_obj_bwd_latent(BwdLatArgs a) {
+  const int per_b = a.G * (a.Zd + 1);
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)a.B * per_b) return;
+  const int64_t b = idx / per_b;
+  const int rem = (int)(idx - b * per_b);
+  const int gp = rem / (a.Zd + 1);
+  const int j = rem - gp * (a.Zd + 1);
+  const float gs = a.gscale ? a.gscale[0] : 1.f;
+  const bool strat = a.mix_kind == DMV_Q_STRATIFIED;
+  const bool has_mix = a.base_qmix != 0.f;
+
+  // normalised log mixture weights (uniform for the imputation mixture)
+  float lse_logit = 0.f;
+  if (has_mix && strat) {
+    float lm = -INFINITY;
+    for (int c = 0; c < a.G; ++c) lm = fmaxf(lm, a.enc[b * a.q.sb + a.q.logit_off + c]);
+    float ss = 0.f;
+    for (int c = 0; c < a.G; ++c) ss += expf(a.enc[b * a.q.sb + a.q.logit_off + c] - lm);
+    lse_logit = lm + logf(ss);
+  }
+  const float log_unif = -logf((float)a.G);
+  auto logpi = [&](int c) { return strat ? a.enc[b * a.q.sb + a.q.logit_off + c] - lse_logit : log_unif; };
+
+  if (j == a.Zd) {
+    // ---- mixture logit (b, gp)
+    if (!strat) return;
+    float acc = a.dlogit ? a.base_w * a.dlogit[b * a.G + gp] : 0.f;
+    if (has_mix && a.mix_live) {
+      const float pi = expf(logpi(gp));
+      for (int s = 0; s < a.S; ++s)
+        for (int g = 0; g < a.G; ++g) {
+          const int64_t n = ((int64_t)s * a.B + b) * a.G + g;
+          const float cw = a.base_qmix * (a.wgt ? a.wgt[n] : 1.f);
+          const float r = expf(logpi(gp) + a.comp_lp[n * a.G + gp] - a.qmix[n]);
+          acc += cw * (r - pi);
+        }
+    }
+    a.d_enc[b * a.q.sb + a.q.logit_off + gp] = gs * acc;
+    return;
+  }
+
+  const float mu = q_mu(a.enc, a.q, b, gp, j);
+  const float raw = a.enc[b * a.q.sb + gp * a.q.sg + a.q.raw_off + j];
+  const float sg = dmv_softplus(raw) + a.q.eps;
+  float acc_mu = 0.f, acc_sg = 0.f;
+  for (int s = 0; s < a.S; ++s) {
+    // (1) reparameterised path: only samples drawn from component gp depend on (mu, sigma)_{gp}
+    {
+      const int64_t n = ((int64_t)s * a.B + b) * a.G + gp;
+      const float w = a.wgt ? a.wgt[n] : 1.f;
+      const float z = a.Z[n * a.ldz + j];
+      float dz = a.dZ ? a.dZ[n * a.ld_dz + j] : 0.f;
+      dz += a.base_prior * w * (-z);
+      if (a.base_qown != 0.f) dz += a.base_qown * w * (-(z - mu) / (sg * sg));
+      if (has_mix) {
+        float t = 0.f;
+        for (int c = 0; c < a.G; ++c) {
+          const float r = expf(logpi(c) + a.comp_lp[n * a.G + c] - a.qmix[n]);
+          const float mc = q_mu(a.enc, a.q, b, c, j), sc = q_sigma(a.enc, a.q, b, c, j);
+          t += r * (-(z - mc) / (sc * sc));
+        }
+        dz += a.base_qmix * w * t;
+      }
+      if (a.use_zscale && a.zscale) dz *= a.zscale[n];
+      acc_mu += dz;
+      acc_sg += dz * a.eps[n * a.ldz + j];
+      // (2) direct dependence of log q_own on its parameters
+      if (a.own_live && a.base_qown != 0.f) {
+        const float df = z - mu;
+        acc_mu += a.base_qown * w * (df / (sg * sg));
+        acc_sg += a.base_qown * w * (df * df / (sg * sg * sg) - 1.f / sg);
+      }
+    }
+    // (3) direct dependence of log q_mix (evaluated at every sample of the datapoint) on component gp
+    if (has_mix && a.mix_live) {
+      for (int g = 0; g < a.G; ++g) {
+        const int64_t n = ((int64_t)s * a.B + b) * a.G + g;
+        const float w = a.wgt ? a.wgt[n] : 1.f;
+        const float z = a.Z[n * a.ldz + j];
+        const float r = expf(logpi(gp) + a.comp_lp[n * a.G + gp] - a.qmix[n]);
+        const float df = z - mu;
+        acc_mu += a.base_qmix * w * r * (df / (sg * sg));
+        acc_sg += a.base_qmix * w * r * (df * df / (sg * sg * sg) - 1.f / sg);
+      }
+    }
+  }
+  if (a.kl_coef != 0.f) {
+    const float kc = a.kl_coef * (a.kl_wgt ? a.kl_wgt[b * a.G + gp] : 1.f);
+    acc_mu += kc * mu;
+    acc_sg += kc * (sg - 1.f / sg);
+  }
+  a.d_enc[b * a.q.sb + gp * a.q.sg + j] = gs * acc_mu;
+  a.d_enc[b * a.q.sb + gp * a.q.sg + a.q.raw_off + j] = gs * acc_sg * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
+}
+
+// analytic -KL(N(mu,sigma)||N(0,1)) summed over j, per (b, g):  models/vae.py:404-406
+struct KlArgs { int B, G, Zd; QAddr q; const float* enc; float* kl; };
+__global__ void k_kl(KlArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)a.B * a.G) return;
+  const int64_t b = i / a.G; const int g = (int)(i % a.G);
+  float s = 0.f;
+  for (int j = 0; j < a.Zd; ++j) {
+    const float mu = q_mu(a.enc, a.q, b, g, j), sg = q_sigma(a.enc, a.q, b, g, j);
+    const float v = sg * sg;
+    s += 0.5f * (v + mu * mu - 1.f - logf(v));
+  }
+  a.kl[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// streaming logsumexp for the K-sample log-likelihood (test/refit_...py:189-222): fold a chunk of
+// log-weights [Kc][B] into running (max, sum exp) per datapoint.  One block per datapoint.
+// ------------------------------------------------------------------------------------------
+struct LseArgs {
+  int B; int64_t Kc;
+  const float* gm; const float* pr; const float* q;   // term arrays of the chunk, each [Kc*B]
+  float* run_max; float* run_sum;   // [B]; initialise to -inf / 0
+};
+__global__ void k_lse_update(LseArgs a) {
+  const int b = blockIdx.x;
+  __shared__ float shm[4], shs[4];
+  float mx = -INFINITY;
+  for (int64_t k = threadIdx.x; k < a.Kc; k += blockDim.x) {
+    const int64_t n = k * a.B + b;
+    mx = fmaxf(mx, a.gm[n] + a.pr[n] - a.q[n]);
+  }
+  mx = group_max<64>(mx);
+  if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+  const float old = a.run_max[b];
+  const float nm = fmaxf(mx, old);
+  float se = 0.f;
+  for (int64_t k = threadIdx.x; k < a.Kc; k += blockDim.x) {
+    const int64_t n = k * a.B + b;
+    se += expf(a.gm[n] + a.pr[n] - a.q[n] - nm);
+  }
+  se = group_sum<64>(se);
+  if ((threadIdx.x & 63) == 0) shs[threadIdx.x >> 6] = se;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float prev = (old == -INFINITY) ? 0.f : a.run_sum[b] * expf(old - nm);
+    a.run_sum[b] = prev + shs[0] + shs[1] + shs[2] + shs[3];
+    a.run_max[b] = nm;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int check_cfg(const DmvObjCfg* c) {
+  if (!c) return DMV_E_BADARG;
+  if (c->B < 1 || c->G < 1 || c->nz < 1 || c->I < 1 || c->D < 1 || c->Zd < 1) return DMV_E_BADARG;
+  if (c->G > 64) return DMV_E_UNSUPPORTED;
+  if (c->gen_dist < DMV_GEN_NORMAL || c->gen_dist > DMV_GEN_BERN_M1P1) return DMV_E_UNSUPPORTED;
+  return DMV_OK;
+}
+static QAddr qaddr(const DmvObjCfg* c) {
+  QAddr q;
+  q.sb = c->enc_sb; q.sg = c->enc_sg; q.raw_off = c->raw_off; q.logit_off = c->logit_off;
+  q.eps = c->q_eps ? DMV_EPSILON : 0.f;
+  return q;
+}
+static inline int64_t nrows(const DmvObjCfg* c) { return (int64_t)c->nz * c->I * c->B * c->G; }
+static inline unsigned grid_for(int64_t work, int block, unsigned cap = 8192) {
+  int64_t g = (work + block - 1) / block;
+  if (g < 1) g = 1;
+  return (unsigned)(g > cap ? cap : g);
+}
+
+extern "C" int dmv_latent_sample(const DmvObjCfg* cfg, const float* enc, const float* eps, uint64_t seed,
+                                 uint64_t offset, int64_t ldz, const int64_t* comp_idx, float* Z, float* eps_out,
+                                 void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (!enc || !Z || ldz < cfg->Zd) return DMV_E_BADARG;
+  if (comp_idx && cfg->G != 1) return DMV_E_BADARG;
+  SampleArgs a;
+  a.N = nrows(cfg); a.B = cfg->B; a.G = cfg->G; a.Zd = cfg->Zd;
+  a.q = qaddr(cfg); a.enc = enc; a.eps = eps; a.eps_out = eps_out; a.comp_idx = comp_idx;
+  a.ldz = ldz; a.Z = Z; a.seed = seed; a.offset = offset;
+  hipLaunchKernelGGL(k_latent_sample, dim3(grid_for(a.N * ldz, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+extern "C" int dmv_obj_terms(const DmvObjCfg* cfg, int32_t q_kind, int32_t mix_C, const float* dec, int64_t ld_dec,
+                             const float* X, const uint8_t* M, const float* Z, int64_t ldz, const float* enc,
+                             float* terms, float* comp_lp, void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (!dec || !X || !M || !Z || !enc || !terms) return DMV_E_BADARG;
+  if (q_kind < DMV_Q_OWN || q_kind > DMV_Q_IMPUTATION) return DMV_E_UNSUPPORTED;
+  if (q_kind != DMV_Q_OWN && (mix_C < 1 || mix_C > 64)) return DMV_E_UNSUPPORTED;
+  const int P = cfg->gen_dist <= DMV_GEN_NORMAL_EPS ? 2 * cfg->D : cfg->D;
+  if (ld_dec < P || ldz < cfg->Zd) return DMV_E_BADARG;
+  TermsArgs a;
+  a.N = nrows(cfg); a.B = cfg->B; a.G = cfg->G; a.D = cfg->D; a.Zd = cfg->Zd;
+  a.gen_dist = cfg->gen_dist; a.x_per_component = cfg->x_per_component;
+  a.q_kind = q_kind; a.mix_C = mix_C; a.q = qaddr(cfg);
+  a.dec = dec; a.ld_dec = ld_dec; a.X = X; a.M = M; a.Z = Z; a.ldz = ldz; a.enc = enc;
+  a.terms = terms; a.comp_lp = comp_lp;
+  hipStream_t st = (hipStream_t)stream;
+  const int span = cfg->D > cfg->Zd ? cfg->D : cfg->Zd;
+  if (span <= 8) {
+    hipLaunchKernelGGL(k_obj_terms<1>, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, st, a);
+  } else if (span <= 96) {
+    hipLaunchKernelGGL(k_obj_terms<8>, dim3((unsigned)((a.N * 8 + 255) / 256)), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(k_obj_terms<64>, dim3((unsigned)((a.N * 64 + 255) / 256)), dim3(256), 0, st, a);
+  }
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+extern "C" int dmv_obj_bound(const DmvObjCfg* cfg, int32_t kind, int32_t q_kind, int32_t use_logpi, int32_t dreg,
+                             const float* enc, const float* terms, float* log_w, float* bound, float* mean_out,
+                             float* wgt, float* zscale, float* dlogit, void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (!terms || !bound) return DMV_E_BADARG;
+  if (kind != DMV_BOUND_LSE && kind != DMV_BOUND_WEIGHTED) return DMV_E_UNSUPPORTED;
+  if ((use_logpi || kind == DMV_BOUND_WEIGHTED) && !enc) return DMV_E_BADARG;
+  BoundArgs a;
+  a.B = cfg->B; a.G = cfg->G; a.nz = cfg->nz; a.I = cfg->I;
+  a.kind = kind; a.q_term = (q_kind == DMV_Q_OWN) ? 3 : 4; a.use_logpi = use_logpi; a.dreg = dreg;
+  a.q = qaddr(cfg); a.enc = enc; a.terms = terms; a.N = nrows(cfg);
+  a.log_w = log_w; a.bound = bound; a.wgt = wgt; a.zscale = zscale; a.dlogit = dlogit;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_obj_bound, dim3((unsigned)((cfg->B + 3) / 4)), dim3(256), 0, st, a);
+  DMV_HIP_CHECK_LAUNCH();
+  if (mean_out) {
+    hipLaunchKernelGGL(k_mean, dim3(1), dim3(256), 0, st, (const float*)bound, (int64_t)cfg->B, 1.f / (float)cfg->B, mean_out);
+    DMV_HIP_CHECK_LAUNCH();
+  }
+  return DMV_OK;
+}
+
+extern "C" int dmv_obj_combine(const DmvObjCfg* cfg, const float* coef5, const float* terms, float* obj,
+                               float* mean_out, void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (!coef5 || !terms || !obj || cfg->I != 1) return DMV_E_BADARG;
+  CombineArgs a;
+  a.N = nrows(cfg); a.B = cfg->B; a.G = cfg->G; a.nz = cfg->nz;
+  for (int t = 0; t < 5; ++t) a.c[t] = coef5[t];
+  a.terms = terms; a.obj = obj;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t BG = (int64_t)cfg->B * cfg->G;
+  hipLaunchKernelGGL(k_obj_combine, dim3((unsigned)((BG + 255) / 256)), dim3(256), 0, st, a);
+  DMV_HIP_CHECK_LAUNCH();
+  if (mean_out) {
+    hipLaunchKernelGGL(k_mean, dim3(1), dim3(256), 0, st, (const float*)obj, BG, 1.f / (float)BG, mean_out);
+    DMV_HIP_CHECK_LAUNCH();
+  }
+  return DMV_OK;
+}
+
+extern "C" int dmv_kl_std_normal(const DmvObjCfg* cfg, const float* enc, float* kl, void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (!enc || !kl) return DMV_E_BADARG;
+  KlArgs a; a.B = cfg->B; a.G = cfg->G; a.Zd = cfg->Zd; a.q = qaddr(cfg); a.enc = enc; a.kl = kl;
+  const int64_t BG = (int64_t)cfg->B * cfg->G;
+  hipLaunchKernelGGL(k_kl, dim3((unsigned)((BG + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+extern "C" int dmv_obj_backward_dec(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec, const float* X,
+                                    const uint8_t* M, const float* wgt, const float* gscale, float base_m, float base_f,
+                                    float* d_dec, int64_t ld_ddec, void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (!dec || !X || !M || !d_dec) return DMV_E_BADARG;
+  const int P = cfg->gen_dist <= DMV_GEN_NORMAL_EPS ? 2 * cfg->D : cfg->D;
+  if (ld_dec < P || ld_ddec < P) return DMV_E_BADARG;
+  BwdDecArgs a;
+  a.N = nrows(cfg); a.B = cfg->B; a.G = cfg->G; a.D = cfg->D;
+  a.gen_dist = cfg->gen_dist; a.x_per_component = cfg->x_per_component;
+  a.dec = dec; a.ld_dec = ld_dec; a.X = X; a.M = M; a.wgt = wgt; a.gscale = gscale;
+  a.base_m = base_m; a.base_f = base_f; a.d_dec = d_dec; a.ld_ddec = ld_ddec;
+  hipLaunchKernelGGL(k_obj_bwd_dec, dim3(grid_for(a.N * ld_ddec, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+extern "C" int dmv_obj_backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const float* enc, const float* Z,
+                                       const float* eps, int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
+                                       const float* zscale, const float* comp_lp, const float* qmix,
+                                       const float* dlogit, const float* kl_wgt, const float* gscale, float* d_enc,
+                                       void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (!p || !enc || !Z || !eps || !d_enc || ldz < cfg->Zd) return DMV_E_BADARG;
+  if (dZ && ld_dz < cfg->Zd) return DMV_E_BADARG;
+  if (p->base_qmix != 0.f && (!comp_lp || !qmix)) return DMV_E_BADARG;
+  BwdLatArgs a;
+  a.B = cfg->B; a.G = cfg->G; a.S = cfg->nz * cfg->I; a.Zd = cfg->Zd; a.N = nrows(cfg);
+  a.q = qaddr(cfg); a.mix_kind = p->mix_kind;
+  a.base_prior = p->base_prior; a.base_qown = p->base_qown; a.base_qmix = p->base_qmix; a.base_w = p->base_w;
+  a.own_live = p->own_live; a.mix_live = p->mix_live; a.use_zscale = p->use_zscale; a.kl_coef = p->kl_coef;
+  a.enc = enc; a.Z = Z; a.eps = eps; a.ldz = ldz; a.dZ = dZ; a.ld_dz = ld_dz;
+  a.wgt = wgt; a.zscale = zscale; a.comp_lp = comp_lp; a.qmix = qmix; a.dlogit = dlogit; a.kl_wgt = kl_wgt; a.gscale = gscale;
+  a.d_enc = d_enc;
+  const int64_t work = (int64_t)cfg->B * cfg->G * (cfg->Zd + 1);
+  hipLaunchKernelGGL(k_obj_bwd_latent, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+extern "C" int dmv_lse_update(int32_t B, int64_t Kc, const float* terms, int32_t q_term, float* run_max, float* run_sum,
+                              void* stream) {
+  if (B < 1 || Kc < 1 || !terms || !run_max || !run_sum || (q_term != 3 && q_term != 4)) return DMV_E_BADARG;
+  LseArgs a;
+  const int64_t N = Kc * B;
+  a.B = B; a.Kc = Kc; a.gm = terms; a.pr = terms + 2 * N; a.q = terms + (int64_t)q_term * N;
+  a.run_max = run_max; a.run_sum = run_sum;
+  hipLaunchKernelGGL(k_lse_update, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}

@@ -1,0 +1,42 @@
+// Counter-based RNG for the device samplers: Philox4x32-10 (Salmon et al., SC'11) keyed by the 64-bit
+// seed, counter = the 64-bit element index; one call yields four 32-bit words.  Normals by Box-Muller.
+// Every element of a launch draws from its own counter, so results do not depend on the launch
+// geometry and a backward pass can regenerate the same noise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct dmv_u4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline dmv_u4 dmv_philox4x32_10(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  return dmv_u4{c0, c1, c2, c3};
+}
+
+// uniform in (0, 1]: never 0, so log() is finite
+__host__ __device__ inline float dmv_u01(uint32_t w) { return ((float)(w >> 8) + 1.0f) * (1.0f / 16777216.0f); }
+
+// standard normal for element `idx` of stream `seed` (one Philox call per element; two words used)
+__device__ inline float dmv_philox_normal(uint64_t seed, uint64_t idx) {
+  const dmv_u4 r = dmv_philox4x32_10(seed, idx, 0x6e6f726dull /* "norm" */);
+  const float u1 = dmv_u01(r.x), u2 = dmv_u01(r.y);
+  return sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
+}
+
+// uniform in [0, 1) for element `idx`
+__device__ inline float dmv_philox_uniform(uint64_t seed, uint64_t idx) {
+  const dmv_u4 r = dmv_philox4x32_10(seed, idx, 0x756e6966ull /* "unif" */);
+  return (float)(r.x >> 8) * (1.0f / 16777216.0f);
+}

@@ -1,0 +1,169 @@
+"""Host side of the fused residual-MLP kernels (dmv_mlp_* in include/dmv.h).
+
+`PackedNet` owns the fragment-ordered copy of a network's weights and re-packs it when the
+parameters change (tracked through the tensors' version counters, which every in-place optimiser
+update bumps).  `mlp_forward` / `mlp_backward` are thin wrappers over the C ABI working on padded
+row-major buffers; `ResidualMLPFunction` exposes one network call to autograd.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+def pad32(n: int) -> int:
+    return 32 * ((n + 31) // 32)
+
+
+@dataclass(frozen=True)
+class NetDims:
+    """Constructor arguments of ResidualFCNetwork (vgiwae/shared/neural_nets.py:92-99)."""
+    in_dim: int
+    out_dim: int
+    nb: int
+    hidden: int
+    act: str = "relu"
+    dropout: float = 0.0
+
+    def c_struct(self):
+        if self.act not in L.ACT:
+            raise NotImplementedError(f"activation {self.act!r} has no HIP kernel")
+        return L.DmvNet(self.in_dim, self.out_dim, self.hidden, self.nb, L.ACT[self.act], float(self.dropout))
+
+    @property
+    def num_layers(self):
+        return 2 * self.nb + 2
+
+
+class PackedNet:
+    """A network's parameters (2*nb+2 weight and bias tensors, nn.Linear layout, in layer order)
+    plus their MFMA-fragment image on the device."""
+
+    def __init__(self, dims: NetDims, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]):
+        assert len(weights) == dims.num_layers and len(biases) == dims.num_layers
+        self.dims = dims
+        self.weights = list(weights)
+        self.biases = list(biases)
+        self.c = dims.c_struct()
+        self._packed = None
+        self._stamp = None
+        n = L.lib().dmv_mlp_packed_floats(C.byref(self.c))
+        if n == 0:
+            raise RuntimeError(f"unsupported network shape for the HIP kernels: {dims}")
+        self._n_packed = n
+
+    def params(self) -> List[torch.Tensor]:
+        out = []
+        for w, b in zip(self.weights, self.biases):
+            out += [w, b]
+        return out
+
+    def _current_stamp(self):
+        return tuple((t.data_ptr(), t._version) for t in self.params())
+
+    def packed(self) -> torch.Tensor:
+        """Fragment image of the current weights (re-packed only when a parameter changed)."""
+        stamp = self._current_stamp()
+        if self._packed is None or stamp != self._stamp or self._packed.device != self.weights[0].device:
+            dev = self.weights[0].device
+            for t in self.params():
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev or not t.is_cuda:
+                    raise RuntimeError("network parameters must be contiguous fp32 CUDA tensors on one device")
+            if self._packed is None or self._packed.device != dev:
+                self._packed = torch.empty(self._n_packed, dtype=torch.float32, device=dev)
+            L.check(L.lib().dmv_mlp_pack(C.byref(self.c), L.ptr_array([w.detach() for w in self.weights]),
+                                         L.ptr_array([b.detach() for b in self.biases]),
+                                         L.ptr(self._packed), L.stream_ptr()))
+            self._stamp = stamp
+        return self._packed
+
+
+def mlp_forward(net: PackedNet, x: torch.Tensor, ldx: int, rows: int, *, in_mode=L.IN_PLAIN, D: Optional[int] = None,
+                m: Optional[torch.Tensor] = None, ldm: int = 0, save: bool = False,
+                drop_keep: Optional[torch.Tensor] = None):
+    """y [rows, pad32(out_dim)] (columns past out_dim are zero) and the saved-activation buffer (or None)."""
+    d = net.dims
+    if D is None:
+        D = d.in_dim
+    dev = x.device
+    y = torch.empty((rows, pad32(d.out_dim)), dtype=torch.float32, device=dev)
+    saved = None
+    if save:
+        saved = torch.empty(L.lib().dmv_mlp_saved_floats(C.byref(net.c), rows), dtype=torch.float32, device=dev)
+    if rows:
+        L.check(L.lib().dmv_mlp_forward(C.byref(net.c), L.ptr(net.packed()), in_mode, D, L.ptr(x), ldx, L.ptr(m), ldm,
+                                        rows, L.ptr(y), y.shape[1], L.ptr(saved), L.ptr(drop_keep), L.stream_ptr()))
+    return y, saved
+
+
+def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: int, *, need_dx: bool,
+                 need_param_grads: bool, drop_keep: Optional[torch.Tensor] = None):
+    """gy [rows, pad32(out_dim)] -> (dx [rows, pad32(in_dim)] or None, [gW0, gb0, gW1, ...] or None)."""
+    d = net.dims
+    dev = gy.device
+    assert gy.shape == (rows, pad32(d.out_dim)) and gy.is_contiguous()
+    dx = torch.empty((rows, pad32(d.in_dim)), dtype=torch.float32, device=dev) if need_dx else None
+    gws = gbs = None
+    gw_arr = gb_arr = None
+    if need_param_grads:
+        gws = [torch.empty_like(w) for w in net.weights]
+        gbs = [torch.empty_like(b) for b in net.biases]
+        gw_arr, gb_arr = L.ptr_array(gws), L.ptr_array(gbs)
+    nbytes = L.lib().dmv_mlp_backward_ws_bytes(C.byref(net.c), rows)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+    if rows:
+        L.check(L.lib().dmv_mlp_backward(C.byref(net.c), L.ptr(net.packed()), L.ptr(saved), L.ptr(drop_keep),
+                                         L.ptr(gy), gy.shape[1], rows, L.ptr(dx), dx.shape[1] if need_dx else 0,
+                                         gw_arr, gb_arr, 0.0, L.ptr(ws), nbytes, L.stream_ptr()))
+    elif need_param_grads:
+        for t in gws + gbs:
+            t.zero_()
+    grads = None
+    if need_param_grads:
+        grads = []
+        for w, b in zip(gws, gbs):
+            grads += [w, b]
+    return dx, grads
+
+
+def make_keep_masks(dims: NetDims, rows: int, device, generator: Optional[torch.Generator] = None):
+    """Bernoulli(1-p) keep masks [nb, rows, hidden] uint8 for the blocks' dropout layers."""
+    if dims.dropout <= 0 or dims.nb == 0:
+        return None
+    u = torch.rand((dims.nb, rows, dims.hidden), device=device, generator=generator)
+    return (u >= dims.dropout).to(torch.uint8)
+
+
+class ResidualMLPFunction(torch.autograd.Function):
+    """y = net(x) for x [rows, in_dim] through the HIP kernels, differentiable w.r.t. x and the parameters.
+
+    The general-purpose entry used wherever the reference calls a network directly
+    (e.g. model.generator_network(Z), vgiwae/models/vae.py:279,309)."""
+
+    @staticmethod
+    def forward(ctx, net: PackedNet, drop_keep, x, *params):
+        d = net.dims
+        x2 = x.reshape(-1, d.in_dim).contiguous().float()
+        rows = x2.shape[0]
+        need = any(ctx.needs_input_grad[2:])
+        y, saved = mlp_forward(net, x2, d.in_dim, rows, save=need, drop_keep=drop_keep)
+        ctx.net, ctx.saved, ctx.rows, ctx.drop_keep = net, saved, rows, drop_keep
+        ctx.lead = x.shape[:-1]
+        return y[:, :d.out_dim].reshape(*x.shape[:-1], d.out_dim)
+
+    @staticmethod
+    def backward(ctx, gy):
+        net, d = ctx.net, ctx.net.dims
+        g = torch.zeros((ctx.rows, pad32(d.out_dim)), dtype=torch.float32, device=gy.device)
+        g[:, :d.out_dim] = gy.reshape(ctx.rows, d.out_dim)
+        need_dx = ctx.needs_input_grad[2]
+        need_p = any(ctx.needs_input_grad[3:])
+        dx, grads = mlp_backward(net, ctx.saved, g, ctx.rows, need_dx=need_dx, need_param_grads=need_p,
+                                 drop_keep=ctx.drop_keep)
+        gx = dx[:, :d.in_dim].reshape(*ctx.lead, d.in_dim) if need_dx else None
+        if grads is None:
+            grads = [None] * (2 * d.num_layers)
+        return (None, None, gx, *grads)

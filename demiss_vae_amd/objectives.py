@@ -1,0 +1,375 @@
+"""The masked VAE / IWAE / MissSVAE / MissSIWAE / DeMissVAE objectives as fused HIP pipelines.
+
+One call = encoder MLP -> latent sampling -> decoder MLP -> per-sample terms -> bound, all through
+libdmv; `_FusedObjective.backward` is the hand-derived backward (decoder-side gradient, decoder
+MLP backward, latent-side gradient, encoder MLP backward).  The public functions mirror the
+reference's estimators:
+
+  estimate_elbo            vgiwae/models/vae.py:447-473
+  estimate_iwelbo          vgiwae/models/iwae.py:125-154
+  estimate_multiple_elbo   vgiwae/models/multiple_vae.py:162-195
+  estimate_multiple_iwelbo vgiwae/models/multiple_iwae.py:201-237
+  mvb2_objectives / cvi_objective / mvb_objective   vgiwae/models/mvbvae.py:67-190
+
+Noise: pass `eps` (standard normal, reference sample shape) for reproducible parity runs, or leave
+it None to draw from the on-device Philox stream (demiss_vae_amd.rng).
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from . import rng
+from .mlp import PackedNet, mlp_forward, mlp_backward, pad32
+
+
+@dataclass(frozen=True)
+class ModelDims:
+    D: int
+    Zd: int
+    gen_dist: str = "normal_with_eps"    # normal | normal_with_eps | bern | bern_m1_p1
+    q_dist: str = "normal_with_eps"      # normal | normal_with_eps | stratified | stratified_with_eps
+    C: int = 1
+    encoder_use_mis_mask: bool = False
+
+    @property
+    def q_eps(self):
+        return 1 if self.q_dist.endswith("with_eps") else 0
+
+    @property
+    def q_is_mixture(self):
+        return self.q_dist.startswith("stratified")
+
+    @property
+    def dec_params(self):
+        return 2 * self.D if self.gen_dist in ("normal", "normal_with_eps") else self.D
+
+
+@dataclass(frozen=True)
+class _Plan:
+    kind: str            # iwae | elbo_analytic | miwae | mvb2 | cvi | mvb
+    nz: int
+    I: int
+    STL: bool = False
+    DREG: bool = False
+    looser: bool = False
+    kl_analytic: bool = False
+
+
+def _u8(M: torch.Tensor) -> torch.Tensor:
+    M = M.contiguous()
+    return M.view(torch.uint8) if M.dtype == torch.bool else M.to(torch.uint8)
+
+
+class _Ctx:
+    pass
+
+
+def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, X, M, eps, enc_keep, dec_keep,
+                  training: bool, comp_idx=None):
+    """Runs the forward pipeline; returns a context holding every buffer the backward needs."""
+    lib = L.lib()
+    st = L.stream_ptr()
+    dev = X.device
+    demiss = plan.kind in ("mvb2", "cvi", "mvb")
+    c = _Ctx()
+    if demiss:
+        B, K, D = X.shape
+        G, enc_rows = K, B * K
+    else:
+        B, D = X.shape
+        G = dims.C if dims.q_is_mixture else 1
+        enc_rows = B
+    assert D == dims.D
+    Xc = X.contiguous().float()
+    Mu = _u8(M)
+    assert Mu.shape == Xc.shape
+    nz, I, Zd = plan.nz, plan.I, dims.Zd
+    N = nz * I * B * G
+
+    # ---- encoder (vgiwae/models/vae.py:80-91; the X*M products of the non-imputing estimators)
+    if dims.encoder_use_mis_mask:
+        in_mode = L.IN_CONCAT if demiss else L.IN_CONCAT_MASKED
+    else:
+        in_mode = L.IN_PLAIN if demiss else L.IN_MASKED
+    enc_out, enc_saved = mlp_forward(enc, Xc, D, enc_rows, in_mode=in_mode, D=D, m=Mu, ldm=D, save=training,
+                                     drop_keep=enc_keep)
+    ldE = enc_out.shape[1]
+
+    cfg = L.DmvObjCfg()
+    cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, G, nz, I, D, Zd
+    cfg.gen_dist, cfg.q_eps = L.GEN[dims.gen_dist], dims.q_eps
+    cfg.x_per_component = 1 if demiss else 0
+    if demiss:
+        cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = K * ldE, ldE, Zd, 0
+    elif dims.q_is_mixture:
+        cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, Zd, dims.C * Zd, 2 * dims.C * Zd
+    else:
+        cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, 0, Zd, 0
+
+    # ---- z = mu + sigma * eps
+    Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
+    if eps is not None:
+        eps_used = eps.reshape(N, Zd).contiguous().float()
+        L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(eps_used), 0, 0, Zd, L.ptr(comp_idx),
+                                      L.ptr(Z), None, st))
+    else:
+        eps_used = torch.empty((N, Zd), dtype=torch.float32, device=dev) if training else None
+        seed, off = rng.next_offset(N * Zd)
+        L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, Zd, L.ptr(comp_idx),
+                                      L.ptr(Z), L.ptr(eps_used), st))
+
+    # ---- decoder
+    dec_out, dec_saved = mlp_forward(dec, Z, Zd, N, save=training, drop_keep=dec_keep)
+
+    # ---- per-sample terms
+    if demiss:
+        q_kind, mix_C = L.Q_IMPUTATION, K
+    elif dims.q_is_mixture:
+        q_kind, mix_C = L.Q_STRATIFIED, dims.C
+    else:
+        q_kind, mix_C = L.Q_OWN, 1
+    terms = torch.empty((5, N), dtype=torch.float32, device=dev)
+    need_comp = training and q_kind != L.Q_OWN and plan.kind in ("miwae", "cvi")
+    comp_lp = torch.empty((N, mix_C), dtype=torch.float32, device=dev) if need_comp else None
+    L.check(lib.dmv_obj_terms(C.byref(cfg), q_kind, mix_C, L.ptr(dec_out), dec_out.shape[1], L.ptr(Xc), L.ptr(Mu),
+                              L.ptr(Z), Zd, L.ptr(enc_out), L.ptr(terms), L.ptr(comp_lp), st))
+
+    c.cfg, c.B, c.G, c.N, c.demiss, c.q_kind, c.mix_C = cfg, B, G, N, demiss, q_kind, mix_C
+    c.Xc, c.Mu, c.enc_out, c.enc_saved, c.Z, c.eps, c.dec_out, c.dec_saved = Xc, Mu, enc_out, enc_saved, Z, eps_used, dec_out, dec_saved
+    c.terms, c.comp_lp, c.enc_rows = terms, comp_lp, enc_rows
+    c.enc_keep, c.dec_keep = enc_keep, dec_keep
+    return c
+
+
+def _bound(c, plan: _Plan, training: bool):
+    lib, st = L.lib(), L.stream_ptr()
+    dev = c.terms.device
+    B, G, N = c.B, c.G, c.N
+    per_b = torch.empty(B, dtype=torch.float32, device=dev)
+    wgt = torch.empty(N, dtype=torch.float32, device=dev) if training else None
+    zscale = torch.empty(N, dtype=torch.float32, device=dev) if (training and plan.DREG) else None
+    mixture = c.q_kind == L.Q_STRATIFIED
+    dlogit = torch.zeros((B, G), dtype=torch.float32, device=dev) if (training and mixture) else None
+    kind = L.BOUND_WEIGHTED if plan.looser else L.BOUND_LSE
+    L.check(lib.dmv_obj_bound(C.byref(c.cfg), kind, c.q_kind, 1 if (mixture and not plan.looser) else 0,
+                              1 if plan.DREG else 0, L.ptr(c.enc_out), L.ptr(c.terms), None, L.ptr(per_b), None,
+                              L.ptr(wgt), L.ptr(zscale), L.ptr(dlogit), st))
+    c.wgt, c.zscale, c.dlogit = wgt, zscale, dlogit
+    return per_b
+
+
+def _combine(c, coef):
+    lib, st = L.lib(), L.stream_ptr()
+    obj = torch.empty((c.B, c.G), dtype=torch.float32, device=c.terms.device)
+    arr = (C.c_float * 5)(*coef)
+    L.check(lib.dmv_obj_combine(C.byref(c.cfg), arr, L.ptr(c.terms), L.ptr(obj), None, st))
+    return obj
+
+
+def _kl(c):
+    lib, st = L.lib(), L.stream_ptr()
+    kl = torch.empty((c.B, c.G), dtype=torch.float32, device=c.terms.device)
+    L.check(lib.dmv_kl_std_normal(C.byref(c.cfg), L.ptr(c.enc_out), L.ptr(kl), st))
+    return kl
+
+
+def _dec_side(c, dec: PackedNet, wgt_total, base_m, base_f, need_dx, need_param_grads):
+    lib, st = L.lib(), L.stream_ptr()
+    d_dec = torch.empty_like(c.dec_out)
+    L.check(lib.dmv_obj_backward_dec(C.byref(c.cfg), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
+                                     L.ptr(wgt_total), None, base_m, base_f, L.ptr(d_dec), d_dec.shape[1], st))
+    return mlp_backward(dec, c.dec_saved, d_dec, c.N, need_dx=need_dx, need_param_grads=need_param_grads,
+                        drop_keep=c.dec_keep)
+
+
+def _enc_side(c, enc: PackedNet, p: L.DmvLatentBwd, dZ, wgt_total, zscale, dlogit_total, kl_wgt):
+    lib, st = L.lib(), L.stream_ptr()
+    d_enc = torch.zeros_like(c.enc_out)
+    need_mix = p.base_qmix != 0.0
+    L.check(lib.dmv_obj_backward_latent(
+        C.byref(c.cfg), C.byref(p), L.ptr(c.enc_out), L.ptr(c.Z), L.ptr(c.eps), c.Z.shape[1],
+        L.ptr(dZ), dZ.shape[1] if dZ is not None else 0, L.ptr(wgt_total), L.ptr(zscale),
+        L.ptr(c.comp_lp) if need_mix else None, L.ptr(c.terms[4]) if need_mix else None,
+        L.ptr(dlogit_total), L.ptr(kl_wgt), None, L.ptr(d_enc), st))
+    _, grads = mlp_backward(enc, c.enc_saved, d_enc, c.enc_rows, need_dx=False, need_param_grads=True,
+                            drop_keep=c.enc_keep)
+    return grads
+
+
+def _latent_params(**kw):
+    p = L.DmvLatentBwd()
+    p.base_prior = kw.get("prior", 0.0)
+    p.base_qown = kw.get("qown", 0.0)
+    p.base_qmix = kw.get("qmix", 0.0)
+    p.base_w = kw.get("w", 1.0)
+    p.kl_coef = kw.get("kl", 0.0)
+    p.own_live = int(kw.get("own_live", False))
+    p.mix_live = int(kw.get("mix_live", False))
+    p.use_zscale = int(kw.get("use_zscale", False))
+    p.mix_kind = kw.get("mix_kind", L.Q_STRATIFIED)
+    return p
+
+
+class _FusedObjective(torch.autograd.Function):
+    """outputs: (per-datapoint bound [B],) or (generator objective [B,K], encoder objective [B,K])."""
+
+    @staticmethod
+    def forward(ctx, dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, *params):
+        training = any(ctx.needs_input_grad[9:])
+        c = _forward_core(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, training)
+        ctx.c, ctx.dims, ctx.plan, ctx.enc, ctx.dec = c, dims, plan, enc, dec
+        ctx.set_materialize_grads(False)
+        k = plan.kind
+        if k in ("iwae", "miwae"):
+            return (_bound(c, plan, training),)
+        if k == "elbo_analytic":
+            return (_combine(c, (1, 0, 0, 0, 0)).reshape(c.B) - _kl(c).reshape(c.B),)
+        if k == "cvi":
+            return (_combine(c, (1, 0, 1, 0, -1)),)
+        if k == "mvb":
+            if plan.kl_analytic:
+                return (_combine(c, (0, 1, 0, 0, 0)) - _kl(c),)
+            return (_combine(c, (0, 1, 1, -1, 0)),)
+        if k == "mvb2":
+            gen_obj = _combine(c, (1, 0, 1, 0, -1))
+            if plan.kl_analytic:
+                enc_obj = _combine(c, (0, 1, 0, 0, 0)) - _kl(c)
+            else:
+                enc_obj = _combine(c, (0, 1, 1, -1, 0))
+            return gen_obj, enc_obj
+        raise NotImplementedError(k)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        c, dims, plan, enc, dec = ctx.c, ctx.dims, ctx.plan, ctx.enc, ctx.dec
+        n_enc = 2 * enc.dims.num_layers
+        n_dec = 2 * dec.dims.num_layers
+        g_enc_params = [None] * n_enc
+        g_dec_params = [None] * n_dec
+        k = plan.kind
+        nz, S = plan.nz, plan.nz * plan.I
+        B, G = c.B, c.G
+
+        def per_sample(g_bg):
+            """[B] or [B,G] upstream gradient -> per-sample weights [N] (rows (s, b, g)), divided by nz."""
+            g = g_bg.reshape(1, B, -1).float()
+            return (g / nz).expand(S, B, G).contiguous().reshape(-1)
+
+        if k in ("iwae", "miwae") and gouts[0] is not None:
+            g_b = gouts[0].float().contiguous()
+            wt = (c.wgt.reshape(S, B, G) * g_b.reshape(1, B, 1)).reshape(-1).contiguous()
+            dZ, g_dec_params = _dec_side(c, dec, wt, 1.0, 0.0, True, True)
+            mixture = c.q_kind == L.Q_STRATIFIED
+            dl = (c.dlogit * g_b.reshape(B, 1)).contiguous() if mixture else None
+            if mixture:
+                p = _latent_params(prior=1.0, qmix=-1.0, mix_live=not plan.STL, mix_kind=L.Q_STRATIFIED)
+            else:
+                p = _latent_params(prior=1.0, qown=-1.0, own_live=not (plan.STL or plan.DREG), use_zscale=plan.DREG)
+            g_enc_params = _enc_side(c, enc, p, dZ, wt, c.zscale, dl, None)
+        elif k == "elbo_analytic" and gouts[0] is not None:
+            g_b = gouts[0].float().contiguous()
+            wt = per_sample(g_b)
+            dZ, g_dec_params = _dec_side(c, dec, wt, 1.0, 0.0, True, True)
+            p = _latent_params(kl=-1.0)
+            g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, g_b.reshape(B, 1).contiguous())
+        elif k == "cvi" and gouts[0] is not None:
+            wt = per_sample(gouts[0])
+            dZ, g_dec_params = _dec_side(c, dec, wt, 1.0, 0.0, True, True)
+            p = _latent_params(prior=1.0, qmix=-1.0, mix_live=not plan.STL, mix_kind=L.Q_IMPUTATION)
+            g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, None)
+        elif k == "mvb" and gouts[0] is not None:
+            wt = per_sample(gouts[0])
+            dZ, g_dec_params = _dec_side(c, dec, wt, 0.0, 1.0, True, True)
+            if plan.kl_analytic:
+                p = _latent_params(kl=-1.0)
+                g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, gouts[0].float().contiguous())
+            else:
+                p = _latent_params(prior=1.0, qown=-1.0, own_live=not plan.STL)
+                g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, None)
+        elif k == "mvb2":
+            # vgiwae/shared/mvb2_manual_optimisation.py:6-8: the generator objective updates the decoder
+            # only, the encoder objective the encoder only (through the decoder's input gradient).
+            g_gen, g_enc = gouts
+            if g_gen is not None:
+                _, g_dec_params = _dec_side(c, dec, per_sample(g_gen), 1.0, 0.0, False, True)
+            if g_enc is not None:
+                wt = per_sample(g_enc)
+                dZ, _ = _dec_side(c, dec, wt, 0.0, 1.0, True, False)
+                if plan.kl_analytic:
+                    p = _latent_params(kl=-1.0)
+                    g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, g_enc.float().contiguous())
+                else:
+                    p = _latent_params(prior=1.0, qown=-1.0, own_live=not plan.STL)
+                    g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, None)
+        return (None,) * 9 + tuple(g_enc_params) + tuple(g_dec_params)
+
+
+def _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep):
+    return _FusedObjective.apply(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, *enc.params(), *dec.params())
+
+
+# ------------------------------------------------------------------------------------------ public API
+def estimate_iwelbo(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_latent_samples=1,
+                    num_importance_samples=1, STL=False, DREG=False, eps=None, enc_keep=None, dec_keep=None):
+    """IWAE bound averaged over the batch, and the per-datapoint bounds.  eps [nz, I, B, Zd]."""
+    assert not (STL and DREG), "Cannot use STL and DREG gradients at the same time."
+    assert not dims.q_is_mixture
+    plan = _Plan("iwae", num_latent_samples, num_importance_samples, STL=STL, DREG=DREG)
+    (per_b,) = _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep)
+    return per_b.mean(), per_b
+
+
+def estimate_elbo(dims, enc, dec, X, M, *, num_latent_samples=1, kl_analytic=True, STL=False, eps=None,
+                  enc_keep=None, dec_keep=None):
+    """VAE ELBO with analytic or Monte-Carlo KL.  eps [nz, B, Zd]."""
+    assert not (STL and kl_analytic), '"Sticking the Landing" cannot be used with analytical KL.'
+    assert not dims.q_is_mixture
+    if kl_analytic:
+        plan = _Plan("elbo_analytic", num_latent_samples, 1)
+    else:
+        plan = _Plan("iwae", num_latent_samples, 1, STL=STL)   # logsumexp over a single sample = identity
+    (per_b,) = _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep)
+    return per_b.mean(), per_b
+
+
+def estimate_multiple_iwelbo(dims, enc, dec, X, M, *, num_latent_samples=1, num_importance_samples_for_each_component=1,
+                             STL=False, looser=False, eps=None, enc_keep=None, dec_keep=None):
+    """MissSIWAE bound (stratified mixture encoder).  eps [nz, I, B, C, Zd]."""
+    assert dims.q_is_mixture
+    plan = _Plan("miwae", num_latent_samples, num_importance_samples_for_each_component, STL=STL, looser=looser)
+    (per_b,) = _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep)
+    return per_b.mean(), per_b
+
+
+def estimate_multiple_elbo(dims, enc, dec, X, M, *, num_latent_samples=1, STL=False, eps=None, enc_keep=None,
+                           dec_keep=None):
+    """MissSVAE stratified ELBO = sum_c pi_c * ratio_c.  eps [nz, B, C, Zd]."""
+    assert dims.q_is_mixture
+    plan = _Plan("miwae", num_latent_samples, 1, STL=STL, looser=True)
+    (per_b,) = _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep)
+    return per_b.mean(), per_b
+
+
+def mvb2_objectives(dims, enc, dec, Xt, M, *, num_latent_samples=1, STL=False, kl_analytic=False, eps=None,
+                    enc_keep=None, dec_keep=None):
+    """DeMissVAE: (generator objective, encoder objective), each [B, K].  Xt, M [B,K,D]; eps [nz,B,K,Zd].
+    Gradients: the first output reaches the decoder parameters only, the second the encoder parameters only."""
+    assert not dims.q_is_mixture
+    plan = _Plan("mvb2", num_latent_samples, 1, STL=STL, kl_analytic=kl_analytic)
+    return _run(dims, plan, enc, dec, Xt, M, eps, enc_keep, dec_keep)
+
+
+def cvi_objective(dims, enc, dec, Xt, M, *, num_latent_samples=1, STL=False, eps=None, enc_keep=None, dec_keep=None):
+    assert not dims.q_is_mixture
+    plan = _Plan("cvi", num_latent_samples, 1, STL=STL)
+    return _run(dims, plan, enc, dec, Xt, M, eps, enc_keep, dec_keep)[0]
+
+
+def mvb_objective(dims, enc, dec, Xt, M, *, num_latent_samples=1, STL=False, kl_analytic=False, eps=None,
+                  enc_keep=None, dec_keep=None):
+    assert not dims.q_is_mixture
+    plan = _Plan("mvb", num_latent_samples, 1, STL=STL, kl_analytic=kl_analytic)
+    return _run(dims, plan, enc, dec, Xt, M, eps, enc_keep, dec_keep)[0]

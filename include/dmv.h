@@ -1,0 +1,204 @@
+/*
+ * libdmv — MI355X (gfx950) kernels for the vgiwae training / evaluation hot path.
+ *
+ * C ABI: plain pointers and sizes, no C++ or torch types.  Every pointer named "device" is a
+ * device (HBM) address owned by the caller; the library never allocates or frees device memory
+ * and never synchronises the device: all work is enqueued on the `stream` argument
+ * (a hipStream_t passed as void*; NULL = the default stream).
+ *
+ * Return value of every int function: 0 = ok, < 0 = DMV_E_* (argument / shape / workspace
+ * errors), > 0 = a hipError_t from a launch.  dmv_strerror() names either.
+ *
+ * Each entry point cites the reference code it replaces (paths relative to the
+ * vsimkus/demiss-vae checkout).
+ */
+#ifndef DMV_H
+#define DMV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMV_VERSION 100
+
+enum {
+  DMV_OK = 0,
+  DMV_E_BADARG = -1,       /* null pointer / negative size / inconsistent dims */
+  DMV_E_UNSUPPORTED = -2,  /* enum value or size outside what the kernels are built for */
+  DMV_E_WORKSPACE = -3,    /* caller-provided workspace too small */
+};
+
+/* activation of the residual MLP (vgiwae/shared/neural_nets.py:8-13) */
+enum { DMV_ACT_RELU = 0, DMV_ACT_LEAKY_RELU = 1, DMV_ACT_TANH = 2, DMV_ACT_SIGMOID = 3 };
+
+/* how the first layer's input row is formed from (x, m)
+ * (vgiwae/models/vae.py:80-91 and the X*M products at models/iwae.py:136, models/vae.py:455) */
+enum {
+  DMV_IN_PLAIN = 0,         /* x                         in_dim = D   */
+  DMV_IN_MASKED = 1,        /* x * m                     in_dim = D   */
+  DMV_IN_CONCAT = 2,        /* [x, m]                    in_dim = 2 D */
+  DMV_IN_CONCAT_MASKED = 3, /* [x * m, m]                in_dim = 2 D */
+};
+
+/* decoder likelihood (vgiwae/models/vae.py:113-129, shared/bernoulli_between_m1_and_p1.py) */
+enum { DMV_GEN_NORMAL = 0, DMV_GEN_NORMAL_EPS = 1, DMV_GEN_BERN = 2, DMV_GEN_BERN_M1P1 = 3 };
+
+/* variational family used for log q (vgiwae/shared/iwae.py:26-30, 102-132) */
+enum {
+  DMV_Q_OWN = 0,        /* Gaussian of the sample's own component                         */
+  DMV_Q_STRATIFIED = 1, /* sum_c' pi_c' N(z; mu_c', sigma_c')  (MixtureSameFamily)        */
+  DMV_Q_IMPUTATION = 2, /* (1/G) sum_g' N(z; mu_g', sigma_g')  (DeMissVAE imputation mix) */
+};
+
+/* how per-sample log-weights are combined into a bound */
+enum {
+  DMV_BOUND_LSE = 0,      /* logsumexp over (i, g) of log_w (+ log pi_g) - log I, mean over nz:
+                             models/iwae.py:70-90 (G = 1), models/multiple_iwae.py:124-140 */
+  DMV_BOUND_WEIGHTED = 1, /* sum_g pi_g (logsumexp_i log_w - log I), mean over nz:
+                             models/multiple_iwae.py:142-159; with I = 1 models/multiple_vae.py:152-158 */
+  DMV_BOUND_PER_COMPONENT = 2, /* mean over nz of each (b, g): models/mvbvae.py:108-109,134-137 */
+};
+
+/* Shape of a residual fully-connected network (vgiwae/shared/neural_nets.py:79-133):
+ *   a0 = act(W0 x + b0); for each block: t = drop(act(W1 a + b1)); a = act(a + W2 t + b2);
+ *   y = Wf a + bf.
+ * Layer order everywhere below: initial, block0.linear0, block0.linear1, ..., final
+ * (2*nb + 2 layers); weights are nn.Linear layout [out][in] row-major fp32. */
+typedef struct DmvNet {
+  int32_t in_dim;
+  int32_t out_dim;
+  int32_t hidden;   /* 1..256 */
+  int32_t nb;       /* residual blocks, 0..8 */
+  int32_t act;      /* DMV_ACT_* */
+  float dropout_p;  /* 0 = none */
+} DmvNet;
+
+int dmv_version(void);
+const char* dmv_strerror(int rc);
+
+/* ----- weight packing ---------------------------------------------------------------------
+ * The MLP kernels read weights in MFMA-fragment order (both W and W^T, zero padded to 32-wide
+ * tiles).  dmv_mlp_pack rewrites the 2*nb+2 nn.Linear tensors into `packed`
+ * (dmv_mlp_packed_floats(net) floats).  Call it again whenever the weights change. */
+size_t dmv_mlp_packed_floats(const DmvNet* net);
+int dmv_mlp_pack(const DmvNet* net, const float* const* weights /* host array of device ptrs */,
+                 const float* const* biases, float* packed /* device */, void* stream);
+
+/* padded widths used for activations and outputs: 32*ceil(n/32) */
+int32_t dmv_pad32(int32_t n);
+
+/* ----- forward ----------------------------------------------------------------------------
+ * Replaces ResidualFCNetwork.forward (vgiwae/shared/neural_nets.py:127-133) on `rows` rows.
+ *   x [rows][ldx] fp32, m [rows][ldm] uint8 (only for the masked / concat input modes, D = x width)
+ *   y [rows][ldy], ldy >= dmv_pad32(out_dim): columns >= out_dim are written as zeros
+ *   saved: NULL for inference, or dmv_mlp_saved_floats(net, rows) floats that dmv_mlp_backward reads
+ *   drop_keep: NULL, or nb keep-masks [nb][rows][hidden] uint8 (1 = keep), scaled by 1/(1-p) */
+size_t dmv_mlp_saved_floats(const DmvNet* net, int64_t rows);
+int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t in_mode, int32_t D,
+                    const float* x, int64_t ldx, const uint8_t* m, int64_t ldm, int64_t rows,
+                    float* y, int64_t ldy, float* saved, const uint8_t* drop_keep, void* stream);
+
+/* ----- backward ---------------------------------------------------------------------------
+ * Replaces autograd's backward of the same network: given gy [rows][ldgy] (ldgy >= pad32(out_dim),
+ * columns >= out_dim must be zero) computes
+ *   dx [rows][lddx] (lddx >= pad32(in_dim); NULL = not needed), and, when grad_w != NULL, the
+ *   parameter gradients, written (beta = 0) or accumulated (beta = 1) into the 2*nb+2 tensors
+ *   grad_w[l] ([out][in]) and grad_b[l].
+ * ws: workspace of dmv_mlp_backward_ws_bytes(net, rows) bytes. */
+size_t dmv_mlp_backward_ws_bytes(const DmvNet* net, int64_t rows);
+int dmv_mlp_backward(const DmvNet* net, const float* packed, const float* saved,
+                     const uint8_t* drop_keep, const float* gy, int64_t ldgy, int64_t rows,
+                     float* dx, int64_t lddx, float* const* grad_w, float* const* grad_b, float beta,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ----- objective --------------------------------------------------------------------------
+ * Sample rows are ordered n = (s*B + b)*G + g with s = z*I + i  (reference tensor shapes
+ * [nz, I, B, (G,) .]).  Encoder-output addressing (in floats, per datapoint b and component g):
+ *   mu(b,g,j)  = enc[b*enc_sb + g*enc_sg + j]
+ *   raw(b,g,j) = enc[b*enc_sb + g*enc_sg + raw_off + j],  sigma = softplus(raw) (+1e-5 if q_eps)
+ *   logit(b,g) = enc[b*enc_sb + logit_off + g]            (stratified mixtures only)            */
+typedef struct DmvObjCfg {
+  int32_t B, G, nz, I;
+  int32_t D, Zd;
+  int32_t gen_dist;        /* DMV_GEN_*  */
+  int32_t q_eps;           /* 1: variational sigma = softplus(raw) + 1e-5 */
+  int32_t x_per_component; /* 0: X, M are [B][D]; 1: X, M are [B][G][D] */
+  int64_t enc_sb, enc_sg, raw_off, logit_off;
+} DmvObjCfg;
+
+/* z = mu + sigma*eps (vgiwae/models/vae.py:303; Normal.rsample / StratifiedMixtureSameFamily.rsample
+ * at shared/stratified_mixture_same_family.py:16-22).  eps, Z, eps_out: [N][ldz], N = nz*I*B*G,
+ * ldz >= Zd; columns in [Zd, ldz) are zeroed.  eps == NULL: standard normals from Philox4x32-10
+ * (stream `seed`, element counter `offset` + n*ldz + j); eps_out (nullable) receives the noise used.
+ * comp_idx (nullable, int64 [N], cfg->G must be 1): draw row n from component comp_idx[n] of the
+ * stratified encoder output (sampling the mixture without stratification, models/vae.py:298-301). */
+int dmv_latent_sample(const DmvObjCfg* cfg, const float* enc, const float* eps, uint64_t seed, uint64_t offset,
+                      int64_t ldz, const int64_t* comp_idx, float* Z, float* eps_out, void* stream);
+
+/* Per-sample terms (vgiwae/shared/iwae.py:17-45, 66-90, 102-132; models/mvbvae.py:83-137):
+ *   terms[0][n] = sum_d M_d log p(x_d|z)      terms[1][n] = sum_d log p(x_d|z)
+ *   terms[2][n] = sum_j log N(z_j;0,1)        terms[3][n] = log q_own(z)   terms[4][n] = log q_mix(z)
+ * dec [N][ld_dec] decoder outputs, Z [N][ldz].  q_kind DMV_Q_OWN leaves terms[4] = terms[3];
+ * otherwise the mixture has mix_C components taken from the encoder output of the row's datapoint.
+ * terms: 5*N floats.  comp_lp (nullable, [N][mix_C]) receives each component's log density
+ * (needed by dmv_obj_backward_latent when the mixture enters the loss). */
+int dmv_obj_terms(const DmvObjCfg* cfg, int32_t q_kind, int32_t mix_C, const float* dec, int64_t ld_dec,
+                  const float* X, const uint8_t* M, const float* Z, int64_t ldz, const float* enc,
+                  float* terms, float* comp_lp, void* stream);
+
+/* Bounds from the terms: log_w = terms[0] + terms[2] - terms[q] (q = 3 for DMV_Q_OWN else 4), combined
+ * per datapoint by `kind` (DMV_BOUND_LSE / DMV_BOUND_WEIGHTED); use_logpi adds log pi_g inside the
+ * logsumexp (models/multiple_iwae.py:127).  One wavefront per datapoint.
+ *   bound [B] per-datapoint bounds; mean_out (nullable) their mean;
+ *   log_w (nullable) [N]; wgt (nullable) [N] = d(sum_b bound_b)/d log_w_n;
+ *   zscale (nullable) [N] = softmax_i(log_w) when dreg (models/iwae.py:78-81,115-117) else 1;
+ *   dlogit (nullable) [B][G] = d(sum_b bound_b)/d logit through the pi factors. */
+int dmv_obj_bound(const DmvObjCfg* cfg, int32_t kind, int32_t q_kind, int32_t use_logpi, int32_t dreg,
+                  const float* enc, const float* terms, float* log_w, float* bound, float* mean_out,
+                  float* wgt, float* zscale, float* dlogit, void* stream);
+
+/* DeMissVAE per-(b,g) objectives (models/mvbvae.py:108-109,134-137; I must be 1):
+ *   obj[b*G+g] = mean_z sum_t coef5[t] * terms[t][n];  mean_out (nullable) = mean over (b,g). */
+int dmv_obj_combine(const DmvObjCfg* cfg, const float* coef5 /* host */, const float* terms, float* obj,
+                    float* mean_out, void* stream);
+
+/* kl[b*G+g] = sum_j KL(N(mu,sigma) || N(0,1))  (models/vae.py:404-406, models/mvbvae.py:119-122) */
+int dmv_kl_std_normal(const DmvObjCfg* cfg, const float* enc, float* kl, void* stream);
+
+/* Decoder-side backward: d_dec[n][c] = gscale * wgt[n] * (base_m * M_d + base_f) * d log p(x_d|z)/d dec[n][c]
+ * for every column c < ld_ddec (zeros past the parameter count).  wgt == NULL means 1, gscale (device
+ * scalar, nullable) is the upstream gradient of the scalar loss. */
+int dmv_obj_backward_dec(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec, const float* X, const uint8_t* M,
+                         const float* wgt, const float* gscale, float base_m, float base_f,
+                         float* d_dec, int64_t ld_ddec, void* stream);
+
+/* Latent-side backward: gradient of
+ *   loss = sum_n wgt[n] * (base_prior*terms[2] + base_qown*terms[3] + base_qmix*terms[4])[n]
+ *          + (decoder path, given as dZ) + base_w * sum_{b,g} dlogit[b][g]*logit[b][g] (linearised)
+ *          + kl_coef * sum_{b,g} kl_wgt[b][g] * KL          (kl_wgt == NULL means 1)
+ * with respect to the encoder output, through z = mu + sigma*eps (times zscale[n] when use_zscale)
+ * and, when own_live / mix_live, through q's own parameters (no "sticking the landing").
+ * d_enc uses the same addressing as enc and must be zero-filled by the caller. */
+typedef struct DmvLatentBwd {
+  float base_prior, base_qown, base_qmix, base_w, kl_coef;
+  int32_t own_live, mix_live, use_zscale;
+  int32_t mix_kind; /* DMV_Q_STRATIFIED or DMV_Q_IMPUTATION */
+} DmvLatentBwd;
+int dmv_obj_backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const float* enc, const float* Z,
+                            const float* eps, int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
+                            const float* zscale, const float* comp_lp, const float* qmix, const float* dlogit,
+                            const float* kl_wgt, const float* gscale, float* d_enc, void* stream);
+
+/* Streaming logsumexp for the K-sample log-likelihood (test/refit_encoder_using_iwae_and_estimate_loglik.py
+ * :189-222): folds a chunk of Kc samples per datapoint (terms of that chunk, rows k*B + b) into
+ * run_max / run_sum [B] (initialise to -inf / 0).  log-lik_b = run_max + log(run_sum) - log(K). */
+int dmv_lse_update(int32_t B, int64_t Kc, const float* terms, int32_t q_term /* 3 own, 4 mixture */,
+                   float* run_max, float* run_sum, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMV_H */

