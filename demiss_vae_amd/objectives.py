@@ -209,7 +209,7 @@ def _latent_params(**kw):
     p.own_live = int(kw.get("own_live", False))
     p.mix_live = int(kw.get("mix_live", False))
     p.use_zscale = int(kw.get("use_zscale", False))
-    p.mix_kind = kw.get("mix_kind", L.Q_STRATIFIED)
+    p.mix_kind = kw.get("mix_kind", L.Q_OWN)   # no mixture logits unless asked for
     return p
 
 

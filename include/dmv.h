@@ -185,7 +185,7 @@ int dmv_obj_backward_dec(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec,
 typedef struct DmvLatentBwd {
   float base_prior, base_qown, base_qmix, base_w, kl_coef;
   int32_t own_live, mix_live, use_zscale;
-  int32_t mix_kind; /* DMV_Q_STRATIFIED or DMV_Q_IMPUTATION */
+  int32_t mix_kind; /* DMV_Q_OWN (no mixture), DMV_Q_STRATIFIED (has logits) or DMV_Q_IMPUTATION */
 } DmvLatentBwd;
 int dmv_obj_backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const float* enc, const float* Z,
                             const float* eps, int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
