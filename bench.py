@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""Benchmark of the vgiwae hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A step = one data-parallel training step of the UCI-gas MissIWAE model (K=5 importance samples, STL,
+mask-concat encoder (16,32,2,256), decoder (16,16,2,256)): fused objective forward + backward over one
+synthetic batch already resident in HBM, gradient all-reduce over RCCL when N > 1, clip-norm 5 and one
+Adam(amsgrad) update (so the weight re-pack that a real training step needs is inside the timed region).
+`value` = importance-weighted samples (batch x K) per second summed over all ranks; per-GPU batch is
+fixed as N grows (weak scaling).
+
+The JSON line also carries
+  roofline      fp32-MFMA roofline of the dominant kernel (decoder MLP kernels), timed live with events
+  cpu_baseline  the CPU oracle (stock PyTorch ops) timed on this host on a bounded sample of the workload
+  extra         fwd+bwd-only rate, the yaml batch size (512), the DeMissVAE step and the LL-eval rate
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X fp32 matrix peak (dense)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32768, help="datapoints per GPU per step")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    return ap.parse_args()
+
+
+def mlp_flops_per_row(spec):
+    return 2 * (spec.in_dim * spec.hidden + spec.nb * 2 * spec.hidden * spec.hidden + spec.hidden * spec.out_dim)
+
+
+def make_gas(device, B, seed=20220118):
+    import demiss_vae_amd as dmv
+    from oracle.recipes import NetSpec, make_params, make_batch
+    enc_s, dec_s = NetSpec(16, 32, 2, 256), NetSpec(16, 16, 2, 256)
+    ep, dp = make_params(enc_s, seed), make_params(dec_s, seed + 1)
+
+    def packed(spec, params):
+        ws = [params[n + ".weight"].to(device).requires_grad_(True) for n in spec.layer_names()]
+        bs = [params[n + ".bias"].to(device).requires_grad_(True) for n in spec.layer_names()]
+        return dmv.PackedNet(dmv.NetDims(spec.in_dim, spec.out_dim, spec.nb, spec.hidden), ws, bs)
+
+    enc, dec = packed(enc_s, ep), packed(dec_s, dp)
+    dims = dmv.ModelDims(D=8, Zd=16, gen_dist="normal_with_eps", q_dist="normal_with_eps", encoder_use_mis_mask=True)
+    X, M = make_batch(seed + 2, B, 8)
+    return dims, enc, dec, enc_s, dec_s, X.to(device), M.to(device)
+
+
+def timed(fn, steps, warmup, barrier):
+    for _ in range(warmup):
+        fn()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    barrier()
+    return (time.perf_counter() - t0) / steps
+
+
+def event_time(fn, reps):
+    """Average device time of fn() in seconds, bracketed by events on the current stream."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def kernel_roofline(dec, dec_s, rows, device):
+    """Times the three decoder MLP kernels on their own (forward, input-gradient chain, weight-gradient
+    GEMM + split fold) and returns the roofline record of the slowest, plus all three."""
+    import ctypes as C
+    import demiss_vae_amd as dmv
+    from demiss_vae_amd import _lib as L
+    from demiss_vae_amd.mlp import mlp_forward, pad32
+    Z = torch.randn(rows, dec_s.in_dim, device=device)
+    y, saved = mlp_forward(dec, Z, dec_s.in_dim, rows, save=True)
+    gy = torch.randn_like(y)
+    gy[:, dec_s.out_dim:] = 0
+    lib, st = L.lib(), L.stream_ptr()
+    nbytes = lib.dmv_mlp_backward_ws_bytes(C.byref(dec.c), rows)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    dx = torch.empty(rows, pad32(dec_s.in_dim), device=device)
+    gws = [torch.empty_like(w) for w in dec.weights]
+    gbs = [torch.empty_like(b) for b in dec.biases]
+    packed = dec.packed()
+
+    def fwd():
+        L.check(lib.dmv_mlp_forward(C.byref(dec.c), L.ptr(packed), L.IN_PLAIN, dec_s.in_dim, L.ptr(Z), dec_s.in_dim, None, 0,
+                                    rows, L.ptr(y), y.shape[1], L.ptr(saved), None, st))
+
+    def chain():
+        L.check(lib.dmv_mlp_backward(C.byref(dec.c), L.ptr(packed), L.ptr(saved), None, L.ptr(gy), gy.shape[1], rows,
+                                     L.ptr(dx), dx.shape[1], None, None, 0.0, L.ptr(ws), nbytes, st))
+
+    def chain_wgrad():
+        L.check(lib.dmv_mlp_backward(C.byref(dec.c), L.ptr(packed), L.ptr(saved), None, L.ptr(gy), gy.shape[1], rows,
+                                     L.ptr(dx), dx.shape[1], L.ptr_array(gws), L.ptr_array(gbs), 0.0, L.ptr(ws), nbytes, st))
+
+    reps = 10
+    t_f, t_c, t_cw = event_time(fwd, reps), event_time(chain, reps), event_time(chain_wgrad, reps)
+    flops = rows * mlp_flops_per_row(dec_s)
+    parts = {
+        "k_mlp_fwd": {"ms": t_f * 1e3, "tflops": flops / t_f / 1e12},
+        "k_mlp_bwd": {"ms": t_c * 1e3, "tflops": flops / t_c / 1e12},
+        "k_mlp_wgrad+k_wgrad_reduce": {"ms": (t_cw - t_c) * 1e3, "tflops": flops / max(t_cw - t_c, 1e-9) / 1e12},
+    }
+    name = max(parts, key=lambda k: parts[k]["ms"])
+    ach = parts[name]["tflops"]
+    roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "flops_per_launch": flops, "ms_per_launch": round(parts[name]["ms"], 4),
+            "all_kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in parts.items()}}
+    return roof
+
+
+def cpu_baseline(budget_s=15.0):
+    """The CPU oracle (stock PyTorch ops + autograd, the op sequence the reference issues) on the yaml batch
+    (B=512, K=5) of the same workload, repeated for about `budget_s` seconds on this host's cores."""
+    from oracle import core
+    from oracle.recipes import NetSpec, make_params, make_batch, make_noise
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    enc_s, dec_s = NetSpec(16, 32, 2, 256), NetSpec(16, 16, 2, 256)
+    spec = core.ModelSpec(D=8, Zd=16, enc=enc_s, dec=dec_s, encoder_use_mis_mask=True)
+    ep = {k: v.requires_grad_(True) for k, v in make_params(enc_s, 1).items()}
+    dp = {k: v.requires_grad_(True) for k, v in make_params(dec_s, 2).items()}
+    B, K = 512, 5
+    X, M = make_batch(3, B, 8)
+
+    def step():
+        eps = torch.randn(1, K, B, 16)
+        bound, _ = core.estimate_iwelbo(spec, ep, dp, X, M, eps, STL=True)
+        (-bound).backward()
+        for p in list(ep.values()) + list(dp.values()):
+            p.grad = None
+
+    for _ in range(3):
+        step()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(B * K / dt, 1), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{n} fwd+bwd steps of B=512, K=5 (the yaml batch) in {budget_s:.0f} s; CPU oracle = stock PyTorch ops"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    import demiss_vae_amd as dmv
+    from demiss_vae_amd import rng
+    from demiss_vae_amd.parallel import allreduce_grads
+    rng.set_seed(20220118 + rank)
+
+    B, K = args.batch, 5
+    dims, enc, dec, enc_s, dec_s, X, M = make_gas(device, B, seed=20220118 + 1000 * rank)
+    params = enc.params() + dec.params()
+    opt = torch.optim.Adam([{"params": dec.params(), "amsgrad": True, "lr": 1e-3},
+                            {"params": enc.params(), "amsgrad": True, "lr": 1e-3}], fused=True)
+
+    def barrier():
+        if dist:
+            td.barrier()
+
+    def fwd_bwd():
+        bound, _ = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=1, num_importance_samples=K, STL=True)
+        (-bound).backward()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        fwd_bwd()
+        if dist:
+            allreduce_grads(params)
+        torch.nn.utils.clip_grad_norm_(params, 5.0, foreach=True)
+        opt.step()
+
+    dt = timed(step, args.steps, args.warmup, barrier)
+    if dist:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = t.item()
+
+    out = None
+    if rank == 0:
+        value = world * B * K / dt
+        flops_per_sample = (mlp_flops_per_row(enc_s) + K * mlp_flops_per_row(dec_s)) * 3 / K
+        out = {
+            "metric": "IWAE fwd+bwd samples/sec (batch x K)", "value": round(value, 1), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"UCI-gas MissIWAE K=5 STL training step (fwd+bwd+allreduce+clip+Adam), "
+                                   f"B={B} per GPU, enc (16,32,2,256) mask-concat, dec (16,16,2,256), D=8, Zd=16",
+                       "global_batch": world * B, "K": K, "parallelism": f"dp{world}"},
+            "step_tflops": round(value * flops_per_sample / 1e12, 2),
+            "step_frac_of_fp32_mfma_peak": round(value * flops_per_sample / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+        }
+    if rank == 0 and world == 1:
+        out["roofline"] = kernel_roofline(dec, dec_s, B * K, device)
+        if not args.no_extra:
+            extra = {}
+            t_fb = timed(lambda: (opt.zero_grad(set_to_none=True), fwd_bwd()), max(5, args.steps // 2), 2, barrier)
+            extra["fwd_bwd_only_samples_per_s"] = round(B * K / t_fb, 1)
+            # the yaml batch size (configs/uci_gas/compare/mis50/iwae_i5_encm_stl.yaml: batch_size 512)
+            d2 = make_gas(device, 512)
+            dims2, enc2, dec2, X2, M2 = d2[0], d2[1], d2[2], d2[5], d2[6]
+            p2 = enc2.params() + dec2.params()
+            opt2 = torch.optim.Adam(p2, lr=1e-3, amsgrad=True, fused=True)
+
+            def step512():
+                opt2.zero_grad(set_to_none=True)
+                b, _ = dmv.estimate_iwelbo(dims2, enc2, dec2, X2, M2, num_latent_samples=1, num_importance_samples=K, STL=True)
+                (-b).backward()
+                torch.nn.utils.clip_grad_norm_(p2, 5.0, foreach=True)
+                opt2.step()
+
+            t512 = timed(step512, 50, 10, barrier)
+            extra["yaml_batch_512"] = {"ms_per_step": round(t512 * 1e3, 4), "samples_per_s": round(512 * K / t512, 1)}
+            try:
+                from demiss_vae_amd.bench_extra import demiss_toy_step, loglik_eval_rate
+                extra["demiss_toy_mvb2"] = demiss_toy_step(device)
+                extra["loglik_eval_K50000"] = loglik_eval_rate(device)
+            except ImportError:
+                pass
+            out["extra"] = extra
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

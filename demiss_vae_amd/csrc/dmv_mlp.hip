@@ -131,12 +131,20 @@ __device__ __forceinline__ void store_rows(const f32x16 (&v)[NT], float* __restr
     }
 }
 
+// relu (every shipped config) gets a branch-free path; the other activations share a generic one
 template <int NT>
 __device__ __forceinline__ void apply_act(f32x16 (&v)[NT], int act) {
+  if (act == DMV_ACT_RELU) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[t][r] = dmv_act(v[t][r], act);
+      for (int r = 0; r < 16; ++r) v[t][r] = fmaxf(v[t][r], 0.f);
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll 1
+      for (int r = 0; r < 16; ++r) v[t][r] = dmv_act(v[t][r], act);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -290,14 +298,25 @@ struct BwdArgs {
 // v *= act'(saved output)
 template <int NT>
 __device__ __forceinline__ void mul_act_grad(f32x16 (&v)[NT], const float* __restrict__ saved_row, int h, int act) {
+  if (act == DMV_ACT_RELU) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 y = *(const f32x4*)(saved_row + 32 * t + 8 * q + 4 * h);
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 y = *(const f32x4*)(saved_row + 32 * t + 8 * q + 4 * h);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[t][4 * q + e] *= dmv_act_grad(y[e], act);
-    }
+        for (int e = 0; e < 4; ++e) v[t][4 * q + e] = y[e] > 0.f ? v[t][4 * q + e] : 0.f;
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 y = *(const f32x4*)(saved_row + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[t][4 * q + e] *= dmv_act_grad(y[e], act);
+      }
+  }
 }
 
 template <int NT>
@@ -339,9 +358,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
     zero<NT>(dT);
     gemm_hh<NT>((const f32x4*)(a.packed + a.L.wt[l2]), lane, dA, dT);
     // through dropout and the inner activation
-    {
+    if (!a.drop_keep) {
+      mul_act_grad<NT>(dT, a.acts + l1 * act_stride + rl * Hp, h, a.act);
+    } else {
       const float* trow = a.acts + l1 * act_stride + rl * Hp;
-      const uint8_t* keep = a.drop_keep ? a.drop_keep + ((int64_t)blk * a.rows + rl) * a.hidden : nullptr;
+      const uint8_t* keep = a.drop_keep + ((int64_t)blk * a.rows + rl) * a.hidden;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -349,14 +370,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
           const f32x4 y = *(const f32x4*)(trow + 32 * t + 8 * q + 4 * h);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float f;
-            if (keep) {
-              const int n = 32 * t + 8 * q + 4 * h + e;
-              const bool kp = n < a.hidden && keep[n];
-              f = kp ? a.drop_scale * dmv_act_grad(y[e] / a.drop_scale, a.act) : 0.f;
-            } else {
-              f = dmv_act_grad(y[e], a.act);
-            }
+            const int n = 32 * t + 8 * q + 4 * h + e;
+            const bool kp = n < a.hidden && keep[n];
+            // the saved value is post-dropout: undo the 1/(1-p) scaling to get the activation output
+            const float f = kp ? a.drop_scale * dmv_act_grad(y[e] / a.drop_scale, a.act) : 0.f;
             dT[t][4 * q + e] *= f;
           }
         }
@@ -420,9 +437,115 @@ struct WgradArgs {
   float* slab;
 };
 
+// One block of TN x TK tiles over rows [r_begin, r_end).  Compile-time tile counts keep the loop free of
+// branches; loads are unconditional with the row clamped into the slice, so no exec-masked region (and
+// no vmcnt(0)) separates a load from its use.  A ring of 4 reduction steps (2 rows each) is kept in
+// flight: a slot is refilled with the step 4 ahead right after its MFMAs issue (one wave per SIMD, so
+// latency has to be covered by the wave's own MFMAs: 3 steps = 48 MFMAs at 4x4 tiles).
+template <int TN, int TK>
+__device__ __forceinline__ void wgrad_block(const WgradLayer& Ly, int nb0, int kb0, int64_t r_begin, int64_t r_end,
+                                            float* __restrict__ slab, int lane) {
+  const int j = lane & 31, h = lane >> 5;
+  f32x16 acc[TN][TK];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int k = 0; k < TK; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+  float bsum[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) bsum[i] = 0.f;
+
+  const float* Yp = Ly.dY + 32 * nb0 + j;
+  const float* Xp = Ly.X + 32 * kb0 + j;
+  const int64_t r_last = r_end - 1;
+  float ya[4][TN], xb[4][TK];
+  auto load_step = [&](int64_t rr0, float (&yy)[TN], float (&xx)[TK]) {
+    const int64_t rr = rr0 + h;
+    const int64_t rc = rr < r_end ? rr : r_last;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) yy[i] = Yp[rc * Ly.ldy + 32 * i];
+#pragma unroll
+    for (int k = 0; k < TK; ++k) xx[k] = Xp[rc * Ly.ldx + 32 * k];
+  };
+  auto fma_step = [&](const float (&yy)[TN], const float (&xx)[TK]) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      bsum[i] += yy[i];
+#pragma unroll
+      for (int k = 0; k < TK; ++k) acc[i][k] = MFMA(yy[i], xx[k], acc[i][k]);
+    }
+  };
+  const int64_t n_rows = r_end - r_begin;
+  const int64_t n_steps = n_rows >> 1;       // steps with both rows inside the slice
+  const int64_t n_groups = n_steps >> 2;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) load_step(r_begin + 2 * u, ya[u], xb[u]);
+  int64_t r = r_begin;
+  for (int64_t g = 0; g < n_groups; ++g, r += 8) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      fma_step(ya[u], xb[u]);
+      load_step(r + 8 + 2 * u, ya[u], xb[u]);
+      // pin the program order: without it the scheduler sinks every refill to the end of the iteration
+      // and the first slot of the next iteration is waited for right after it was issued
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // remainder: the ring already holds the next 4 steps (rows clamped)
+  const int rem = (int)(n_steps & 3);
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+    if (u < rem) fma_step(ya[u], xb[u]);
+  if (n_rows & 1) {
+    // a last single row: only the h = 0 half is inside the slice
+    float yy[TN], xx[TK];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u == rem) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) yy[i] = h == 0 ? ya[u][i] : 0.f;
+#pragma unroll
+        for (int k = 0; k < TK; ++k) xx[k] = h == 0 ? xb[u][k] : 0.f;
+      }
+    fma_step(yy, xx);
+  }
+
+  const int Kp = 32 * Ly.kt;
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int k = 0; k < TK; ++k)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int n = 32 * (nb0 + i) + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+        slab[Ly.slab_w + (int64_t)n * Kp + 32 * (kb0 + k) + j] = acc[i][k][rr];
+      }
+  if (kb0 == 0) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const float s = bsum[i] + __shfl_xor(bsum[i], 32);
+      if (h == 0) slab[Ly.slab_b + 32 * (nb0 + i) + j] = s;
+    }
+  }
+}
+
+template <int TN>
+__device__ __forceinline__ void wgrad_dispatch_k(int tk, const WgradLayer& Ly, int nb0, int kb0, int64_t r0, int64_t r1,
+                                                 float* slab, int lane) {
+  switch (tk) {
+    case 1: wgrad_block<TN, 1>(Ly, nb0, kb0, r0, r1, slab, lane); break;
+    case 2: wgrad_block<TN, 2>(Ly, nb0, kb0, r0, r1, slab, lane); break;
+    case 3: wgrad_block<TN, 3>(Ly, nb0, kb0, r0, r1, slab, lane); break;
+    default: wgrad_block<TN, 4>(Ly, nb0, kb0, r0, r1, slab, lane); break;
+  }
+}
+
 __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(WgradArgs a) {
   const int lane = threadIdx.x & 63;
-  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // wave-uniform by construction; readfirstlane lets the compiler keep the whole work decomposition scalar
+  const int64_t wid = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int split = (int)(wid / a.waves_per_split);
   if (split >= a.splits) return;
   const int wb = (int)(wid % a.waves_per_split);
@@ -432,73 +555,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(WgradArgs a) {
   const int bi = wb - Ly.wave0;
   const int nb0 = (bi / Ly.kblk) * 4, kb0 = (bi % Ly.kblk) * 4;
   const int tn = min(4, Ly.nt - nb0), tk = min(4, Ly.kt - kb0);
-  const int j = lane & 31, h = lane >> 5;
-
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-
   const int64_t r_begin = (int64_t)split * a.rows_per_split;
   const int64_t r_end = min(a.rows, r_begin + a.rows_per_split);
-  const float* Yp = Ly.dY + 32 * nb0 + j;
-  const float* Xp = Ly.X + 32 * kb0 + j;
-
-  // A ring of 4 reduction steps (2 rows each): a slot is refilled with the step 4 ahead as soon as its
-  // MFMAs have issued, so every load has ~48 MFMAs (3 steps) of latency cover at one wave per SIMD.
-  float ya[4][4], xb[4][4];
-  auto load_step = [&](int64_t rr0, float (&yy)[4], float (&xx)[4]) {
-    const int64_t rr = rr0 + h;
-    const bool ok = rr < r_end;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      yy[i] = (ok && i < tn) ? Yp[rr * Ly.ldy + 32 * i] : 0.f;
-      xx[i] = (ok && i < tk) ? Xp[rr * Ly.ldx + 32 * i] : 0.f;
-    }
-  };
-#pragma unroll
-  for (int u = 0; u < 4; ++u) load_step(r_begin + 2 * u, ya[u], xb[u]);
-  for (int64_t r = r_begin; r < r_end; r += 8) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bsum[i] += ya[u][i];
-        if (i < tn) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (k < tk) acc[i][k] = MFMA(ya[u][i], xb[u][k], acc[i][k]);
-        }
-      }
-      load_step(r + 8 + 2 * u, ya[u], xb[u]);
-    }
-  }
-
   float* slab = a.slab + (int64_t)split * a.slab_stride;
-  const int Kp = 32 * Ly.kt;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i >= tn) break;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k >= tk) break;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = 32 * (nb0 + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
-        slab[Ly.slab_w + (int64_t)n * Kp + 32 * (kb0 + k) + j] = acc[i][k][r];
-      }
-    }
-  }
-  if (kb0 == 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float s = bsum[i] + __shfl_xor(bsum[i], 32);
-      if (i < tn && h == 0) slab[Ly.slab_b + 32 * (nb0 + i) + j] = s;
-    }
+  switch (tn) {
+    case 1: wgrad_dispatch_k<1>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
+    case 2: wgrad_dispatch_k<2>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
+    case 3: wgrad_dispatch_k<3>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
+    default: wgrad_dispatch_k<4>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
   }
 }
 

@@ -1,0 +1,61 @@
+"""Multi-GPU pieces of the hot path: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI on
+the GPU box, "gloo" in the CPU tests).
+
+Training is pure data parallelism: datapoints are independent and every loss is a mean over the batch,
+so each rank runs the fused step on its own shard and the only exchange is ONE flat all-reduce of all
+parameter gradients per step (UCI models: 2-4 MB, latency-bound, so a single message beats per-tensor
+buckets), done before gradient clipping so the clip norm is that of the averaged gradient.
+
+The K-sample log-likelihood shards either test points (no exchange until the final sum) or importance
+samples of the same points; the latter combines per-rank (max, sum-exp) pairs with a max all-reduce
+followed by a sum all-reduce of the rescaled sums (two messages of B floats).
+"""
+import math
+from typing import Sequence
+
+import torch
+import torch.distributed as dist
+from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+
+
+def world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def allreduce_grads(params: Sequence[torch.Tensor], group=None):
+    """Average .grad over ranks with one flat all-reduce (equal shard sizes assumed)."""
+    if world() == 1:
+        return
+    with_grad = [p for p in params if p.grad is not None]
+    if not with_grad:
+        return
+    flat = _flatten_dense_tensors([p.grad for p in with_grad])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(dist.get_world_size(group))
+    for p, g in zip(with_grad, _unflatten_dense_tensors(flat, [p.grad for p in with_grad])):
+        p.grad.copy_(g)
+
+
+def lse_allreduce(run_max: torch.Tensor, run_sum: torch.Tensor, group=None):
+    """Combine per-rank streaming-logsumexp states (max m_r, s_r = sum exp(x - m_r)) into the global one:
+    m = max_r m_r (all-reduce MAX), s = sum_r s_r exp(m_r - m) (all-reduce SUM).  Returns (m, s)."""
+    if world() == 1:
+        return run_max, run_sum
+    m = run_max.clone()
+    dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    s = run_sum * torch.exp(run_max - m)
+    s = torch.where(torch.isfinite(run_max), s, torch.zeros_like(s))
+    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    return m, s
+
+
+def shard_slice(n: int, r: int = None, w: int = None):
+    """Contiguous, near-equal shard [lo, hi) of n items for rank r of w."""
+    r = rank() if r is None else r
+    w = world() if w is None else w
+    per = math.ceil(n / w)
+    return min(n, r * per), min(n, (r + 1) * per)
