@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Turn the rocprofv3 output of tools/prof.sh (gpurun_out/prof_k) into profiles/<tag>_*.csv + a short .md."""
+import collections
+import csv
+import glob
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof_k"
+stats = glob.glob(f"{src}/trace/vm/*_kernel_stats.csv")[0]
+shutil.copy(stats, f"profiles/{tag}_decoder_kernels_kernel_stats.csv")
+lines = [f"# rocprofv3 summary ({tag}): `python bench.py --kernels-only` (decoder MLP kernels, 163840 rows)", "",
+         "## --kernel-trace --stats", "", "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
+dur = {}
+for r in csv.DictReader(open(stats)):
+    if r["Name"].startswith(("void k_", "k_")):
+        dur[r["Name"]] = float(r["AverageNs"])
+        lines.append(f"| {r['Name']} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} |")
+lines += ["", "## --pmc (separate passes; averages per launch)", ""]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ("pmc1", "pmc2", "pmc3"):
+    f = glob.glob(f"{src}/{d}/vm/*_counter_collection.csv")[0]
+    shutil.copy(f, f"profiles/{tag}_decoder_kernels_{d}.csv")
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"].startswith(("void k_mlp", "k_mlp", "k_wgrad")):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in agg.items():
+    m = {c: sum(x) / len(x) for c, x in v.items()}
+    lines.append(f"### {k}")
+    for c, x in sorted(m.items()):
+        lines.append(f"- {c}: {x:,.0f}")
+    if "GRBM_GUI_ACTIVE" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+        cyc = m["GRBM_GUI_ACTIVE"] / 8
+        lines.append(f"- derived: cycles per XCD {cyc:,.0f}; MFMA busy / (1024 SIMDs x cycles) = {m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):.3f}; "
+                     f"waitcnt-parked share SQ_WAIT_ANY/SQ_WAVE_CYCLES = {m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.3f}")
+    if "FETCH_SIZE" in m:
+        lines.append(f"- derived: HBM read bytes = 2 x FETCH_SIZE KiB (gfx950 correction) = {2 * m['FETCH_SIZE'] * 1024 / 1e6:,.0f} MB; "
+                     f"written = {m.get('WRITE_SIZE', 0) * 1024 / 1e6:,.0f} MB")
+    lines.append("")
+open(f"profiles/{tag}_decoder_kernels.md", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
