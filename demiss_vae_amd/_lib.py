@@ -65,6 +65,11 @@ SIGNATURES = {
     "dmv_obj_backward_latent": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvLatentBwd), _P, _P, _P, _I64, _P, _I64,
                                           _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmv_lse_update": (C.c_int, [_I32, _I64, _P, _I32, _P, _P, _P]),
+    "dmv_rows_gather": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "dmv_rows_scatter": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "dmv_impute_tail": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P, _P, _P, _U64, _U64, _P, _P, _I32, _P, _P, _P, _P]),
+    "dmv_categorical_draw": (C.c_int, [_I32, _I32, _I32, _P, _P, _U64, _U64, _P, _P]),
+    "dmv_dropout_masks": (C.c_int, [_P, _I64, _F, _U64, _U64, _P]),
 }
 
 

@@ -1,0 +1,322 @@
+"""DeMissVAE imputation update on the device.
+
+  ImputationBuffer      device-resident twin of the reference's ImputationDistribution
+                        (vgiwae/utils/imputation_distribution.py:18-187): data_imp [(N K), D] in HBM,
+                        idx_imp [N, K] = n*K + k, gather / scatter by dataset index through libdmv.
+  pseudo_gibbs          vgiwae/shared/vae_imputation.py:26-82
+  lair                  vgiwae/shared/vae_imputation.py:177-201, 390-696 (dmis weights, global
+                        multinomial resampling, prior-replenish proposals, resample_final_imps)
+
+Every sampler runs the encoder / decoder through the fused MLP kernels without saving activations
+(the reference runs them under inference_mode) and finishes with one fused tail kernel that draws
+x_m, clamps, applies the non-finite fallback, blends with the observed entries and (optionally)
+writes the rows straight back into the buffer.  Noise is explicit (parity) or Philox (default).
+"""
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import rng
+from .mlp import PackedNet, mlp_forward, make_keep_masks
+from .objectives import ModelDims, _u8
+
+
+def softplus_inverse(x: torch.Tensor) -> torch.Tensor:
+    """vgiwae/utils/softplus_inverse.py:3-7"""
+    return x + torch.log(-torch.expm1(-x))
+
+
+# ------------------------------------------------------------------------------------------ buffer
+class ImputationBuffer:
+    """K imputations per datapoint, kept on the device for the whole run (the reference keeps them on the
+    host and copies every step, vgiwae/utils/imputation_distribution.py:160-163, 180)."""
+
+    def __init__(self, data: torch.Tensor, num_imputations: int, device):
+        data = torch.as_tensor(data, dtype=torch.float32)
+        self.N, self.D = data.shape
+        self.K = int(num_imputations)
+        self.device = torch.device(device)
+        # 'n d -> (n k) d' and '(n k) -> n k'   (imputation_distribution.py:77-79)
+        self.data_imp = data.to(self.device).repeat_interleave(self.K, dim=0).contiguous()
+        self.idx_imp = torch.arange(self.N * self.K, device=self.device, dtype=torch.int64).reshape(self.N, self.K)
+
+    def gather(self, index: torch.Tensor, sampled_i: Optional[torch.Tensor] = None):
+        """Rows of `index` [B] -> (X_imp [B, K', D], idx [B, K']).  sampled_i [B, K'] picks a subset of the K
+        imputations (the reference draws it with torch.multinomial without replacement, :146-151)."""
+        index = index.to(self.device, torch.int64)
+        idx = self.idx_imp[index]
+        if sampled_i is not None:
+            idx = torch.gather(idx, 1, sampled_i.to(self.device, torch.int64))
+        idx = idx.contiguous()
+        B, Kp = idx.shape
+        out = torch.empty((B, Kp, self.D), dtype=torch.float32, device=self.device)
+        L.check(L.lib().dmv_rows_gather(L.ptr(self.data_imp), L.ptr(idx), B * Kp, self.D, L.ptr(out), L.stream_ptr()))
+        return out, idx
+
+    def scatter(self, idx: torch.Tensor, X_imp: torch.Tensor):
+        idx = idx.to(self.device, torch.int64).contiguous()
+        X = X_imp.detach().to(self.device, torch.float32).contiguous()
+        L.check(L.lib().dmv_rows_scatter(L.ptr(self.data_imp), L.ptr(idx), idx.numel(), self.D, L.ptr(X), L.stream_ptr()))
+
+    def sample_subset(self, batch_size: int, num_imputations: int, generator=None):
+        """num_imputations of the K slots per datapoint, without replacement."""
+        w = torch.ones((batch_size, self.K), device=self.device)
+        return torch.multinomial(w, num_samples=num_imputations, replacement=False, generator=generator)
+
+    # ---- initial imputations (imputation_distribution.py:274-386); host-side, once per run
+    def init_empirical(self, data: np.ndarray, mask: np.ndarray):
+        """Missing entries <- draws from the observed values of the same dimension, with numpy's global RNG in
+        increasing dimension order exactly as the reference does (:331-338)."""
+        data = np.asarray(data)
+        mask = np.asarray(mask).astype(bool)
+        imp = self.data_imp.cpu()
+        mis_imp_not = torch.from_numpy(~np.repeat(mask, self.K, axis=0))
+        count = mis_imp_not.sum(0)
+        for i in range(data.shape[-1]):
+            if count[i] == 0:
+                continue
+            samples = np.random.choice(data[:, i][mask[:, i]], size=int(count[i]))
+            imp[mis_imp_not[:, i], i] = torch.as_tensor(samples, dtype=torch.float32)
+        self.data_imp.copy_(imp)
+
+    def init_zero(self, mask):
+        m = torch.as_tensor(np.asarray(mask)).to(self.device).repeat_interleave(self.K, dim=0)
+        self.data_imp.mul_(m.float())
+
+    def init_mean(self, data, mask):
+        data, mask = np.asarray(data, dtype=np.float32), np.asarray(mask).astype(bool)
+        means = (data * mask).sum(0) / mask.sum(0)
+        m = torch.as_tensor(mask).to(self.device).repeat_interleave(self.K, dim=0)
+        self.data_imp.copy_(torch.where(m, self.data_imp, torch.as_tensor(means, device=self.device).expand_as(self.data_imp)))
+
+
+# ------------------------------------------------------------------------------------------ shared pieces
+def _encode_rows(dims: ModelDims, enc: PackedNet, X2, M2, enc_keep):
+    in_mode = L.IN_CONCAT if dims.encoder_use_mis_mask else L.IN_PLAIN
+    y, _ = mlp_forward(enc, X2, dims.D, X2.shape[0], in_mode=in_mode, D=dims.D, m=M2, ldm=dims.D, save=False,
+                       drop_keep=enc_keep)
+    return y
+
+
+def _sample_cfg(dims: ModelDims, rows: int, I: int, ld_enc: int):
+    """Rows (i, r) with r indexing encoder rows: z[i, r] ~ q(. | enc row r)."""
+    cfg = L.DmvObjCfg()
+    cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = rows, 1, 1, I, dims.D, dims.Zd
+    cfg.gen_dist, cfg.q_eps, cfg.x_per_component = L.GEN[dims.gen_dist], dims.q_eps, 0
+    cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ld_enc, 0, dims.Zd, 0
+    return cfg
+
+
+def _tail(dims, dec_out, row_map, X_old, M, noise, clip_min, clip_max, clip_after_blend, buf, idx_imp):
+    N, D = X_old.shape[0] * X_old.shape[1], dims.D
+    X_out = torch.empty_like(X_old)
+    seed = off = 0
+    if noise is None:
+        seed, off = rng.next_offset(N * D)
+    else:
+        noise = noise.reshape(N, D).contiguous().float()
+    L.check(L.lib().dmv_impute_tail(N, D, L.GEN[dims.gen_dist], L.ptr(dec_out), dec_out.shape[1], L.ptr(row_map),
+                                    L.ptr(X_old), L.ptr(M), L.ptr(noise), seed, off, L.ptr(clip_min), L.ptr(clip_max),
+                                    1 if clip_after_blend else 0, L.ptr(X_out),
+                                    L.ptr(buf.data_imp) if buf is not None else None, L.ptr(idx_imp), L.stream_ptr()))
+    return X_out
+
+
+def _keep(net: PackedNet, rows, training, device):
+    if not training or net.dims.dropout <= 0:
+        return None
+    n = net.dims.nb * rows * net.dims.hidden
+    keep = torch.empty(n, dtype=torch.uint8, device=device)
+    seed, off = rng.next_offset(n)
+    L.check(L.lib().dmv_dropout_masks(L.ptr(keep), n, net.dims.dropout, seed, off, L.stream_ptr()))
+    return keep
+
+
+# ------------------------------------------------------------------------------------------ pseudo-Gibbs
+@torch.no_grad()
+def pseudo_gibbs(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iterations=1, clip_min=None,
+                 clip_max=None, eps_z=None, noise_x=None, training=True, buf: Optional[ImputationBuffer] = None,
+                 idx_imp=None):
+    """X [B,K,D] current imputations, M [B,K,D] (True = observed).  eps_z [T,B,K,Zd], noise_x [T,B,K,D] optional.
+    With `buf`/`idx_imp` the last iteration writes its rows straight into the imputation buffer."""
+    B, K, D = X.shape
+    dev = X.device
+    Xc = X.contiguous().float()
+    Mu = _u8(M)
+    st = L.stream_ptr()
+    lib = L.lib()
+    cmin = clip_min.to(dev).float().contiguous() if clip_min is not None else None
+    cmax = clip_max.to(dev).float().contiguous() if clip_max is not None else None
+    N = B * K
+    for t in range(num_iterations):
+        enc_out = _encode_rows(dims, enc, Xc.reshape(N, D), Mu.reshape(N, D), _keep(enc, N, training, dev))
+        cfg = _sample_cfg(dims, N, 1, enc_out.shape[1])
+        Z = torch.empty((N, dims.Zd), dtype=torch.float32, device=dev)
+        if eps_z is not None:
+            e = eps_z[t].reshape(N, dims.Zd).contiguous().float()
+            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(e), 0, 0, dims.Zd, None, L.ptr(Z), None, st))
+        else:
+            seed, off = rng.next_offset(N * dims.Zd)
+            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, dims.Zd, None, L.ptr(Z), None, st))
+        dec_out, _ = mlp_forward(dec, Z, dims.Zd, N, save=False, drop_keep=_keep(dec, N, training, dev))
+        last = t == num_iterations - 1
+        Xc = _tail(dims, dec_out, None, Xc, Mu, noise_x[t] if noise_x is not None else None, cmin, cmax, False,
+                   buf if last else None, idx_imp.reshape(-1).contiguous() if (last and idx_imp is not None) else None)
+    return Xc
+
+
+# ------------------------------------------------------------------------------------------ LAIR
+@torch.no_grad()
+def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iterations=1, num_imp_samples=1,
+         num_prior_replenish_proposals=0, resample_final_imps=False, clip_min=None, clip_max=None,
+         eps_z=None, idx=None, noise_x=None, training=True, buf: Optional[ImputationBuffer] = None, idx_imp=None):
+    """Latent-adaptive importance resampling with DMIS weights and global multinomial resampling.
+
+    X [B,K,D], M [B,K,D].  Parity inputs (all optional): eps_z [T][I,B,K+r,Zd], idx [T (+1)][K+r, B] categorical
+    draws (proposal index i*(K+r)+k; the extra entry is the final resampling's [K, B]), noise_x [T (+1)][B,K,D]."""
+    assert not dims.q_is_mixture
+    if resample_final_imps:
+        assert num_iterations > 1, "Need >1 iterations to resample final imps"
+    B, K, D = X.shape
+    r, I, Zd = num_prior_replenish_proposals, num_imp_samples, dims.Zd
+    Kp = K + r
+    dev = X.device
+    lib, st = L.lib(), L.stream_ptr()
+    Xc = X.contiguous().float()
+    Mu = _u8(M)
+    cmin = clip_min.to(dev).float().contiguous() if clip_min is not None else None
+    cmax = clip_max.to(dev).float().contiguous() if clip_max is not None else None
+    Z_all, lw_all = [], []
+    for t in range(num_iterations):
+        enc_out = _encode_rows(dims, enc, Xc.reshape(B * K, D), Mu.reshape(B * K, D), _keep(enc, B * K, training, dev))
+        ldE = enc_out.shape[1]
+        Xe, Me = Xc, Mu
+        if r > 0:
+            # prior components: mu = 0, sigma = 1 (vgiwae/shared/vae_imputation.py:419-441)
+            rep = torch.zeros((B, r, ldE), dtype=torch.float32, device=dev)
+            one = torch.ones((), device=dev) - (1e-5 if dims.q_eps else 0.0)
+            rep[:, :, Zd:2 * Zd] = softplus_inverse(one)
+            enc_out = torch.cat([enc_out.reshape(B, K, ldE), rep], dim=1).reshape(B * Kp, ldE).contiguous()
+            Xe = torch.cat([Xc, Xc[:, :1].expand(B, r, D)], dim=1).contiguous()
+            Me = torch.cat([Mu, Mu[:, :1].expand(B, r, D)], dim=1).contiguous()
+        # proposals z[i, b, k] ~ q(. | component (b, k))
+        N = I * B * Kp
+        scfg = _sample_cfg(dims, B * Kp, I, ldE)
+        Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
+        if eps_z is not None:
+            e = eps_z[t].reshape(N, Zd).contiguous().float()
+            L.check(lib.dmv_latent_sample(C.byref(scfg), L.ptr(enc_out), L.ptr(e), 0, 0, Zd, None, L.ptr(Z), None, st))
+        else:
+            seed, off = rng.next_offset(N * Zd)
+            L.check(lib.dmv_latent_sample(C.byref(scfg), L.ptr(enc_out), None, seed, off, Zd, None, L.ptr(Z), None, st))
+        dec_out, _ = mlp_forward(dec, Z, Zd, N, save=False, drop_keep=_keep(dec, N, training, dev))
+        # DMIS log-weights: uniform mixture over the K+r components of the datapoint (shared/iwae.py:57-100)
+        cfg = L.DmvObjCfg()
+        cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, Kp, 1, I, D, Zd
+        cfg.gen_dist, cfg.q_eps, cfg.x_per_component = L.GEN[dims.gen_dist], dims.q_eps, 1
+        cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = Kp * ldE, ldE, Zd, 0
+        terms = torch.empty((5, N), dtype=torch.float32, device=dev)
+        L.check(lib.dmv_obj_terms(C.byref(cfg), L.Q_IMPUTATION, Kp, L.ptr(dec_out), dec_out.shape[1], L.ptr(Xe), L.ptr(Me),
+                                  L.ptr(Z), Zd, L.ptr(enc_out), L.ptr(terms), None, st))
+        log_w = terms[0] + terms[2] - terms[4]                                   # [(i b k)]
+        logits = log_w.reshape(I, B, Kp).permute(1, 0, 2).reshape(B, I * Kp).contiguous()   # 'i b k -> b (i k)'
+        if idx is not None:
+            draw = idx[t].to(dev, torch.int64).t().contiguous()                 # [B, K+r]
+        else:
+            draw = torch.empty((B, Kp), dtype=torch.int64, device=dev)
+            seed, off = rng.next_offset(B * Kp)
+            L.check(lib.dmv_categorical_draw(B, I * Kp, Kp, L.ptr(logits), None, seed, off, L.ptr(draw), st))
+        draw = draw[:, :K]                                                       # keep the first K (:521-524)
+        i_sel, k_sel = draw // Kp, draw % Kp
+        row_map = ((i_sel * B + torch.arange(B, device=dev)[:, None]) * Kp + k_sel).reshape(-1).contiguous()
+        clip = (cmin is not None or cmax is not None)
+        last = (t == num_iterations - 1) and not resample_final_imps
+        Xc = _tail(dims, dec_out, row_map, Xc, Mu, noise_x[t] if noise_x is not None else None,
+                   cmin if clip else None, cmax if clip else None, True,
+                   buf if last else None, idx_imp.reshape(-1).contiguous() if (last and idx_imp is not None) else None)
+        if resample_final_imps:
+            Z_all.append(Z.reshape(I, B, Kp, Zd))
+            lw_all.append(log_w.reshape(I, B, Kp))
+    if resample_final_imps:
+        T = num_iterations
+        Zs = torch.stack(Z_all).permute(2, 0, 1, 3, 4).reshape(B, T * I * Kp, Zd)          # 't i b k d -> b (t i k) d'
+        lws = torch.stack(lw_all).permute(2, 0, 1, 3).reshape(B, T * I * Kp).contiguous()
+        if idx is not None:
+            draw = idx[T].to(dev, torch.int64).t().contiguous()                 # [B, K]
+        else:
+            draw = torch.empty((B, K), dtype=torch.int64, device=dev)
+            seed, off = rng.next_offset(B * K)
+            L.check(lib.dmv_categorical_draw(B, T * I * Kp, K, L.ptr(lws), None, seed, off, L.ptr(draw), st))
+        Zf = torch.gather(Zs, 1, draw[..., None].expand(B, K, Zd)).reshape(B * K, Zd).contiguous()
+        dec_out, _ = mlp_forward(dec, Zf, Zd, B * K, save=False, drop_keep=_keep(dec, B * K, training, dev))
+        Xc = _tail(dims, dec_out, None, Xc, Mu, noise_x[T] if noise_x is not None else None, None, None, False,
+                   buf, idx_imp.reshape(-1).contiguous() if idx_imp is not None else None)
+    return Xc
+
+
+# ------------------------------------------------------------------------------------------ log-likelihood
+@torch.no_grad()
+def estimate_loglik(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_importance_samples, chunk=4096,
+                    eps=None, comp_idx=None, k_offset=0, k_total=None, return_state=False):
+    """K-sample importance-sampling estimate of log p(x_o) per datapoint
+    (vgiwae/test/refit_encoder_using_iwae_and_estimate_loglik.py:189-222), streamed over K in chunks with an
+    online (max, sum-exp) so that no [K, B, .] tensor is materialised.
+
+    Stratified encoders are sampled without stratification (vgiwae/models/vae.py:298-301): the component of each
+    draw comes from comp_idx [K, B] (parity) or from device categorical draws.  eps [K, B, Zd] optional.
+    return_state=True returns the running (max, sum) so ranks that shard K can combine them
+    (parallel.lse_allreduce); k_total is then the global K."""
+    B, D = X.shape
+    K = num_importance_samples
+    dev = X.device
+    lib, st = L.lib(), L.stream_ptr()
+    Xc, Mu = X.contiguous().float(), _u8(M)
+    Zd = dims.Zd
+    in_mode = L.IN_CONCAT_MASKED if dims.encoder_use_mis_mask else L.IN_MASKED
+    enc_out, _ = mlp_forward(enc, Xc, D, B, in_mode=in_mode, D=D, m=Mu, ldm=D, save=False)
+    ldE = enc_out.shape[1]
+    mixture = dims.q_is_mixture
+    run_max = torch.full((B,), float("-inf"), dtype=torch.float32, device=dev)
+    run_sum = torch.zeros(B, dtype=torch.float32, device=dev)
+    if mixture:
+        Cn = dims.C
+        logits = enc_out[:, 2 * Cn * Zd: 2 * Cn * Zd + Cn].contiguous()
+    for k0 in range(0, K, chunk):
+        Kc = min(chunk, K - k0)
+        N = Kc * B
+        cfg = L.DmvObjCfg()
+        cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, 1, 1, Kc, D, Zd
+        cfg.gen_dist, cfg.q_eps, cfg.x_per_component = L.GEN[dims.gen_dist], dims.q_eps, 0
+        comp = None
+        if mixture:
+            cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, Zd, dims.C * Zd, 2 * dims.C * Zd
+            if comp_idx is not None:
+                comp = comp_idx[k0:k0 + Kc].reshape(-1).to(dev, torch.int64).contiguous()
+            else:
+                d = torch.empty((B, Kc), dtype=torch.int64, device=dev)
+                seed, off = rng.next_offset(B * Kc)
+                L.check(lib.dmv_categorical_draw(B, dims.C, Kc, L.ptr(logits), None, seed, off, L.ptr(d), st))
+                comp = d.t().contiguous().reshape(-1)
+        else:
+            cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, 0, Zd, 0
+        Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
+        if eps is not None:
+            e = eps[k0:k0 + Kc].reshape(N, Zd).contiguous().float()
+            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(e), 0, 0, Zd, L.ptr(comp), L.ptr(Z), None, st))
+        else:
+            seed, off = rng.next_offset(N * Zd)
+            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, Zd, L.ptr(comp), L.ptr(Z), None, st))
+        dec_out, _ = mlp_forward(dec, Z, Zd, N, save=False)
+        terms = torch.empty((5, N), dtype=torch.float32, device=dev)
+        q_kind = L.Q_STRATIFIED if mixture else L.Q_OWN
+        L.check(lib.dmv_obj_terms(C.byref(cfg), q_kind, dims.C if mixture else 1, L.ptr(dec_out), dec_out.shape[1],
+                                  L.ptr(Xc), L.ptr(Mu), L.ptr(Z), Zd, L.ptr(enc_out), L.ptr(terms), None, st))
+        L.check(lib.dmv_lse_update(B, Kc, L.ptr(terms), 4 if mixture else 3, L.ptr(run_max), L.ptr(run_sum), st))
+    if return_state:
+        return run_max, run_sum
+    per_b = run_max + torch.log(run_sum) - math.log(K if k_total is None else k_total)
+    return per_b.mean(), per_b

@@ -198,6 +198,33 @@ int dmv_obj_backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const f
 int dmv_lse_update(int32_t B, int64_t Kc, const float* terms, int32_t q_term /* 3 own, 4 mixture */,
                    float* run_max, float* run_sum, void* stream);
 
+/* ----- imputation update -------------------------------------------------------------------
+ * Persistent imputation buffer rows (vgiwae/utils/imputation_distribution.py:145-157 gather,
+ * :180-187 scatter).  idx: int64 row numbers; rows are D floats.  Bit-exact copies. */
+int dmv_rows_gather(const float* src, const int64_t* idx, int64_t n, int32_t D, float* dst, void* stream);
+int dmv_rows_scatter(float* dst, const int64_t* idx, int64_t n, int32_t D, const float* src, void* stream);
+
+/* Sampling tail of one imputation iteration for N = B*K rows (vgiwae/shared/vae_imputation.py:38-52
+ * pseudo-Gibbs; :526-561 and :657-666 LAIR):
+ *   x_m ~ p(. | dec[row_map ? row_map[n] : n])   Gaussian: m + s*noise; Bernoulli: 1[noise < sigmoid(logit)]
+ *   clamp to [clip_min, clip_max] (NaN-propagating, like torch.max/min), non-finite -> X_old,
+ *   X_out = M ? X_old : x_m            (clip_after_blend = 1: the LAIR order, clamp applied to the blend)
+ *   optional write-back: buf[idx_imp[n]] = X_out[n].
+ * noise == NULL: Philox stream (seed, offset + n*D + d). */
+int dmv_impute_tail(int64_t N, int32_t D, int32_t gen_dist, const float* dec, int64_t ld_dec,
+                    const int64_t* row_map, const float* X_old, const uint8_t* M, const float* noise,
+                    uint64_t seed, uint64_t offset, const float* clip_min, const float* clip_max,
+                    int32_t clip_after_blend, float* X_out, float* buf, const int64_t* idx_imp, void* stream);
+
+/* K categorical draws per datapoint from softmax(logits[b][0..P)) by inverse CDF
+ * (replaces Categorical(logits).sample((K,)), vgiwae/shared/vae_imputation.py:185-186, :679-680).
+ * u (nullable) [B][K] uniforms in [0,1); NULL: Philox stream (seed, offset + b*K + k).  idx int64 [B][K]. */
+int dmv_categorical_draw(int32_t B, int32_t P, int32_t K, const float* logits, const float* u, uint64_t seed,
+                         uint64_t offset, int64_t* idx, void* stream);
+
+/* keep[i] = 1 with probability 1-p (dropout masks of the residual blocks, neural_nets.py:65,70) */
+int dmv_dropout_masks(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
