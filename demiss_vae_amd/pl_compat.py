@@ -1,0 +1,117 @@
+"""What the model classes need from PyTorch Lightning, for machines where it is not installed.
+
+If `pytorch_lightning` imports, its LightningModule is used unchanged.  Otherwise `LightningModule` here
+is an nn.Module with the handful of attributes and hooks the vgiwae classes touch (hparams,
+save_hyperparameters, log, device, current_epoch, automatic_optimization, optimizers / lr_schedulers /
+manual_backward / clip_gradients for the manual-optimisation step); demiss_vae_amd.runner drives it.
+"""
+import inspect
+from typing import Any
+
+import torch
+import torch.nn as nn
+
+try:  # pragma: no cover - depends on the environment
+    import pytorch_lightning as _pl
+    LightningModule = _pl.LightningModule
+    HAVE_LIGHTNING = True
+except Exception:  # ModuleNotFoundError here; any import-time failure means "not usable"
+    HAVE_LIGHTNING = False
+
+    class _HParams(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError as e:
+                raise AttributeError(k) from e
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+    class LightningModule(nn.Module):
+        CHECKPOINT_HYPER_PARAMS_KEY = "hyper_parameters"
+
+        def __init__(self, *args, **kwargs):
+            super().__init__()
+            object.__setattr__(self, "_hparams_store", _HParams())
+            self.automatic_optimization = True
+            self.current_epoch = 0
+            self.global_step = 0
+            self.trainer = None
+            self._logged = {}
+            self._optimizers = None
+            self._schedulers = None
+
+        # ---- hyper-parameters
+        @property
+        def hparams(self):
+            return self._hparams_store
+
+        def save_hyperparameters(self):
+            """Record the arguments of the __init__ that called this (one class level at a time)."""
+            frame = inspect.currentframe().f_back
+            code, loc = frame.f_code, frame.f_locals
+            n_named = code.co_argcount + code.co_kwonlyargcount
+            for name in code.co_varnames[:n_named]:
+                if name != "self":
+                    self.hparams[name] = loc[name]
+            pos = n_named
+            if code.co_flags & inspect.CO_VARARGS:
+                pos += 1
+            if code.co_flags & inspect.CO_VARKEYWORDS:
+                for k, v in loc.get(code.co_varnames[pos], {}).items():
+                    self.hparams.setdefault(k, v)
+
+        # ---- plumbing
+        @property
+        def device(self):
+            for p in self.parameters():
+                return p.device
+            return torch.device("cpu")
+
+        def log(self, name, value, **kwargs):
+            self._logged[name] = value.detach() if isinstance(value, torch.Tensor) else value
+
+        def setup(self, stage=None):
+            pass
+
+        def on_train_start(self):
+            pass
+
+        def on_train_end(self):
+            pass
+
+        def on_train_epoch_start(self):
+            pass
+
+        def on_train_epoch_end(self):
+            pass
+
+        def on_validation_epoch_end(self):
+            pass
+
+        # ---- manual optimisation support
+        def optimizers(self, use_pl_optimizer=True):
+            return self._optimizers
+
+        def lr_schedulers(self):
+            return self._schedulers
+
+        def manual_backward(self, loss, *args, **kwargs):
+            loss.backward(*args, **kwargs)
+
+        def clip_gradients(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):
+            if not gradient_clip_val:
+                return
+            params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+            if (gradient_clip_algorithm or "norm") == "norm":
+                torch.nn.utils.clip_grad_norm_(params, gradient_clip_val)
+            else:
+                torch.nn.utils.clip_grad_value_(params, gradient_clip_val)
+
+        def configure_gradient_clipping(self, optimizer, optimizer_idx, gradient_clip_val=None,
+                                        gradient_clip_algorithm=None):
+            self.clip_gradients(optimizer, gradient_clip_val=gradient_clip_val,
+                                gradient_clip_algorithm=gradient_clip_algorithm)
+
+STEP_OUTPUT = Any

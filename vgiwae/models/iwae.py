@@ -1,0 +1,76 @@
+"""IWAE for incomplete data (reference: vgiwae/models/iwae.py:11-154): constructor, steps and the module-level
+estimator with the reference's signature; the bound, its STL / DREG gradients and the logsumexp over the
+importance axis run in the fused HIP pipeline."""
+from typing import Optional
+
+import torch
+
+import demiss_vae_amd as dmv
+from demiss_vae_amd.pl_compat import STEP_OUTPUT
+from vgiwae.models.vae import VAE, _inner
+
+
+class IWAE(VAE):
+    def __init__(self, *args, num_importance_samples: int = 1, kl_analytic: bool = False,
+                 var_latent_DREG: bool = False, **kwargs):
+        super().__init__(*args, **kwargs, kl_analytic=kl_analytic)
+        self.save_hyperparameters()
+        assert not kl_analytic, "Analytical KL is not tractable for a IWAE."
+        assert not (self.hparams.var_latent_DREG and self.hparams.var_latent_STL), \
+            "Cannot use STL and DREG gradients at the same time."
+
+    def _bound(self, batch):
+        h = self.hparams
+        return estimate_iwelbo(self, batch, var_latent_STL=h.var_latent_STL, var_latent_DREG=h.var_latent_DREG,
+                               num_latent_samples=h.num_latent_samples, num_importance_samples=h.num_importance_samples)
+
+    def training_step(self, batch, batch_idx) -> STEP_OUTPUT:
+        elbo = self._bound(batch)
+        self.log("elbo/train", elbo, on_step=True, on_epoch=True, prog_bar=False, logger=True)
+        self.log("loss/train", -elbo, on_step=True, on_epoch=True, prog_bar=True, logger=True)
+        return -elbo
+
+    def validation_step(self, batch, batch_idx) -> Optional[STEP_OUTPUT]:
+        with torch.no_grad():
+            elbo = self._bound(batch)
+        self.log("elbo/val", elbo, on_step=True, on_epoch=True, prog_bar=False, logger=True)
+        self.log("loss/val", -elbo, on_step=True, on_epoch=True, prog_bar=True, logger=True)
+
+    def log_weights_to_iwelbo(self, *args, **kwargs):
+        return log_weights_to_iwelbo(*args, **kwargs)
+
+
+def log_weights_to_iwelbo(log_weights, *, create_Z_hook=None, var_latent_DREG=False):
+    """logsumexp over dim 1 minus log I for callers that already hold log-weights [z, i, b, ...]
+    (vgiwae/models/iwae.py:70-90).  Small tensor glue; the training path never calls it."""
+    iwelbo = torch.logsumexp(log_weights, dim=1) - torch.log(torch.tensor(float(log_weights.shape[1])))
+    if var_latent_DREG and create_Z_hook is not None:
+        with torch.no_grad():
+            create_Z_hook(torch.softmax(log_weights, dim=1))
+    return iwelbo
+
+
+def estimate_iwelbo(model, batch, var_latent_STL: bool = False, var_latent_DREG: bool = False,
+                    num_latent_samples: int = 1, num_importance_samples: int = 1, *,
+                    sample_stratifieddistr_without_stratification_norsample=False, eps=None, comp_idx=None):
+    """Batch-mean IWAE bound (vgiwae/models/iwae.py:125-154).
+
+    With gradients enabled this is the fused training pipeline.  Under no_grad with a large number of
+    importance samples, or for a stratified encoder sampled without stratification (the refit test step),
+    it is the streaming K-sample log-likelihood estimator."""
+    from demiss_vae_amd.imputation import estimate_loglik
+    X, M = batch[:2]
+    m = _inner(model)
+    dims, enc, dec = m.engine()
+    streaming = sample_stratifieddistr_without_stratification_norsample or \
+        (not torch.is_grad_enabled() and num_latent_samples == 1 and num_importance_samples >= 1024)
+    if streaming:
+        assert num_latent_samples == 1
+        val, _ = estimate_loglik(dims, enc, dec, X, M, num_importance_samples=num_importance_samples, eps=eps,
+                                 comp_idx=comp_idx)
+        return val
+    ek, dk = m.dropout_masks(X.shape[0], num_latent_samples * num_importance_samples * X.shape[0])
+    bound, _ = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=num_latent_samples,
+                                   num_importance_samples=num_importance_samples, STL=var_latent_STL,
+                                   DREG=var_latent_DREG, eps=eps, enc_keep=ek, dec_keep=dk)
+    return bound

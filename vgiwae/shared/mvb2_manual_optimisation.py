@@ -1,0 +1,13 @@
+def mvb2_manual_optimisation_step(self, enc_loss, gen_loss):
+    """One optimiser step driven by two losses: the generator loss updates the decoder parameters, the encoder
+    loss the encoder parameters; then clip, step and (per-step) schedule
+    (reference: vgiwae/shared/mvb2_manual_optimisation.py:1-22)."""
+    opt = self.optimizers(use_pl_optimizer=True)
+    opt.zero_grad()
+    self.manual_backward(gen_loss, retain_graph=True, inputs=list(self.generator_network.parameters()))
+    self.manual_backward(enc_loss, inputs=list(self.var_latent_network.parameters()))
+    self.configure_gradient_clipping(opt, -1, gradient_clip_val=self.hparams.mvb2_optim_gradclip_val,
+                                     gradient_clip_algorithm=self.hparams.mvb2_optim_gradclip_alg)
+    opt.step()
+    if self.hparams.use_lr_scheduler:
+        self.lr_schedulers().step()
