@@ -1,0 +1,104 @@
+"""CPU tests of the host side: the batch contract (masks / filter / index, bit-exact against the reference's
+outputs), the C ABI surface, and the Philox generator shared by the device kernels."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import torch
+
+import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Plain(torch.utils.data.Dataset):
+    def __init__(self, data):
+        self.data = data
+
+    def __getitem__(self, i):
+        return self.data[i]
+
+    def __len__(self):
+        return len(self.data)
+
+
+def test_masks_filter_index_bit_exact():
+    from vgiwae.data import (UniformMissingnessDataset, QuadrantMissingnessDataset, FullyMissingDataFilter,
+                             DatasetWithIndices)
+    g = gu.load("masks")
+    N, D = int(g["N"]), int(g["D"])
+    data = np.arange(N * D, dtype=np.float32).reshape(N, D)
+    for miss in (20, 50, 80):
+        rng = torch.Generator()
+        rng.manual_seed(int(g["seed"]))
+        ds = UniformMissingnessDataset(_Plain(data), total_miss=miss / 100, rng=rng)
+        assert ds.miss_mask.dtype == np.bool_ and np.array_equal(ds.miss_mask, g[f"uniform_{miss}"])
+        assert (~ds.miss_mask).sum() == int(miss / 100 * N * D)
+        f = FullyMissingDataFilter(ds)
+        assert np.array_equal(np.asarray(f.not_fully_missing_idx), g[f"kept_{miss}"])
+        w = DatasetWithIndices(f)
+        assert w.index_idx == 2
+        X, M, idx = w[:]
+        assert idx.dtype == np.int64 and np.array_equal(idx, g[f"index_{miss}"])
+        assert M.any(axis=1).all() and np.array_equal(X, data[g[f"kept_{miss}"]])
+    img = np.zeros((19, 784), dtype=np.float32)
+    for miss in (25, 50, 75):
+        rng = torch.Generator()
+        rng.manual_seed(int(g["seed"]))
+        ds = QuadrantMissingnessDataset(_Plain(img), total_miss=miss / 100, img_dims=[28, 28], rng=rng)
+        assert np.array_equal(ds.miss_mask, g[f"quadrant_{miss}"])
+        assert ((~ds.miss_mask).sum(1) == 784 * miss // 100).all()
+
+
+def test_abi_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports exactly what include/dmv.h declares."""
+    header = open(os.path.join(ROOT, "include", "dmv.h")).read()
+    declared = set(re.findall(r"\b(dmv_[a-z0-9_]+)\s*\(", header))
+    from demiss_vae_amd import _lib
+    lib = ctypes.CDLL(_lib.lib_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/dmv.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    l = _lib.lib()
+    assert l.dmv_version() == 100 and l.dmv_pad32(33) == 64
+    assert b"workspace" in l.dmv_strerror(-3)
+    # pure host entry points: sizes follow the documented layout
+    net = _lib.DmvNet(16, 16, 256, 2, 0, 0.0)
+    per_hidden = 2 * (8 * 32 * 256) + 256
+    assert l.dmv_mlp_packed_floats(ctypes.byref(net)) == (2 * 8 * 2 * 256 + 256) + 4 * per_hidden + (2 * 32 * 256 + 32)
+    assert l.dmv_mlp_saved_floats(ctypes.byref(net), 100) == 100 * 32 + 5 * 100 * 256
+    bad = _lib.DmvNet(16, 16, 512, 2, 0, 0.0)
+    assert l.dmv_mlp_packed_floats(ctypes.byref(bad)) == 0          # hidden width outside the kernels' range
+
+
+def test_enum_names_match_config_surface():
+    from vgiwae.shared.vae_enums import DISTRIBUTION, mixture_components, engine_name
+    assert DISTRIBUTION["normal_with_eps"].value == 7 and DISTRIBUTION["bern_m1_p1"].value == 14
+    assert mixture_components(DISTRIBUTION["stratified_mixture25_normal_with_eps"]) == 25
+    assert engine_name(DISTRIBUTION["stratified_mixture5_normal"]) == "stratified"
+    assert len(DISTRIBUTION) == 22
+
+
+def test_model_classes_construct_on_cpu_and_forward_is_gpu_only():
+    import pytest
+    import vgiwae.models as models
+    from vgiwae.shared.neural_nets import ResidualFCNetwork
+    from vgiwae.shared.vae_enums import DISTRIBUTION
+    from vgiwae.shared.vae_imputation import VAESampler_LAIR, VAESampler_PseudoGibbs
+    enc, dec = ResidualFCNetwork(5, 4, 3, 200), ResidualFCNetwork(2, 10, 3, 200)
+    assert [k for k in enc.state_dict()][:2] == ["initial_layer.weight", "initial_layer.bias"]
+    assert "blocks.2.linear_layers.1.bias" in enc.state_dict() and "final_layer.weight" in enc.state_dict()
+    sampler = VAESampler_LAIR(num_iterations=1, num_imp_samples=1, num_prior_replenish_proposals=0, is_weights="dmis",
+                              resampling_scheme="global_resampling")
+    m = models.MVBVAEMargLogprob(generator_network=dec, generator_distribution=DISTRIBUTION.normal, var_latent_network=enc,
+                                 var_latent_distribution=DISTRIBUTION.normal, num_latent_samples=1, lr_generator=1e-3,
+                                 lr_latent=1e-3, var_latent_STL=True, kl_analytic=False, num_imputations_train=5,
+                                 mvb_objective=models.MVB_OBJECTIVE["mvb2"], vae_sampler=sampler, latent_grid_steps=500)
+    assert m.hparams.num_imputations_train == 5 and m.hparams.latent_grid_steps == 500 and not m.automatic_optimization
+    assert m.model_dims().D == 5 and m.model_dims().Zd == 2
+    with pytest.raises(RuntimeError):
+        enc(torch.zeros(3, 5))                         # no CPU compute path
+    with pytest.raises(NotImplementedError):
+        VAESampler_LAIR(1, 1, 0, "smis", "global_resampling")
+    assert VAESampler_PseudoGibbs(num_iterations=1).num_iterations == 1
