@@ -169,17 +169,28 @@ def cpu_baseline(budget_s=15.0):
             "sample": f"{n} fwd+bwd steps of B=512, K=5 (the yaml batch) in {budget_s:.0f} s; CPU oracle = stock PyTorch ops"}
 
 
+def dbg(msg):
+    if os.environ.get("DMV_BENCH_DEBUG"):
+        print(f"[bench rank {os.environ.get('RANK', 0)}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    dist = world > 1
+    dist = world > 1 or bool(os.environ.get("DMV_BENCH_FORCE_DIST"))   # the latter: one-rank rehearsal of the RCCL calls
     if dist:
         import torch.distributed as td
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        ndev = torch.cuda.device_count()
+        backend = os.environ.get("DMV_BENCH_BACKEND", "nccl")   # "gloo" lets two ranks share one GPU in rehearsals
+        torch.cuda.set_device(local % ndev)
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
+        else:
+            td.init_process_group(backend)
+        local = local % ndev
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
@@ -213,11 +224,27 @@ def main():
         torch.nn.utils.clip_grad_norm_(params, 5.0, foreach=True)
         opt.step()
 
+    dbg("model built")
     dt = timed(step, args.steps, args.warmup, barrier)
+    dbg(f"timed {dt}")
     if dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = t.item()
+
+    # K = 50 000 log-likelihood estimation: test points sharded over ranks, rates summed
+    ll = None
+    if not args.no_extra:
+        from demiss_vae_amd.bench_extra import loglik_eval_rate
+        barrier()
+        dbg("loglik start")
+        ll = loglik_eval_rate(device)
+        dbg("loglik done")
+        if dist:
+            t = torch.tensor([ll["samples_per_s"]], device=device, dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+            ll["samples_per_s"] = round(t.item(), 1)
+            ll["workload"] += f", {world} ranks each on its own test points"
 
     out = None
     if rank == 0:
@@ -254,15 +281,14 @@ def main():
 
             t512 = timed(step512, 50, 10, barrier)
             extra["yaml_batch_512"] = {"ms_per_step": round(t512 * 1e3, 4), "samples_per_s": round(512 * K / t512, 1)}
-            try:
-                from demiss_vae_amd.bench_extra import demiss_toy_step, loglik_eval_rate
-                extra["demiss_toy_mvb2"] = demiss_toy_step(device)
-                extra["loglik_eval_K50000"] = loglik_eval_rate(device)
-            except ImportError:
-                pass
+            from demiss_vae_amd.bench_extra import demiss_toy_step
+            extra["demiss_toy_mvb2"] = demiss_toy_step(device)
+            extra["loglik_eval_K50000"] = ll
             out["extra"] = extra
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
+    if rank == 0 and world > 1 and ll is not None:
+        out["extra"] = {"loglik_eval_K50000": ll}
     if rank == 0:
         print(json.dumps(out))
     if dist:

@@ -1,0 +1,81 @@
+"""Secondary workloads reported by bench.py under "extra": the DeMissVAE (toy MoG2-large shapes) training step
+with its LAIR imputation update, and the K = 50 000 log-likelihood estimator on UCI-gas shapes."""
+import time
+
+import torch
+
+from . import estimate_iwelbo, mvb2_objectives, ModelDims, NetDims, PackedNet  # noqa: F401
+from . import imputation as imp
+from . import parallel as P
+
+
+def _sync_time(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def _packed(device, spec, seed, requires_grad):
+    from oracle.recipes import make_params
+    p = make_params(spec, seed)
+    ws = [p[n + ".weight"].to(device).requires_grad_(requires_grad) for n in spec.layer_names()]
+    bs = [p[n + ".bias"].to(device).requires_grad_(requires_grad) for n in spec.layer_names()]
+    return PackedNet(NetDims(spec.in_dim, spec.out_dim, spec.nb, spec.hidden), ws, bs)
+
+
+def demiss_toy_step(device, B=4096, K=5):
+    """toy_mog2_large DeMissVAE (configs/toy_mog2_large/compare/mis50/mvb2vae_lairdmisr0_k5_stl_mlp.yaml shapes:
+    D=5, Zd=2, encoder (5,4,3,200), decoder (2,10,3,200), K=5 imputations, LAIR I=1 r=0 T=1, mvb2 + STL):
+    gather from the device buffer -> LAIR update with write-back -> two objectives -> two backward calls -> Adam."""
+    from oracle.recipes import NetSpec, make_batch
+    enc_s, dec_s = NetSpec(5, 4, 3, 200), NetSpec(2, 10, 3, 200)
+    enc, dec = _packed(device, enc_s, 1, True), _packed(device, dec_s, 2, True)
+    dims = ModelDims(D=5, Zd=2, gen_dist="normal", q_dist="normal", encoder_use_mis_mask=False)
+    N = 19366
+    X, M = make_batch(3, N, 5)
+    buf = imp.ImputationBuffer(X, K, device)
+    Mdev = M.to(device)
+    params = enc.params() + dec.params()
+    opt = torch.optim.Adam(params, lr=1e-3, amsgrad=True, fused=True)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(0)
+
+    def step():
+        index = torch.randint(0, N, (B,), device=device, generator=gen)
+        Xt, idx = buf.gather(index)
+        Mk = Mdev[index].unsqueeze(1).expand(B, K, 5).contiguous()
+        Xt = imp.lair(dims, enc, dec, Xt, Mk, num_iterations=1, num_imp_samples=1, buf=buf, idx_imp=idx)
+        gen_obj, enc_obj = mvb2_objectives(dims, enc, dec, Xt, Mk, num_latent_samples=1, STL=True)
+        opt.zero_grad(set_to_none=True)
+        (-gen_obj.mean()).backward(retain_graph=True, inputs=dec.params())
+        (-enc_obj.mean()).backward(inputs=enc.params())
+        opt.step()
+
+    t = _sync_time(step, 20, 5)
+    return {"workload": f"toy_mog2_large DeMissVAE mvb2 step incl. LAIR update, B={B}, K={K}", "ms_per_step": round(t * 1e3, 4),
+            "samples_per_s": round(B * K / t, 1)}
+
+
+def loglik_eval_rate(device, B=50, K=50000, batches=4):
+    """Refit test step on UCI-gas shapes: B=50 test points x K=50 000 importance samples per batch.  Under data
+    parallelism every rank takes its own batches of test points (no exchange until the final mean)."""
+    from oracle.recipes import NetSpec, make_batch
+    enc_s, dec_s = NetSpec(16, 32, 2, 256), NetSpec(16, 16, 2, 256)
+    enc, dec = _packed(device, enc_s, 1, False), _packed(device, dec_s, 2, False)
+    dims = ModelDims(D=8, Zd=16, encoder_use_mis_mask=True)
+    X, _ = make_batch(5 + P.rank(), B, 8)
+    X = X.to(device)
+    M = torch.ones_like(X, dtype=torch.bool)
+
+    def run():
+        for _ in range(batches):
+            imp.estimate_loglik(dims, enc, dec, X, M, num_importance_samples=K, chunk=8192)
+
+    t = _sync_time(run, 2, 1)
+    return {"workload": f"refit test_step, gas shapes, B={B} x K={K} per batch", "ms_per_batch": round(t / batches * 1e3, 3),
+            "samples_per_s": round(batches * B * K / t, 1)}
