@@ -60,28 +60,32 @@ __global__ void k_pack(PackArgs a) {
 // ------------------------------------------------------------------------------------------
 // device building blocks
 // ------------------------------------------------------------------------------------------
-// acc[to] += sum over the 32*NT inputs held in `in`  (Wimg: fragment image with S = 4*NT groups)
-template <int NT>
+// acc[to] += sum over the 32*NT inputs held in `in`  (Wimg: fragment image with S = 4*NT groups).
+// Weight fragments are fetched DMV_PF groups ahead of their use (each group = NT coalesced 1 KiB loads
+// feeding 4*NT MFMAs), so an L2 / Infinity-Cache round trip hides under the wave's own MFMAs.  Two groups
+// ahead is faster but needs 4*NT more registers: only the kernels that do not stage activations for a
+// store have them to spare.
+template <int NT, int DMV_PF = 1>
 __device__ __forceinline__ void gemm_hh(const f32x4* __restrict__ Wimg, int lane, const f32x16 (&in)[NT],
                                         f32x16 (&acc)[NT]) {
   constexpr int S = 4 * NT;
-  f32x4 wc[NT], wn[NT];
+  f32x4 w[DMV_PF + 1][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) wc[t] = Wimg[(t * S + 0) * 64 + lane];
+  for (int p = 0; p < DMV_PF; ++p)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) w[p][t] = Wimg[(t * S + p) * 64 + lane];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    if (s + 1 < S) {
+    if (s + DMV_PF < S) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wn[t] = Wimg[(t * S + s + 1) * 64 + lane];
+      for (int t = 0; t < NT; ++t) w[(s + DMV_PF) % (DMV_PF + 1)][t] = Wimg[(t * S + s + DMV_PF) * 64 + lane];
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float b = in[s >> 2][4 * (s & 3) + e];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = MFMA(wc[t][e], b, acc[t]);
+      for (int t = 0; t < NT; ++t) acc[t] = MFMA(w[s % (DMV_PF + 1)][t][e], b, acc[t]);
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wc[t] = wn[t];
   }
 }
 
@@ -136,9 +140,10 @@ template <int NT>
 __device__ __forceinline__ void apply_act(f32x16 (&v)[NT], int act) {
   if (act == DMV_ACT_RELU) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[t][r] = fmaxf(v[t][r], 0.f);
+    }
   } else {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -180,8 +185,10 @@ __device__ __forceinline__ float first_layer_input(const FwdArgs& a, int64_t r, 
   }
 }
 
-template <int NT>
+// SAVE: training forward (stores the first-layer input and every hidden activation for the backward).
+template <int NT, bool SAVE>
 __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
+  constexpr int PF = SAVE ? 1 : 2;
   const int lane = threadIdx.x & 63;
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
   if (row0 >= a.rows) return;
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
       float b[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) b[e] = first_layer_input(a, rl, 8 * s + 4 * h + e);
-      if (a.xs && live) {
+      if (SAVE && live) {
         f32x4 o = {b[0], b[1], b[2], b[3]};
         *(f32x4*)(a.xs + row * (32 * a.L.T_in) + 8 * s + 4 * h) = o;
       }
@@ -217,13 +224,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
     }
   }
   apply_act<NT>(A, a.act);
-  if (a.acts && live) store_rows<NT>(A, a.acts + row * Hp, h);
+  if (SAVE && live) store_rows<NT>(A, a.acts + row * Hp, h);
 
   // ---- residual blocks
   for (int blk = 0; blk < a.nb; ++blk) {
     const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
     set_bias<NT>(T, a.packed + a.L.b[l1], h);
-    gemm_hh<NT>((const f32x4*)(a.packed + a.L.w[l1]), lane, A, T);
+    gemm_hh<NT, PF>((const f32x4*)(a.packed + a.L.w[l1]), lane, A, T);
     apply_act<NT>(T, a.act);
     if (a.drop_keep) {
       const uint8_t* keep = a.drop_keep + ((int64_t)blk * a.rows + rl) * a.hidden;
@@ -236,11 +243,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
           T[t][r] *= kf;
         }
     }
-    if (a.acts && live) store_rows<NT>(T, a.acts + l1 * act_stride + row * Hp, h);
+    if (SAVE && live) store_rows<NT>(T, a.acts + l1 * act_stride + row * Hp, h);
     add_bias<NT>(A, a.packed + a.L.b[l2], h);
-    gemm_hh<NT>((const f32x4*)(a.packed + a.L.w[l2]), lane, T, A);
+    gemm_hh<NT, PF>((const f32x4*)(a.packed + a.L.w[l2]), lane, T, A);
     apply_act<NT>(A, a.act);
-    if (a.acts && live) store_rows<NT>(A, a.acts + l2 * act_stride + row * Hp, h);
+    if (SAVE && live) store_rows<NT>(A, a.acts + l2 * act_stride + row * Hp, h);
   }
 
   // ---- final layer: one 32-wide output tile at a time
@@ -423,17 +430,18 @@ struct WgradLayer {
   int64_t ldx, ldy;
   int nt, kt;          // 32-wide tiles of N and K
   int nblk, kblk;      // 4-tile blocks
-  int wave0;           // first wave-block index of this layer inside one split
-  int64_t slab_w, slab_b;  // offsets (floats) of this layer's image inside one split's slab
+  int splits;          // row slices of this layer (fewer for layers whose blocks hold fewer tiles)
+  int64_t rows_per_split;
+  int wave0;           // first wave of this layer; a layer owns nblk*kblk*splits consecutive waves
+  int64_t slab_w, slab_b;  // offsets (floats) of this layer's split-0 image inside the slab
+  int64_t slab_stride;     // floats per split of this layer
 };
 
 struct WgradArgs {
   WgradLayer ly[DMV_MAX_LAYERS];
   int nl;
-  int waves_per_split;
-  int splits;
-  int64_t rows, rows_per_split;
-  int64_t slab_stride;  // floats per split
+  int total_waves;
+  int64_t rows;
   float* slab;
 };
 
@@ -460,7 +468,9 @@ __device__ __forceinline__ void wgrad_block(const WgradLayer& Ly, int nb0, int k
   const float* Yp = Ly.dY + 32 * nb0 + j;
   const float* Xp = Ly.X + 32 * kb0 + j;
   const int64_t r_last = r_end - 1;
-  float ya[4][TN], xb[4][TK];
+  // small blocks issue few MFMAs per step, so they keep more steps in flight to cover the same latency
+  constexpr int RING = (TN * TK >= 12) ? 4 : 8;
+  float ya[RING][TN], xb[RING][TK];
   auto load_step = [&](int64_t rr0, float (&yy)[TN], float (&xx)[TK]) {
     const int64_t rr = rr0 + h;
     const int64_t rc = rr < r_end ? rr : r_last;
@@ -479,30 +489,30 @@ __device__ __forceinline__ void wgrad_block(const WgradLayer& Ly, int nb0, int k
   };
   const int64_t n_rows = r_end - r_begin;
   const int64_t n_steps = n_rows >> 1;       // steps with both rows inside the slice
-  const int64_t n_groups = n_steps >> 2;
+  const int64_t n_groups = n_steps / RING;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) load_step(r_begin + 2 * u, ya[u], xb[u]);
+  for (int u = 0; u < RING; ++u) load_step(r_begin + 2 * u, ya[u], xb[u]);
   int64_t r = r_begin;
-  for (int64_t g = 0; g < n_groups; ++g, r += 8) {
+  for (int64_t g = 0; g < n_groups; ++g, r += 2 * RING) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < RING; ++u) {
       fma_step(ya[u], xb[u]);
-      load_step(r + 8 + 2 * u, ya[u], xb[u]);
+      load_step(r + 2 * RING + 2 * u, ya[u], xb[u]);
       // pin the program order: without it the scheduler sinks every refill to the end of the iteration
       // and the first slot of the next iteration is waited for right after it was issued
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  // remainder: the ring already holds the next 4 steps (rows clamped)
-  const int rem = (int)(n_steps & 3);
+  // remainder: the ring already holds the next RING steps (rows clamped)
+  const int rem = (int)(n_steps % RING);
 #pragma unroll
-  for (int u = 0; u < 3; ++u)
+  for (int u = 0; u < RING - 1; ++u)
     if (u < rem) fma_step(ya[u], xb[u]);
   if (n_rows & 1) {
     // a last single row: only the h = 0 half is inside the slice
     float yy[TN], xx[TK];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < RING; ++u)
       if (u == rem) {
 #pragma unroll
         for (int i = 0; i < TN; ++i) yy[i] = h == 0 ? ya[u][i] : 0.f;
@@ -545,19 +555,19 @@ __device__ __forceinline__ void wgrad_dispatch_k(int tk, const WgradLayer& Ly, i
 __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(WgradArgs a) {
   const int lane = threadIdx.x & 63;
   // wave-uniform by construction; readfirstlane lets the compiler keep the whole work decomposition scalar
-  const int64_t wid = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int split = (int)(wid / a.waves_per_split);
-  if (split >= a.splits) return;
-  const int wb = (int)(wid % a.waves_per_split);
+  const int wid = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wid >= a.total_waves) return;
   int l = 0;
-  while (l + 1 < a.nl && a.ly[l + 1].wave0 <= wb) ++l;
+  while (l + 1 < a.nl && a.ly[l + 1].wave0 <= wid) ++l;
   const WgradLayer& Ly = a.ly[l];
-  const int bi = wb - Ly.wave0;
+  const int nblocks = Ly.nblk * Ly.kblk;
+  const int rel = wid - Ly.wave0;
+  const int split = rel / nblocks, bi = rel % nblocks;   // the blocks of one row slice are neighbouring waves
   const int nb0 = (bi / Ly.kblk) * 4, kb0 = (bi % Ly.kblk) * 4;
   const int tn = min(4, Ly.nt - nb0), tk = min(4, Ly.kt - kb0);
-  const int64_t r_begin = (int64_t)split * a.rows_per_split;
-  const int64_t r_end = min(a.rows, r_begin + a.rows_per_split);
-  float* slab = a.slab + (int64_t)split * a.slab_stride;
+  const int64_t r_begin = (int64_t)split * Ly.rows_per_split;
+  const int64_t r_end = min(a.rows, r_begin + Ly.rows_per_split);
+  float* slab = a.slab + (int64_t)split * Ly.slab_stride;
   switch (tn) {
     case 1: wgrad_dispatch_k<1>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
     case 2: wgrad_dispatch_k<2>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
@@ -573,8 +583,8 @@ struct ReduceArgs {
   int64_t first[DMV_MAX_LAYERS + 1];  // prefix sums of N*K + N
   float* gw[DMV_MAX_LAYERS];
   float* gb[DMV_MAX_LAYERS];
-  int splits;
-  int64_t slab_stride;
+  int splits[DMV_MAX_LAYERS];
+  int64_t slab_stride[DMV_MAX_LAYERS];
   const float* slab;
   float beta;
 };
@@ -597,7 +607,7 @@ __global__ void k_wgrad_reduce(ReduceArgs a) {
       dst = a.gb[l] + (e - nk);
     }
     float s = 0.f;
-    for (int p = 0; p < a.splits; ++p) s += a.slab[(int64_t)p * a.slab_stride + src];
+    for (int p = 0; p < a.splits[l]; ++p) s += a.slab[(int64_t)p * a.slab_stride[l] + src];
     *dst = (a.beta != 0.f) ? a.beta * (*dst) + s : s;
   }
 }
@@ -641,7 +651,10 @@ template <int NT>
 static int launch_fwd(const FwdArgs& a, hipStream_t st) {
   const int64_t waves = (a.rows + 31) / 32;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  hipLaunchKernelGGL(k_mlp_fwd<NT>, dim3(grid), dim3(256), 0, st, a);
+  if (a.acts)
+    hipLaunchKernelGGL((k_mlp_fwd<NT, true>), dim3(grid), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_mlp_fwd<NT, false>), dim3(grid), dim3(256), 0, st, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
@@ -696,59 +709,70 @@ extern "C" int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t i
 }
 
 // ---- backward host side
-static int wgrad_plan(const DmvNet* net, int64_t rows, WgradArgs* wa, ReduceArgs* ra) {
+// Work decomposition of the weight-gradient GEMMs.  A wave owns one block (up to 4x4 tiles) of one layer over
+// one row slice; slices are sized so that every wave issues about the same number of MFMAs (a layer whose
+// blocks hold c of 16 tiles gets slices 16/c times longer), and the wave count aims at one full round of the
+// 1024 wave slots (256 CUs x 4 SIMDs, one wave per SIMD).
+static int64_t wgrad_plan(const DmvNet* net, int64_t rows, WgradArgs* wa, ReduceArgs* ra) {
   DmvLayout L = dmv_layout(net);
-  int wave0 = 0;
-  int64_t slab = 0;
+  double weight = 0.0;   // waves per unit of slices, in units of a full 16-tile block
+  int cost[DMV_MAX_LAYERS];
   for (int l = 0; l < L.nl; ++l) {
     WgradLayer& y = wa->ly[l];
     y.nt = (L.N[l] + 31) / 32;
     y.kt = (L.K[l] + 31) / 32;
     y.nblk = (y.nt + 3) / 4;
     y.kblk = (y.kt + 3) / 4;
+    cost[l] = (y.nt < 4 ? y.nt : 4) * (y.kt < 4 ? y.kt : 4);
+    if (cost[l] < 8) cost[l] = 8;   // a small block is bound by load latency, not MFMA issue: at most 2x longer slices
+    weight += (double)y.nblk * y.kblk * cost[l] / 16.0;
+  }
+  int64_t base_splits = (int64_t)(1024.0 / weight);
+  if (base_splits < 1) base_splits = 1;
+  const int64_t max_splits = (rows + 63) / 64;
+  if (base_splits > max_splits) base_splits = max_splits;
+  int64_t base_rps = (rows + base_splits - 1) / base_splits;
+  int wave0 = 0;
+  int64_t slab = 0;
+  for (int l = 0; l < L.nl; ++l) {
+    WgradLayer& y = wa->ly[l];
+    int64_t rps = base_rps * 16 / cost[l];
+    rps = (rps + 15) / 16 * 16;
+    y.rows_per_split = rps;
+    y.splits = (int)((rows + rps - 1) / rps);
     y.wave0 = wave0;
-    wave0 += y.nblk * y.kblk;
-    y.slab_w = slab; slab += (int64_t)y.nt * 32 * y.kt * 32;
-    y.slab_b = slab; slab += (int64_t)y.nt * 32;
+    wave0 += y.nblk * y.kblk * y.splits;
+    y.slab_stride = (int64_t)y.nt * 32 * y.kt * 32 + (int64_t)y.nt * 32;
+    y.slab_w = slab;
+    y.slab_b = slab + (int64_t)y.nt * 32 * y.kt * 32;
+    slab += y.slab_stride * y.splits;
   }
   wa->nl = L.nl;
-  wa->waves_per_split = wave0;
-  // one wave per SIMD on 256 CUs = 1024 wave slots; aim for one full round of equal row slices
-  int64_t splits = 1024 / wave0;
-  if (splits < 1) splits = 1;
-  const int64_t max_splits = (rows + 63) / 64;
-  if (splits > max_splits) splits = max_splits;
-  int64_t rps = (rows + splits - 1) / splits;
-  rps = (rps + 7) / 8 * 8;
-  splits = (rows + rps - 1) / rps;
-  wa->splits = (int)splits;
+  wa->total_waves = wave0;
   wa->rows = rows;
-  wa->rows_per_split = rps;
-  wa->slab_stride = slab;
   if (ra) {
     ra->nl = L.nl;
     int64_t first = 0;
     for (int l = 0; l < L.nl; ++l) {
       ra->N[l] = L.N[l]; ra->K[l] = L.K[l]; ra->Kp[l] = wa->ly[l].kt * 32;
       ra->slab_w[l] = wa->ly[l].slab_w; ra->slab_b[l] = wa->ly[l].slab_b;
+      ra->splits[l] = wa->ly[l].splits; ra->slab_stride[l] = wa->ly[l].slab_stride;
       ra->first[l] = first;
       first += (int64_t)L.N[l] * L.K[l] + L.N[l];
     }
     ra->first[L.nl] = first;
-    ra->splits = (int)splits;
-    ra->slab_stride = slab;
   }
-  return DMV_OK;
+  return slab;
 }
 
 extern "C" size_t dmv_mlp_backward_ws_bytes(const DmvNet* net, int64_t rows) {
   if (dmv_check_net(net) != DMV_OK || rows < 0) return 0;
   if (rows == 0) return 16;
   WgradArgs wa;
-  wgrad_plan(net, rows, &wa, nullptr);
+  const int64_t slab_floats = wgrad_plan(net, rows, &wa, nullptr);
   const int64_t Hp = dmv_pad32(net->hidden);
   const int64_t dacts = (2 * net->nb + 1) * rows * Hp;
-  return (size_t)(dacts + (int64_t)wa.splits * wa.slab_stride) * sizeof(float);
+  return (size_t)(dacts + slab_floats) * sizeof(float);
 }
 
 extern "C" int dmv_mlp_backward(const DmvNet* net, const float* packed, const float* saved, const uint8_t* drop_keep,
@@ -812,8 +836,7 @@ extern "C" int dmv_mlp_backward(const DmvNet* net, const float* packed, const fl
   wa.slab = slab;
   ra.slab = slab;
   ra.beta = beta;
-  const int64_t waves = (int64_t)wa.waves_per_split * wa.splits;
-  hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, wa);
+  hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)((wa.total_waves + 3) / 4)), dim3(256), 0, st, wa);
   DMV_HIP_CHECK_LAUNCH();
   const int64_t total = ra.first[nl];
   unsigned rgrid = (unsigned)((total + 255) / 256);
