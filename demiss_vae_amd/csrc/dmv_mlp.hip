@@ -60,33 +60,120 @@ __global__ void k_pack(PackArgs a) {
 // ------------------------------------------------------------------------------------------
 // device building blocks
 // ------------------------------------------------------------------------------------------
-// acc[to] += sum over the 32*NT inputs held in `in`  (Wimg: fragment image with S = 4*NT groups).
-// Weight fragments are fetched DMV_PF groups ahead of their use (each group = NT coalesced 1 KiB loads
-// feeding 4*NT MFMAs), so an L2 / Infinity-Cache round trip hides under the wave's own MFMAs.  Two groups
-// ahead is faster but needs 4*NT more registers: only the kernels that do not stage activations for a
-// store have them to spare.
-template <int NT, int DMV_PF = 1>
+// acc[t] += sum over the 32*NT inputs held in `in`  (Wimg: fragment image with S = 4*NT groups).
+// Weight fragments are fetched PF groups ahead of their use (each group = NT coalesced 1 KiB loads
+// feeding 4*NT MFMAs), so an L2 / Infinity-Cache round trip hides under the wave's own MFMAs.
+//
+// Two optional side streams ride on the same software pipeline, one 16-byte access per lane and group,
+// so that no burst of memory traffic (and no wait for it) sits between two GEMMs:
+//   ST: `in` is written to st[8 s .. 8 s + 3] in group s (st = this lane's row + 4 h): group s multiplies
+//       exactly the four registers that hold those features.  Rows are padded to a multiple of 32 in the
+//       saved buffers, so the store needs no predicate.
+//   MK: the sign bits of a saved activation row (mk_src = that row + 4 h) are collected into mk: bit
+//       16 (t & 1) + r of word t >> 1 is set when element r of tile t is > 0 (relu' of the layer whose
+//       gradient `acc` is).
+constexpr int mask_words(int NT) { return (NT + 1) / 2; }
+
+// wave-uniform base + 32-bit lane offset: selects the scalar-base addressing mode (no 64-bit vector adds,
+// no address registers per fragment)
+__device__ __forceinline__ f32x4 frag_load(const f32x4* __restrict__ base, int frag, uint32_t lane_bytes) {
+  return *(const f32x4*)((const char*)(base + (size_t)frag * 64) + lane_bytes);
+}
+
+template <int NT, int PF, bool ST, bool MK>
 __device__ __forceinline__ void gemm_hh(const f32x4* __restrict__ Wimg, int lane, const f32x16 (&in)[NT],
-                                        f32x16 (&acc)[NT]) {
+                                        f32x16 (&acc)[NT], float* __restrict__ st, const float* __restrict__ mk_src,
+                                        uint32_t (&mk)[mask_words(NT)]) {
   constexpr int S = 4 * NT;
-  f32x4 w[DMV_PF + 1][NT];
+  const uint32_t lb = (uint32_t)lane * 16u;
+  f32x4 w[PF + 1][NT];
+  f32x4 yv[PF + 1];
+  if (MK) {
 #pragma unroll
-  for (int p = 0; p < DMV_PF; ++p)
+    for (int i = 0; i < mask_words(NT); ++i) mk[i] = 0u;
+  }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) w[p][t] = Wimg[(t * S + p) * 64 + lane];
+  for (int p = 0; p < PF; ++p) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) w[p][t] = frag_load(Wimg, t * S + p, lb);
+    if (MK) yv[p] = *(const f32x4*)(mk_src + 8 * p);
+  }
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    if (s + DMV_PF < S) {
+    if (s + PF < S) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) w[(s + DMV_PF) % (DMV_PF + 1)][t] = Wimg[(t * S + s + DMV_PF) * 64 + lane];
+      for (int t = 0; t < NT; ++t) w[(s + PF) % (PF + 1)][t] = frag_load(Wimg, t * S + s + PF, lb);
+      if (MK) yv[(s + PF) % (PF + 1)] = *(const f32x4*)(mk_src + 8 * (s + PF));
     }
+    if (ST) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = in[s >> 2][4 * (s & 3) + e];
+      *(f32x4*)(st + 8 * s) = o;
+    }
+    // keep the memory operations of this group ahead of its MFMAs (the scheduler otherwise sinks them next to
+    // their first use, which exposes the whole L2 latency)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float b = in[s >> 2][4 * (s & 3) + e];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = MFMA(w[s % (DMV_PF + 1)][t][e], b, acc[t]);
+      for (int t = 0; t < NT; ++t) acc[t] = MFMA(w[s % (PF + 1)][t][e], b, acc[t]);
+    }
+    if (MK) {
+      const f32x4 y = yv[s % (PF + 1)];
+      uint32_t bits = 0u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bits |= (y[e] > 0.f ? 1u : 0u) << e;
+      mk[s >> 3] |= bits << (16 * ((s >> 2) & 1) + 4 * (s & 3));
     }
   }
+}
+
+// one 32-wide output tile: acc += W_tile in, optionally storing `in` on the way (see gemm_hh)
+template <int NT, bool ST>
+__device__ __forceinline__ void gemm_h1(const f32x4* __restrict__ Wtile, int lane, const f32x16 (&in)[NT], f32x16& acc,
+                                        float* __restrict__ st) {
+  constexpr int S = 4 * NT;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const f32x4 w = Wtile[s * 64 + lane];
+    if (ST) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = in[s >> 2][4 * (s & 3) + e];
+      *(f32x4*)(st + 8 * s) = o;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = MFMA(w[e], in[s >> 2][4 * (s & 3) + e], acc);
+  }
+}
+
+// sign bits of a whole saved row, gemm_hh's MK layout
+template <int NT>
+__device__ __forceinline__ void load_mask(const float* __restrict__ src, uint32_t (&mk)[mask_words(NT)]) {
+#pragma unroll
+  for (int i = 0; i < mask_words(NT); ++i) mk[i] = 0u;
+#pragma unroll
+  for (int s = 0; s < 4 * NT; ++s) {
+    const f32x4 y = *(const f32x4*)(src + 8 * s);
+    uint32_t bits = 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bits |= (y[e] > 0.f ? 1u : 0u) << e;
+    mk[s >> 3] |= bits << (16 * ((s >> 2) & 1) + 4 * (s & 3));
+  }
+}
+
+// v = bit ? scale * v : 0
+template <int NT>
+__device__ __forceinline__ void apply_mask(f32x16 (&v)[NT], const uint32_t (&mk)[mask_words(NT)], float scale) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool on = (mk[t >> 1] >> (16 * (t & 1) + r)) & 1u;
+      v[t][r] = on ? v[t][r] * scale : 0.f;
+    }
 }
 
 template <int NT>
@@ -185,10 +272,12 @@ __device__ __forceinline__ float first_layer_input(const FwdArgs& a, int64_t r, 
   }
 }
 
-// SAVE: training forward (stores the first-layer input and every hidden activation for the backward).
+// SAVE: training forward (stores the first-layer input and every hidden activation for the backward;
+// the saved buffers hold rows rounded up to a multiple of 32, so whole-wave stores need no predicate).
+// A hidden activation is written while the next GEMM consumes it (gemm_hh / gemm_h1, ST).
 template <int NT, bool SAVE>
 __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
-  constexpr int PF = SAVE ? 1 : 2;
+  constexpr int PF = 2;
   const int lane = threadIdx.x & 63;
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
   if (row0 >= a.rows) return;
@@ -197,7 +286,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
   const bool live = row < a.rows;
   const int64_t rl = live ? row : a.rows - 1;
   constexpr int Hp = 32 * NT;
-  const int64_t act_stride = a.rows * Hp;
+  const int64_t act_stride = ((a.rows + 31) & ~(int64_t)31) * Hp;
+  float* st = SAVE ? a.acts + row * Hp + 4 * h : nullptr;   // this lane's slot in the saved activations, layer 0
+  uint32_t nomask[mask_words(NT)];
 
   f32x16 A[NT], T[NT];
 
@@ -210,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
       float b[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) b[e] = first_layer_input(a, rl, 8 * s + 4 * h + e);
-      if (SAVE && live) {
+      if (SAVE) {
         f32x4 o = {b[0], b[1], b[2], b[3]};
         *(f32x4*)(a.xs + row * (32 * a.L.T_in) + 8 * s + 4 * h) = o;
       }
@@ -224,13 +315,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
     }
   }
   apply_act<NT>(A, a.act);
-  if (SAVE && live) store_rows<NT>(A, a.acts + row * Hp, h);
 
   // ---- residual blocks
   for (int blk = 0; blk < a.nb; ++blk) {
     const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
     set_bias<NT>(T, a.packed + a.L.b[l1], h);
-    gemm_hh<NT, PF>((const f32x4*)(a.packed + a.L.w[l1]), lane, A, T);
+    gemm_hh<NT, PF, SAVE, false>((const f32x4*)(a.packed + a.L.w[l1]), lane, A, T, st + (l1 - 1) * act_stride, nullptr,
+                                 nomask);
     apply_act<NT>(T, a.act);
     if (a.drop_keep) {
       const uint8_t* keep = a.drop_keep + ((int64_t)blk * a.rows + rl) * a.hidden;
@@ -243,11 +334,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
           T[t][r] *= kf;
         }
     }
-    if (SAVE && live) store_rows<NT>(T, a.acts + l1 * act_stride + row * Hp, h);
     add_bias<NT>(A, a.packed + a.L.b[l2], h);
-    gemm_hh<NT, PF>((const f32x4*)(a.packed + a.L.w[l2]), lane, T, A);
+    gemm_hh<NT, PF, SAVE, false>((const f32x4*)(a.packed + a.L.w[l2]), lane, T, A, st + l1 * act_stride, nullptr,
+                                 nomask);
     apply_act<NT>(A, a.act);
-    if (SAVE && live) store_rows<NT>(A, a.acts + l2 * act_stride + row * Hp, h);
   }
 
   // ---- final layer: one 32-wide output tile at a time
@@ -264,12 +354,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[4 * q + e] = b[e];
       }
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const f32x4 w = W[((int64_t)ot * S + s) * 64 + lane];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = MFMA(w[e], A[s >> 2][4 * (s & 3) + e], acc);
-      }
+      if (SAVE && ot == 0)
+        gemm_h1<NT, true>(W, lane, A, acc, st + (lf - 1) * act_stride);
+      else
+        gemm_h1<NT, false>(W + (int64_t)ot * S * 64, lane, A, acc, nullptr);
       if (live) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -326,8 +414,13 @@ __device__ __forceinline__ void mul_act_grad(f32x16 (&v)[NT], const float* __res
   }
 }
 
-template <int NT>
+// RELU: the activation derivative is the sign bit of the saved output (post-dropout outputs included: a
+// dropped or inactive unit saved 0).  Those bits are prefetched while the preceding GEMM runs (gemm_hh, MK),
+// and every layer gradient is written while the following GEMM consumes it (ST), so the only memory waits
+// left between GEMMs are the ones at the two ends of the chain.
+template <int NT, bool RELU>
 __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
+  constexpr int PF = RELU ? 2 : 1;
   const int lane = threadIdx.x & 63;
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
   if (row0 >= a.rows) return;
@@ -336,10 +429,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
   const bool live = row < a.rows;
   const int64_t rl = live ? row : a.rows - 1;
   constexpr int Hp = 32 * NT;
-  const int64_t act_stride = a.rows * Hp;
+  const int64_t act_stride = ((a.rows + 31) & ~(int64_t)31) * Hp;
   const int lf = a.L.nl - 1;
+  float* st = a.dacts + row * Hp + 4 * h;             // this lane's slot in the layer-gradient buffer, layer 0
+  const float* sv = a.acts + rl * Hp + 4 * h;         // ... and in the saved activations
+  const float dscale = a.drop_keep ? a.drop_scale : 1.f;
+  uint32_t mkA[mask_words(NT)], mkT[mask_words(NT)];
 
   f32x16 dA[NT], dT[NT];
+  if (RELU) load_mask<NT>(sv + (lf - 1) * act_stride, mkA);
   zero<NT>(dA);
   // dA = Wf^T gy
   {
@@ -360,12 +458,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
   for (int blk = a.nb - 1; blk >= 0; --blk) {
     const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
     // through the block's output activation: dA becomes the gradient of (a_in + W2 t + b2)
-    mul_act_grad<NT>(dA, a.acts + l2 * act_stride + rl * Hp, h, a.act);
-    if (live) store_rows<NT>(dA, a.dacts + l2 * act_stride + row * Hp, h);
+    if (RELU) apply_mask<NT>(dA, mkA, 1.f);
+    else mul_act_grad<NT>(dA, a.acts + l2 * act_stride + rl * Hp, h, a.act);
     zero<NT>(dT);
-    gemm_hh<NT>((const f32x4*)(a.packed + a.L.wt[l2]), lane, dA, dT);
+    gemm_hh<NT, PF, true, RELU>((const f32x4*)(a.packed + a.L.wt[l2]), lane, dA, dT, st + l2 * act_stride,
+                                sv + l1 * act_stride, mkT);
     // through dropout and the inner activation
-    if (!a.drop_keep) {
+    if (RELU) {
+      apply_mask<NT>(dT, mkT, dscale);
+    } else if (!a.drop_keep) {
       mul_act_grad<NT>(dT, a.acts + l1 * act_stride + rl * Hp, h, a.act);
     } else {
       const float* trow = a.acts + l1 * act_stride + rl * Hp;
@@ -385,11 +486,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
           }
         }
     }
-    if (live) store_rows<NT>(dT, a.dacts + l1 * act_stride + row * Hp, h);
-    gemm_hh<NT>((const f32x4*)(a.packed + a.L.wt[l1]), lane, dT, dA);  // dA (skip path) += W1^T dT
+    // dA (skip path) += W1^T dT
+    gemm_hh<NT, PF, true, RELU>((const f32x4*)(a.packed + a.L.wt[l1]), lane, dT, dA, st + l1 * act_stride,
+                                sv + (l1 - 1) * act_stride, mkA);
   }
-  mul_act_grad<NT>(dA, a.acts + rl * Hp, h, a.act);
-  if (live) store_rows<NT>(dA, a.dacts + row * Hp, h);
+  if (RELU) apply_mask<NT>(dA, mkA, 1.f);
+  else mul_act_grad<NT>(dA, a.acts + rl * Hp, h, a.act);
 
   if (a.dx) {
     const f32x4* W = (const f32x4*)(a.packed + a.L.wt[0]);
@@ -398,12 +500,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const f32x4 w = W[((int64_t)it * S + s) * 64 + lane];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = MFMA(w[e], dA[s >> 2][4 * (s & 3) + e], acc);
-      }
+      if (it == 0)
+        gemm_h1<NT, true>(W, lane, dA, acc, st);
+      else
+        gemm_h1<NT, false>(W + (int64_t)it * S * 64, lane, dA, acc, nullptr);
       if (live) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -414,6 +514,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
         }
       }
     }
+  } else {
+    store_rows<NT>(dA, a.dacts + row * Hp, h);
   }
 }
 
@@ -644,7 +746,8 @@ extern "C" int dmv_mlp_pack(const DmvNet* net, const float* const* weights, cons
 extern "C" size_t dmv_mlp_saved_floats(const DmvNet* net, int64_t rows) {
   if (dmv_check_net(net) != DMV_OK || rows < 0) return 0;
   const int64_t Hp = dmv_pad32(net->hidden), Ip = dmv_pad32(net->in_dim);
-  return (size_t)(rows * Ip + (2 * net->nb + 1) * rows * Hp);
+  const int64_t rp = (rows + 31) & ~(int64_t)31;   // whole 32-row wave tiles: the kernels store without predicates
+  return (size_t)(rp * Ip + (2 * net->nb + 1) * rp * Hp);
 }
 
 template <int NT>
@@ -663,7 +766,10 @@ template <int NT>
 static int launch_bwd(const BwdArgs& a, hipStream_t st) {
   const int64_t waves = (a.rows + 31) / 32;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  hipLaunchKernelGGL(k_mlp_bwd<NT>, dim3(grid), dim3(256), 0, st, a);
+  if (a.act == DMV_ACT_RELU)
+    hipLaunchKernelGGL((k_mlp_bwd<NT, true>), dim3(grid), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_mlp_bwd<NT, false>), dim3(grid), dim3(256), 0, st, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
@@ -703,7 +809,7 @@ extern "C" int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t i
   a.x = x; a.ldx = ldx; a.m = m; a.ldm = ldm; a.rows = rows;
   a.y = y; a.ldy = ldy;
   a.xs = saved;
-  a.acts = saved ? saved + rows * dmv_pad32(net->in_dim) : nullptr;
+  a.acts = saved ? saved + ((rows + 31) & ~(int64_t)31) * dmv_pad32(net->in_dim) : nullptr;
   a.drop_keep = drop_keep;
   DMV_DISPATCH_NT(a.L.NT, launch_fwd, a, (hipStream_t)stream);
 }
@@ -771,7 +877,7 @@ extern "C" size_t dmv_mlp_backward_ws_bytes(const DmvNet* net, int64_t rows) {
   WgradArgs wa;
   const int64_t slab_floats = wgrad_plan(net, rows, &wa, nullptr);
   const int64_t Hp = dmv_pad32(net->hidden);
-  const int64_t dacts = (2 * net->nb + 1) * rows * Hp;
+  const int64_t dacts = (2 * net->nb + 1) * ((rows + 31) & ~(int64_t)31) * Hp;
   return (size_t)(dacts + slab_floats) * sizeof(float);
 }
 
@@ -791,10 +897,11 @@ extern "C" int dmv_mlp_backward(const DmvNet* net, const float* packed, const fl
   if ((uintptr_t)ws & 15) return DMV_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int64_t Hp = dmv_pad32(net->hidden), Ip = dmv_pad32(net->in_dim);
+  const int64_t rp = (rows + 31) & ~(int64_t)31;
   const float* xs = saved;
-  const float* acts = saved + rows * Ip;
+  const float* acts = saved + rp * Ip;
   float* dacts = (float*)ws;
-  float* slab = dacts + (2 * net->nb + 1) * rows * Hp;
+  float* slab = dacts + (2 * net->nb + 1) * rp * Hp;
 
   BwdArgs b;
   b.L = dmv_layout(net);
@@ -828,8 +935,8 @@ extern "C" int dmv_mlp_backward(const DmvNet* net, const float* packed, const fl
   for (int l = 0; l < nl; ++l) {
     if (!grad_w[l] || !grad_b[l]) return DMV_E_BADARG;
     WgradLayer& y = wa.ly[l];
-    if (l == 0) { y.X = xs; y.ldx = Ip; } else { y.X = acts + (int64_t)(l - 1) * rows * Hp; y.ldx = Hp; }
-    if (l == nl - 1) { y.dY = gy; y.ldy = ldgy; } else { y.dY = dacts + (int64_t)l * rows * Hp; y.ldy = Hp; }
+    if (l == 0) { y.X = xs; y.ldx = Ip; } else { y.X = acts + (int64_t)(l - 1) * rp * Hp; y.ldx = Hp; }
+    if (l == nl - 1) { y.dY = gy; y.ldy = ldgy; } else { y.dY = dacts + (int64_t)l * rp * Hp; y.ldy = Hp; }
     ra.gw[l] = grad_w[l];
     ra.gb[l] = grad_b[l];
   }

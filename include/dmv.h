@@ -95,6 +95,7 @@ int32_t dmv_pad32(int32_t n);
  *   x [rows][ldx] fp32, m [rows][ldm] uint8 (only for the masked / concat input modes, D = x width)
  *   y [rows][ldy], ldy >= dmv_pad32(out_dim): columns >= out_dim are written as zeros
  *   saved: NULL for inference, or dmv_mlp_saved_floats(net, rows) floats that dmv_mlp_backward reads
+ *          (opaque; sized for rows rounded up to whole 32-row wave tiles)
  *   drop_keep: NULL, or nb keep-masks [nb][rows][hidden] uint8 (1 = keep), scaled by 1/(1-p) */
 size_t dmv_mlp_saved_floats(const DmvNet* net, int64_t rows);
 int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t in_mode, int32_t D,

@@ -67,7 +67,7 @@ def test_abi_exports_every_declared_symbol():
     net = _lib.DmvNet(16, 16, 256, 2, 0, 0.0)
     per_hidden = 2 * (8 * 32 * 256) + 256
     assert l.dmv_mlp_packed_floats(ctypes.byref(net)) == (2 * 8 * 2 * 256 + 256) + 4 * per_hidden + (2 * 32 * 256 + 32)
-    assert l.dmv_mlp_saved_floats(ctypes.byref(net), 100) == 100 * 32 + 5 * 100 * 256
+    assert l.dmv_mlp_saved_floats(ctypes.byref(net), 100) == 128 * 32 + 5 * 128 * 256  # rows padded to 32
     bad = _lib.DmvNet(16, 16, 512, 2, 0, 0.0)
     assert l.dmv_mlp_packed_floats(ctypes.byref(bad)) == 0          # hidden width outside the kernels' range
 

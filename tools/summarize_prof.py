@@ -3,12 +3,14 @@
 import collections
 import csv
 import glob
+import os
 import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof_k"
-stats = glob.glob(f"{src}/trace/vm/*_kernel_stats.csv")[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+stats = newest(f"{src}/trace/vm/*_kernel_stats.csv")
 shutil.copy(stats, f"profiles/{tag}_decoder_kernels_kernel_stats.csv")
 lines = [f"# rocprofv3 summary ({tag}): `python bench.py --kernels-only` (decoder MLP kernels, 163840 rows)", "",
          "## --kernel-trace --stats", "", "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
@@ -20,7 +22,7 @@ for r in csv.DictReader(open(stats)):
 lines += ["", "## --pmc (separate passes; averages per launch)", ""]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("pmc1", "pmc2", "pmc3"):
-    f = glob.glob(f"{src}/{d}/vm/*_counter_collection.csv")[0]
+    f = newest(f"{src}/{d}/vm/*_counter_collection.csv")
     shutil.copy(f, f"profiles/{tag}_decoder_kernels_{d}.csv")
     for r in csv.DictReader(open(f)):
         if r["Kernel_Name"].startswith(("void k_mlp", "k_mlp", "k_wgrad")):
