@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdmv.so")
+# DMV_LIB selects another build of the same library (e.g. the timestamp-instrumented tuning build)
+_LIB_PATH = os.environ.get("DMV_LIB") or os.path.join(_HERE, "libdmv.so")
 _lib = None
 
 # enums (include/dmv.h)

@@ -17,7 +17,8 @@ static inline int dmv_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) 
 //   element (nt, s, lane, e) = W[32 nt + (lane & 31)][8 s + 4 (lane >> 5) + e]   (0 outside W)
 // Transposed image (for dx = W^T dy):             [ceil(K/32)][ceil(N/8)][64][4]
 //   element (kt, s, lane, e) = W[8 s + 4 (lane >> 5) + e][32 kt + (lane & 31)]
-// Bias image: [32 ceil(N/32)] floats, zero padded.
+// Bias image: [ceil(N/32)][64 lanes] floats, an MFMA A-operand fragment per tile: lane n < 32 carries
+//   bias[32 nt + n], lanes 32..63 carry zero (bias enters a layer as a rank-1 MFMA against a vector of ones).
 struct DmvLayout {
   int nl;                           // layers = 2 nb + 2
   int NT;                           // hidden tiles = ceil(hidden/32)
@@ -63,7 +64,7 @@ static inline DmvLayout dmv_layout(const DmvNet* n) {
     const int64_t nt = dmv_ceil_div(L.N[l], 32), kt = dmv_ceil_div(L.K[l], 32);
     L.w[l] = off;  off += nt * L.S[l] * 256;
     L.wt[l] = off; off += kt * L.Sn[l] * 256;
-    L.b[l] = off;  off += nt * 32;
+    L.b[l] = off;  off += nt * 64;
   }
   L.total = off;
   return L;

@@ -18,6 +18,30 @@
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// Phase timestamps for kernel tuning (debug builds only: make TRACE=1): wave w writes the shader clock at
+// phase i to dmv_trace_buf[16 w + i]; dmv_debug_trace copies the buffer out.
+#ifdef DMV_TRACE
+__device__ long long dmv_trace_buf[16 * 8192];
+#define TRACE(i)                                                                                   \
+  do {                                                                                             \
+    const long long t_ = __builtin_readcyclecounter();                                             \
+    const int w_ = blockIdx.x * 4 + (threadIdx.x >> 6);                                            \
+    if ((threadIdx.x & 63) == 0 && w_ < 8192) dmv_trace_buf[16 * w_ + (i)] = t_;                   \
+  } while (0)
+#define TRACE_REAL(i)                                                                              \
+  do {                                                                                             \
+    const long long t_ = (long long)__builtin_amdgcn_s_memrealtime();                              \
+    const int w_ = blockIdx.x * 4 + (threadIdx.x >> 6);                                            \
+    if ((threadIdx.x & 63) == 0 && w_ < 8192) dmv_trace_buf[16 * w_ + (i)] = t_;                   \
+  } while (0)
+extern "C" int dmv_debug_trace(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dmv_trace_buf), bytes);
+}
+#else
+#define TRACE(i)
+#define TRACE_REAL(i)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // packing
 // ------------------------------------------------------------------------------------------
@@ -33,7 +57,7 @@ __global__ void k_pack(PackArgs a) {
   const int N = a.L.N[l], K = a.L.K[l];
   const int nt = (N + 31) / 32, S = a.L.S[l];
   const int kt = (K + 31) / 32, Sn = a.L.Sn[l];
-  const int64_t nfwd = (int64_t)nt * S * 256, ntr = (int64_t)kt * Sn * 256, nb = (int64_t)nt * 32;
+  const int64_t nfwd = (int64_t)nt * S * 256, ntr = (int64_t)kt * Sn * 256, nb = (int64_t)nt * 64;
   const float* W = a.w[l];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nfwd + ntr + nb;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -51,8 +75,10 @@ __global__ void k_pack(PackArgs a) {
       const int k = 32 * t + (lane & 31), n = 8 * s + 4 * (lane >> 5) + e;
       a.packed[a.L.wt[l] + j] = (n < N && k < K) ? W[(int64_t)n * K + k] : 0.f;
     } else {
+      // bias as an MFMA A-operand fragment: lane (n, h = 0) carries bias[32 t + n], the h = 1 half is zero
       const int64_t j = i - nfwd - ntr;
-      a.packed[a.L.b[l] + j] = (j < N) ? a.b[l][j] : 0.f;
+      const int lane = j & 63, n = 32 * (int)(j >> 6) + (lane & 31);
+      a.packed[a.L.b[l] + j] = (lane < 32 && n < N) ? a.b[l][n] : 0.f;
     }
   }
 }
@@ -60,56 +86,156 @@ __global__ void k_pack(PackArgs a) {
 // ------------------------------------------------------------------------------------------
 // device building blocks
 // ------------------------------------------------------------------------------------------
-// acc[t] += sum over the 32*NT inputs held in `in`  (Wimg: fragment image with S = 4*NT groups).
-// Weight fragments are fetched PF groups ahead of their use (each group = NT coalesced 1 KiB loads
-// feeding 4*NT MFMAs), so an L2 / Infinity-Cache round trip hides under the wave's own MFMAs.
-//
-// Two optional side streams ride on the same software pipeline, one 16-byte access per lane and group,
-// so that no burst of memory traffic (and no wait for it) sits between two GEMMs:
-//   ST: `in` is written to st[8 s .. 8 s + 3] in group s (st = this lane's row + 4 h): group s multiplies
-//       exactly the four registers that hold those features.  Rows are padded to a multiple of 32 in the
-//       saved buffers, so the store needs no predicate.
-//   MK: the sign bits of a saved activation row (mk_src = that row + 4 h) are collected into mk: bit
-//       16 (t & 1) + r of word t >> 1 is set when element r of tile t is > 0 (relu' of the layer whose
-//       gradient `acc` is).
+// Hidden-to-hidden GEMM: acc[t] (+)= sum over the 32*NT inputs held in `in`  (Wimg: fragment image with
+// S = 4*NT groups).  Weight fragments are fetched PF groups ahead of their use (each group = NT coalesced
+// 1 KiB loads feeding 4*NT MFMAs), so an L2 / Infinity-Cache round trip hides under the wave's own MFMAs;
+// the first PF groups are requested by gemm_head, which the caller places ahead of the previous layer's
+// epilogue.
+//   FRESH: acc starts from zero (the first MFMA of each tile takes a zero C operand).
+//   BIAS:  the layer's bias enters as one more rank-1 MFMA per tile (bias fragment x ones), so no bias
+//          loads or adds sit between two GEMMs.
+// An optional side stream rides on the same software pipeline, one 16-byte store per lane and group, so that
+// no burst of memory traffic (and no wait for it) sits between two GEMMs:
+//   ST:  `in` is written to st[8 s .. 8 s + 3] in group s (st = this lane's row + 4 h): group s multiplies
+//        exactly the four registers that hold those features.  Rows are padded to a multiple of 32 in the
+//        saved buffers, so the store needs no predicate.
+//   MKW: (with ST) the sign bits of `in` are collected on the way and written to mk_dst when the GEMM ends:
+//        bit 16 (t & 1) + r of word t >> 1 is set when element r of tile t is > 0.  The backward chain reads
+//        these 4 NT bits per lane instead of the activations (relu' = sign bit of the output).
 constexpr int mask_words(int NT) { return (NT + 1) / 2; }
 
-// wave-uniform base + 32-bit lane offset: selects the scalar-base addressing mode (no 64-bit vector adds,
-// no address registers per fragment)
-__device__ __forceinline__ f32x4 frag_load(const f32x4* __restrict__ base, int frag, uint32_t lane_bytes) {
-  return *(const f32x4*)((const char*)(base + (size_t)frag * 64) + lane_bytes);
+// Fragment and activation-tile traffic goes through buffer instructions: a wave-uniform resource (base in
+// scalar registers), one 32-bit per-lane offset that never changes, and the fragment / group offset as a scalar
+// or immediate.  No per-access vector address arithmetic competes with the MFMAs for issue slots, and an access
+// outside the resource is dropped by the hardware instead of faulting.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 
-template <int NT, int PF, bool ST, bool MK>
-__device__ __forceinline__ void gemm_hh(const f32x4* __restrict__ Wimg, int lane, const f32x16 (&in)[NT],
-                                        f32x16 (&acc)[NT], float* __restrict__ st, const float* __restrict__ mk_src,
-                                        uint32_t (&mk)[mask_words(NT)]) {
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, off, 0));
+}
+
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_bytes, off, 0);
+}
+
+// fragment `frag` (64 lanes x 16 bytes) of a weight image
+__device__ __forceinline__ f32x4 frag_load(__amdgpu_buffer_rsrc_t img, int frag, uint32_t lane_bytes) {
+  return buf_load4(img, lane_bytes, (uint32_t)frag * 1024u);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+template <int NT, int PF, bool BIAS>
+__device__ __forceinline__ void gemm_head(const f32x4* __restrict__ Wimg, const float* __restrict__ Bimg, int lane,
+                                          f32x4 (&w)[PF + 1][NT], float (&bf)[NT]) {
   constexpr int S = 4 * NT;
   const uint32_t lb = (uint32_t)lane * 16u;
-  f32x4 w[PF + 1][NT];
-  f32x4 yv[PF + 1];
-  if (MK) {
+  const __amdgpu_buffer_rsrc_t img = make_rsrc(Wimg, NT * S * 1024u);
 #pragma unroll
-    for (int i = 0; i < mask_words(NT); ++i) mk[i] = 0u;
+  for (int p = 0; p < PF; ++p)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) w[p][t] = frag_load(img, t * S + p, lb);
+  if (BIAS) {
+    const __amdgpu_buffer_rsrc_t bimg = make_rsrc(Bimg, NT * 256u);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      bf[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bimg, (uint32_t)lane * 4u + t * 256u, 0, 0));
   }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NT>
+__device__ __forceinline__ void store_mask(uint32_t* __restrict__ dst, const uint32_t (&mk)[mask_words(NT)]) {
+  if (mask_words(NT) == 4) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    *(u32x4*)dst = u32x4{mk[0], mk[1], mk[2], mk[3]};
+  } else {
 #pragma unroll
-  for (int p = 0; p < PF; ++p) {
+    for (int i = 0; i < mask_words(NT); ++i) dst[i] = mk[i];
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void load_mask(const uint32_t* __restrict__ src, uint32_t (&mk)[mask_words(NT)]) {
+  if (mask_words(NT) == 4) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = *(const u32x4*)src;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) w[p][t] = frag_load(Wimg, t * S + p, lb);
-    if (MK) yv[p] = *(const f32x4*)(mk_src + 8 * p);
+    for (int i = 0; i < 4; ++i) mk[i] = v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < mask_words(NT); ++i) mk[i] = src[i];
+  }
+}
+
+// sign bits of group s of `in`, gemm_hh's MKW layout
+template <int NT>
+__device__ __forceinline__ void collect_mask(const f32x16 (&in)[NT], int s, uint32_t (&mk)[mask_words(NT)]) {
+  uint32_t bits = 0u;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bits |= (in[s >> 2][4 * (s & 3) + e] > 0.f ? 1u : 0u) << (16 * ((s >> 2) & 1) + 4 * (s & 3) + e);
+  if ((s & 7) == 0) mk[s >> 3] = bits;
+  else mk[s >> 3] |= bits;
+  // pin the few compare / select instructions to this group (they issue in the shadow of its MFMAs); left alone,
+  // the optimiser gathers all 32 NT of them after the last group, where nothing hides them
+  asm volatile("" : "+v"(mk[s >> 3]));
+}
+
+// What a GEMM does to its input registers on the way in (in place, four registers per group, in the shadow of
+// the previous group's MFMAs), so that no elementwise pass over the whole state sits between two GEMMs:
+enum { IN_ASIS = 0, IN_RELU = 1, IN_MASK = 2 };   // IN_MASK: v = sign bit set ? scale * v : 0 (relu backward)
+
+template <int INOP, int NT>
+__device__ __forceinline__ void in_op(f32x16 (&in)[NT], int s, const uint32_t (&mkin)[mask_words(NT)], float scale) {
+  if (INOP == IN_ASIS) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v = in[s >> 2][4 * (s & 3) + e];
+    if (INOP == IN_RELU) {
+      v = __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());   // max(v, 0) in one instruction (NaN -> 0, like fmaxf)
+    } else {
+      const bool on = (mkin[s >> 3] >> (16 * ((s >> 2) & 1) + 4 * (s & 3) + e)) & 1u;
+      v = on ? v * scale : 0.f;
+    }
+    in[s >> 2][4 * (s & 3) + e] = v;
+  }
+}
+
+template <int NT, int PF, bool FRESH, bool BIAS, bool ST, bool MKW, int INOP>
+__device__ __forceinline__ void gemm_hh(const f32x4* __restrict__ Wimg, int lane, f32x16 (&in)[NT],
+                                        f32x16 (&acc)[NT], f32x4 (&w)[PF + 1][NT], const float (&bf)[NT],
+                                        float* __restrict__ st_tile, uint32_t st_lane, uint32_t* __restrict__ mk_dst,
+                                        const uint32_t (&mkin)[mask_words(NT)], float scale) {
+  constexpr int S = 4 * NT;
+  const uint32_t lb = (uint32_t)lane * 16u;
+  const __amdgpu_buffer_rsrc_t img = make_rsrc(Wimg, NT * S * 1024u);
+  const __amdgpu_buffer_rsrc_t out = make_rsrc(st_tile, ST ? 32u * 32u * NT * 4u : 0u);
+  uint32_t mk[mask_words(NT)];
+  if (BIAS) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = MFMA(bf[t], 1.f, FRESH ? zero16() : acc[t]);
   }
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     if (s + PF < S) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) w[(s + PF) % (PF + 1)][t] = frag_load(Wimg, t * S + s + PF, lb);
-      if (MK) yv[(s + PF) % (PF + 1)] = *(const f32x4*)(mk_src + 8 * (s + PF));
+      for (int t = 0; t < NT; ++t) w[(s + PF) % (PF + 1)][t] = frag_load(img, t * S + s + PF, lb);
     }
+    in_op<INOP, NT>(in, s, mkin, scale);
     if (ST) {
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = in[s >> 2][4 * (s & 3) + e];
-      *(f32x4*)(st + 8 * s) = o;
+      buf_store4(out, st_lane, 32u * s, o);
     }
     // keep the memory operations of this group ahead of its MFMAs (the scheduler otherwise sinks them next to
     // their first use, which exposes the whole L2 latency)
@@ -118,49 +244,73 @@ __device__ __forceinline__ void gemm_hh(const f32x4* __restrict__ Wimg, int lane
     for (int e = 0; e < 4; ++e) {
       const float b = in[s >> 2][4 * (s & 3) + e];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = MFMA(w[s % (PF + 1)][t][e], b, acc[t]);
+      for (int t = 0; t < NT; ++t)
+        acc[t] = MFMA(w[s % (PF + 1)][t][e], b, (FRESH && !BIAS && s == 0 && e == 0) ? zero16() : acc[t]);
     }
-    if (MK) {
-      const f32x4 y = yv[s % (PF + 1)];
-      uint32_t bits = 0u;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bits |= (y[e] > 0.f ? 1u : 0u) << e;
-      mk[s >> 3] |= bits << (16 * ((s >> 2) & 1) + 4 * (s & 3));
-    }
+    if (MKW) collect_mask<NT>(in, s, mk);
   }
+  if (MKW) store_mask<NT>(mk_dst, mk);
 }
 
-// one 32-wide output tile: acc += W_tile in, optionally storing `in` on the way (see gemm_hh)
-template <int NT, bool ST>
-__device__ __forceinline__ void gemm_h1(const f32x4* __restrict__ Wtile, int lane, const f32x16 (&in)[NT], f32x16& acc,
-                                        float* __restrict__ st) {
+// One 32-wide output tile from the hidden state: acc += W_tile in, optionally storing `in` on the way (see
+// gemm_hh).  One accumulator, so a step is only 4 MFMAs: fragments are requested 8 steps ahead.
+template <int NT, bool ST, bool MKW, int INOP>
+__device__ __forceinline__ void gemm_h1(const f32x4* __restrict__ Wtile, int lane, f32x16 (&in)[NT], f32x16& acc,
+                                        float* __restrict__ st_tile, uint32_t st_lane, uint32_t* __restrict__ mk_dst,
+                                        const uint32_t (&mkin)[mask_words(NT)], float scale) {
   constexpr int S = 4 * NT;
+  constexpr int P1 = S < 8 ? S : 8;
+  const uint32_t lb = (uint32_t)lane * 16u;
+  const __amdgpu_buffer_rsrc_t img = make_rsrc(Wtile, S * 1024u);
+  const __amdgpu_buffer_rsrc_t out = make_rsrc(st_tile, ST ? 32u * 32u * NT * 4u : 0u);
+  uint32_t mk[mask_words(NT)];
+  f32x4 w[P1 + 1];
+#pragma unroll
+  for (int p = 0; p < P1; ++p) w[p] = frag_load(img, p, lb);
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    const f32x4 w = Wtile[s * 64 + lane];
+    if (s + P1 < S) w[(s + P1) % (P1 + 1)] = frag_load(img, s + P1, lb);
+    in_op<INOP, NT>(in, s, mkin, scale);
     if (ST) {
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = in[s >> 2][4 * (s & 3) + e];
-      *(f32x4*)(st + 8 * s) = o;
+      buf_store4(out, st_lane, 32u * s, o);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc = MFMA(w[e], in[s >> 2][4 * (s & 3) + e], acc);
+    for (int e = 0; e < 4; ++e) acc = MFMA(w[s % (P1 + 1)][e], in[s >> 2][4 * (s & 3) + e], acc);
+    if (MKW) collect_mask<NT>(in, s, mk);
   }
+  if (MKW) store_mask<NT>(mk_dst, mk);
 }
 
-// sign bits of a whole saved row, gemm_hh's MK layout
-template <int NT>
-__device__ __forceinline__ void load_mask(const float* __restrict__ src, uint32_t (&mk)[mask_words(NT)]) {
+// Network-input (or output-gradient) GEMM: acc[t] += W[:, 8 s ..] b(s) over a run-time number of groups, the B
+// operand of group s coming from load_b(s) (4 values of this lane's row).  Next group's fragments and operand
+// are requested before the current group's MFMAs (the index is clamped, so the last group is fetched twice
+// rather than branching).
+template <int NT, class LoadB>
+__device__ __forceinline__ void gemm_in(const f32x4* __restrict__ W, int S, int lane, f32x16 (&acc)[NT], LoadB load_b) {
+  const uint32_t lb = (uint32_t)lane * 16u;
+  const __amdgpu_buffer_rsrc_t img = make_rsrc(W, (uint32_t)(NT * S) * 1024u);
+  f32x4 wn[NT];
 #pragma unroll
-  for (int i = 0; i < mask_words(NT); ++i) mk[i] = 0u;
+  for (int t = 0; t < NT; ++t) wn[t] = frag_load(img, t * S, lb);
+  f32x4 bn = load_b(0);
+  for (int s = 0; s < S; ++s) {
+    f32x4 w[NT];
 #pragma unroll
-  for (int s = 0; s < 4 * NT; ++s) {
-    const f32x4 y = *(const f32x4*)(src + 8 * s);
-    uint32_t bits = 0u;
+    for (int t = 0; t < NT; ++t) w[t] = wn[t];
+    const f32x4 b = bn;
+    const int s1 = s + 1 < S ? s + 1 : S - 1;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bits |= (y[e] > 0.f ? 1u : 0u) << e;
-    mk[s >> 3] |= bits << (16 * ((s >> 2) & 1) + 4 * (s & 3));
+    for (int t = 0; t < NT; ++t) wn[t] = frag_load(img, t * S + s1, lb);
+    bn = load_b(s1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = MFMA(w[t][e], b[e], acc[t]);
   }
 }
 
@@ -173,30 +323,6 @@ __device__ __forceinline__ void apply_mask(f32x16 (&v)[NT], const uint32_t (&mk)
     for (int r = 0; r < 16; ++r) {
       const bool on = (mk[t >> 1] >> (16 * (t & 1) + r)) & 1u;
       v[t][r] = on ? v[t][r] * scale : 0.f;
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void set_bias(f32x16 (&v)[NT], const float* __restrict__ bias, int h) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b = *(const f32x4*)(bias + 32 * t + 8 * q + 4 * h);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[t][4 * q + e] = b[e];
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void add_bias(f32x16 (&v)[NT], const float* __restrict__ bias, int h) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b = *(const f32x4*)(bias + 32 * t + 8 * q + 4 * h);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[t][4 * q + e] += b[e];
     }
 }
 
@@ -222,10 +348,11 @@ __device__ __forceinline__ void store_rows(const f32x16 (&v)[NT], float* __restr
     }
 }
 
-// relu (every shipped config) gets a branch-free path; the other activations share a generic one
-template <int NT>
+// relu (every shipped config) is compiled into its own kernels; the other activations share a generic,
+// rolled path (act is a run-time value there)
+template <int NT, bool RELU>
 __device__ __forceinline__ void apply_act(f32x16 (&v)[NT], int act) {
-  if (act == DMV_ACT_RELU) {
+  if (RELU) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -257,29 +384,48 @@ struct FwdArgs {
   int64_t ldy;
   float* xs;     // saved first-layer input [rows][32*T_in] (nullable)
   float* acts;   // saved activations [(2nb+1)][rows][32*NT] (nullable)
+  uint32_t* masks;  // sign bits of the saved activations [(2nb+1)][rows][2][mask_words] (with acts)
   const uint8_t* drop_keep;  // [nb][rows][hidden] (nullable)
 };
 
-__device__ __forceinline__ float first_layer_input(const FwdArgs& a, int64_t r, int k) {
-  if (k >= a.in_dim) return 0.f;
-  switch (a.in_mode) {
-    case DMV_IN_PLAIN: return a.x[r * a.ldx + k];
-    case DMV_IN_MASKED: return a.x[r * a.ldx + k] * (float)a.m[r * a.ldm + k];
-    case DMV_IN_CONCAT:
-      return k < a.D ? a.x[r * a.ldx + k] : (float)a.m[r * a.ldm + (k - a.D)];
-    default:
-      return k < a.D ? a.x[r * a.ldx + k] * (float)a.m[r * a.ldm + k] : (float)a.m[r * a.ldm + (k - a.D)];
+// Four consecutive first-layer inputs (columns k0 .. k0+3) of row r, branch-free: loads are unconditional with
+// the column clamped into the row, the input mode only selects between the loaded values.
+__device__ __forceinline__ f32x4 first_layer_input4(const FwdArgs& a, int64_t r, int k0) {
+  const bool use_mask = a.in_mode == DMV_IN_MASKED || a.in_mode == DMV_IN_CONCAT_MASKED;
+  const float* xr = a.x + r * a.ldx;
+  f32x4 out;
+  if (a.in_mode == DMV_IN_PLAIN) {   // uniform
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + e;
+      const float xv = xr[k < a.D ? k : a.D - 1];
+      out[e] = k < a.in_dim ? xv : 0.f;
+    }
+    return out;
   }
+  const uint8_t* mr = a.m + r * a.ldm;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k = k0 + e;
+    int kc = k < a.D ? k : k - a.D;
+    kc = kc < a.D ? kc : a.D - 1;
+    const float xv = xr[kc], mv = (float)mr[kc];
+    const float head = use_mask ? xv * mv : xv;
+    out[e] = k < a.in_dim ? (k < a.D ? head : mv) : 0.f;
+  }
+  return out;
 }
 
 // SAVE: training forward (stores the first-layer input and every hidden activation for the backward;
 // the saved buffers hold rows rounded up to a multiple of 32, so whole-wave stores need no predicate).
 // A hidden activation is written while the next GEMM consumes it (gemm_hh / gemm_h1, ST).
-template <int NT, bool SAVE>
+// FAST: relu and no dropout (what every shipped configuration runs); the generic kernels take the activation and
+// the keep-masks at run time.
+template <int NT, bool SAVE, bool FAST>
 __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
-  constexpr int PF = 2;
+  constexpr int PF = 1;
   const int lane = threadIdx.x & 63;
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 32;
   if (row0 >= a.rows) return;
   const int m = lane & 31, h = lane >> 5;
   const int64_t row = row0 + m;
@@ -287,43 +433,48 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
   const int64_t rl = live ? row : a.rows - 1;
   constexpr int Hp = 32 * NT;
   const int64_t act_stride = ((a.rows + 31) & ~(int64_t)31) * Hp;
-  float* st = SAVE ? a.acts + row * Hp + 4 * h : nullptr;   // this lane's slot in the saved activations, layer 0
-  uint32_t nomask[mask_words(NT)];
+  constexpr int MW = mask_words(NT);
+  const int64_t mask_stride = ((a.rows + 31) & ~(int64_t)31) * 2 * MW;
+  float* st = SAVE ? a.acts + row0 * Hp : nullptr;          // this wave's 32-row tile of the saved activations, layer 0
+  const uint32_t stl = (uint32_t)(m * Hp + 4 * h) * 4u;     // this lane's byte offset inside a tile
+  uint32_t* mkd = SAVE ? a.masks + (row * 2 + h) * MW : nullptr;   // ... and in their sign bits
 
   f32x16 A[NT], T[NT];
+  f32x4 w[PF + 1][NT];   // weight ring of the hidden GEMMs
+  float bf[NT];          // bias fragments of the next hidden GEMM
 
-  // ---- initial layer
-  set_bias<NT>(A, a.packed + a.L.b[0], h);
+  TRACE(0);
+  TRACE_REAL(13);
+  // ---- initial layer (the first block's weights are requested first: they arrive under the input loads)
+  if (a.nb > 0) gemm_head<NT, PF, true>((const f32x4*)(a.packed + a.L.w[1]), a.packed + a.L.b[1], lane, w, bf);
   {
-    const f32x4* W = (const f32x4*)(a.packed + a.L.w[0]);
-    const int S = a.L.S_in;
-    for (int s = 0; s < S; ++s) {
-      float b[4];
+    const float* B0 = a.packed + a.L.b[0];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) b[e] = first_layer_input(a, rl, 8 * s + 4 * h + e);
-      if (SAVE) {
-        f32x4 o = {b[0], b[1], b[2], b[3]};
-        *(f32x4*)(a.xs + row * (32 * a.L.T_in) + 8 * s + 4 * h) = o;
-      }
-      f32x4 w[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) w[t] = W[(t * S + s) * 64 + lane];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) A[t] = MFMA(w[t][e], b[e], A[t]);
-    }
+    for (int t = 0; t < NT; ++t) A[t] = MFMA(B0[t * 64 + lane], 1.f, zero16());
+    float* xs_row = SAVE ? a.xs + row * (32 * a.L.T_in) + 4 * h : nullptr;
+    gemm_in<NT>((const f32x4*)(a.packed + a.L.w[0]), a.L.S_in, lane, A, [&](int s) {
+      const f32x4 b = first_layer_input4(a, rl, 8 * s + 4 * h);
+      if (SAVE) *(f32x4*)(xs_row + 8 * s) = b;
+      return b;
+    });
   }
-  apply_act<NT>(A, a.act);
+  TRACE(1);
+  // FAST: relu is applied by the GEMM that consumes a state (IN_RELU), in place
+  constexpr int INR = FAST ? IN_RELU : IN_ASIS;
+  uint32_t nomask[mask_words(NT)];
+  if (!FAST) apply_act<NT, false>(A, a.act);
+  TRACE(2);
 
   // ---- residual blocks
   for (int blk = 0; blk < a.nb; ++blk) {
     const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
-    set_bias<NT>(T, a.packed + a.L.b[l1], h);
-    gemm_hh<NT, PF, SAVE, false>((const f32x4*)(a.packed + a.L.w[l1]), lane, A, T, st + (l1 - 1) * act_stride, nullptr,
-                                 nomask);
-    apply_act<NT>(T, a.act);
-    if (a.drop_keep) {
+    gemm_hh<NT, PF, true, true, SAVE, SAVE, INR>((const f32x4*)(a.packed + a.L.w[l1]), lane, A, T, w, bf,
+                                                 st + (l1 - 1) * act_stride, stl, mkd + (l1 - 1) * mask_stride, nomask, 1.f);
+    TRACE(3 + 4 * blk);
+    gemm_head<NT, PF, true>((const f32x4*)(a.packed + a.L.w[l2]), a.packed + a.L.b[l2], lane, w, bf);
+    if (!FAST) apply_act<NT, false>(T, a.act);
+    TRACE(4 + 4 * blk);
+    if (!FAST && a.drop_keep) {
       const uint8_t* keep = a.drop_keep + ((int64_t)blk * a.rows + rl) * a.hidden;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -334,30 +485,28 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
           T[t][r] *= kf;
         }
     }
-    add_bias<NT>(A, a.packed + a.L.b[l2], h);
-    gemm_hh<NT, PF, SAVE, false>((const f32x4*)(a.packed + a.L.w[l2]), lane, T, A, st + l1 * act_stride, nullptr,
-                                 nomask);
-    apply_act<NT>(A, a.act);
+    gemm_hh<NT, PF, false, true, SAVE, SAVE, INR>((const f32x4*)(a.packed + a.L.w[l2]), lane, T, A, w, bf,
+                                                  st + l1 * act_stride, stl, mkd + l1 * mask_stride, nomask, 1.f);
+    TRACE(5 + 4 * blk);
+    if (blk + 1 < a.nb)
+      gemm_head<NT, PF, true>((const f32x4*)(a.packed + a.L.w[l2 + 1]), a.packed + a.L.b[l2 + 1], lane, w, bf);
+    if (!FAST) apply_act<NT, false>(A, a.act);
+    TRACE(6 + 4 * blk);
   }
 
   // ---- final layer: one 32-wide output tile at a time
   {
     const int lf = a.L.nl - 1;
     const f32x4* W = (const f32x4*)(a.packed + a.L.w[lf]);
-    const float* bias = a.packed + a.L.b[lf];
+    const float* Bf = a.packed + a.L.b[lf];
     constexpr int S = 4 * NT;
     for (int ot = 0; ot < a.L.OT; ++ot) {
-      f32x16 acc;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 b = *(const f32x4*)(bias + 32 * ot + 8 * q + 4 * h);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[4 * q + e] = b[e];
-      }
+      f32x16 acc = MFMA(Bf[ot * 64 + lane], 1.f, zero16());
       if (SAVE && ot == 0)
-        gemm_h1<NT, true>(W, lane, A, acc, st + (lf - 1) * act_stride);
-      else
-        gemm_h1<NT, false>(W + (int64_t)ot * S * 64, lane, A, acc, nullptr);
+        gemm_h1<NT, true, true, INR>(W, lane, A, acc, st + (lf - 1) * act_stride, stl, mkd + (lf - 1) * mask_stride,
+                                     nomask, 1.f);
+      else   // (relu is idempotent: a second pass over A leaves it as it is)
+        gemm_h1<NT, false, false, INR>(W + (int64_t)ot * S * 64, lane, A, acc, nullptr, 0u, nullptr, nomask, 1.f);
       if (live) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -369,6 +518,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
       }
     }
   }
+  TRACE(15);
+  TRACE_REAL(14);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -381,6 +532,7 @@ struct BwdArgs {
   int nb, hidden, act;
   float drop_scale;
   const float* acts;         // [(2nb+1)][rows][Hp]
+  const uint32_t* masks;     // sign bits of acts, [(2nb+1)][rows][2][mask_words]
   const uint8_t* drop_keep;  // nullable
   const float* gy;
   int64_t ldgy;
@@ -415,14 +567,14 @@ __device__ __forceinline__ void mul_act_grad(f32x16 (&v)[NT], const float* __res
 }
 
 // RELU: the activation derivative is the sign bit of the saved output (post-dropout outputs included: a
-// dropped or inactive unit saved 0).  Those bits are prefetched while the preceding GEMM runs (gemm_hh, MK),
-// and every layer gradient is written while the following GEMM consumes it (ST), so the only memory waits
-// left between GEMMs are the ones at the two ends of the chain.
+// dropped or inactive unit saved 0).  The forward left those bits packed per lane (gemm_hh, MKW): one 16-byte
+// load per layer, requested before the preceding GEMM.  Every layer gradient is written while the following
+// GEMM consumes it (ST), so the only memory waits left between GEMMs are the ones at the two ends of the chain.
 template <int NT, bool RELU>
 __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
-  constexpr int PF = RELU ? 2 : 1;
+  constexpr int PF = 1;
   const int lane = threadIdx.x & 63;
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 32;
   if (row0 >= a.rows) return;
   const int m = lane & 31, h = lane >> 5;
   const int64_t row = row0 + m;
@@ -431,41 +583,46 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
   constexpr int Hp = 32 * NT;
   const int64_t act_stride = ((a.rows + 31) & ~(int64_t)31) * Hp;
   const int lf = a.L.nl - 1;
-  float* st = a.dacts + row * Hp + 4 * h;             // this lane's slot in the layer-gradient buffer, layer 0
-  const float* sv = a.acts + rl * Hp + 4 * h;         // ... and in the saved activations
+  float* st = a.dacts + row0 * Hp;                    // this wave's 32-row tile of the layer-gradient buffer, layer 0
+  const uint32_t stl = (uint32_t)(m * Hp + 4 * h) * 4u;   // this lane's byte offset inside a tile
+  constexpr int MW = mask_words(NT);
+  const int64_t mask_stride = ((a.rows + 31) & ~(int64_t)31) * 2 * MW;
+  const uint32_t* mks = a.masks + (row * 2 + h) * MW;  // ... and in the sign bits of the saved activations
   const float dscale = a.drop_keep ? a.drop_scale : 1.f;
   uint32_t mkA[mask_words(NT)], mkT[mask_words(NT)];
+  constexpr int INM = RELU ? IN_MASK : IN_ASIS;   // relu backward is applied by the GEMM that consumes a gradient
 
+  TRACE(0);
+  TRACE_REAL(13);
   f32x16 dA[NT], dT[NT];
-  if (RELU) load_mask<NT>(sv + (lf - 1) * act_stride, mkA);
-  zero<NT>(dA);
+  f32x4 w[PF + 1][NT];
+  float nobias[NT];
+  if (a.nb > 0) gemm_head<NT, PF, false>((const f32x4*)(a.packed + a.L.wt[2 * a.nb]), nullptr, lane, w, nobias);
+  if (RELU) load_mask<NT>(mks + (lf - 1) * mask_stride, mkA);
   // dA = Wf^T gy
+  zero<NT>(dA);
   {
-    const f32x4* W = (const f32x4*)(a.packed + a.L.wt[lf]);
-    const int S = a.L.S_out;
-    for (int s = 0; s < S; ++s) {
-      f32x4 b = *(const f32x4*)(a.gy + rl * a.ldgy + 8 * s + 4 * h);
-      if (!live) b = f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 w[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) w[t] = W[(t * S + s) * 64 + lane];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) dA[t] = MFMA(w[t][e], b[e], dA[t]);
-    }
+    const float* gyr = a.gy + rl * a.ldgy + 4 * h;
+    gemm_in<NT>((const f32x4*)(a.packed + a.L.wt[lf]), a.L.S_out, lane, dA, [&](int s) {
+      const f32x4 b = *(const f32x4*)(gyr + 8 * s);
+      return live ? b : f32x4{0.f, 0.f, 0.f, 0.f};
+    });
   }
+  TRACE(1);
   for (int blk = a.nb - 1; blk >= 0; --blk) {
     const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
+    const int tb_ = 4 * (a.nb - 1 - blk); (void)tb_;
     // through the block's output activation: dA becomes the gradient of (a_in + W2 t + b2)
-    if (RELU) apply_mask<NT>(dA, mkA, 1.f);
-    else mul_act_grad<NT>(dA, a.acts + l2 * act_stride + rl * Hp, h, a.act);
-    zero<NT>(dT);
-    gemm_hh<NT, PF, true, RELU>((const f32x4*)(a.packed + a.L.wt[l2]), lane, dA, dT, st + l2 * act_stride,
-                                sv + l1 * act_stride, mkT);
+    if (!RELU) mul_act_grad<NT>(dA, a.acts + l2 * act_stride + rl * Hp, h, a.act);
+    TRACE(2 + tb_);
+    if (RELU) load_mask<NT>(mks + l1 * mask_stride, mkT);   // requested here, needed after the GEMM
+    gemm_hh<NT, PF, true, false, true, false, INM>((const f32x4*)(a.packed + a.L.wt[l2]), lane, dA, dT, w, nobias,
+                                                   st + l2 * act_stride, stl, nullptr, mkA, 1.f);
+    TRACE(3 + tb_);
+    gemm_head<NT, PF, false>((const f32x4*)(a.packed + a.L.wt[l1]), nullptr, lane, w, nobias);
     // through dropout and the inner activation
     if (RELU) {
-      apply_mask<NT>(dT, mkT, dscale);
+      // applied by the next GEMM on its way in
     } else if (!a.drop_keep) {
       mul_act_grad<NT>(dT, a.acts + l1 * act_stride + rl * Hp, h, a.act);
     } else {
@@ -486,24 +643,26 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
           }
         }
     }
+    TRACE(4 + tb_);
     // dA (skip path) += W1^T dT
-    gemm_hh<NT, PF, true, RELU>((const f32x4*)(a.packed + a.L.wt[l1]), lane, dT, dA, st + l1 * act_stride,
-                                sv + (l1 - 1) * act_stride, mkA);
+    if (RELU) load_mask<NT>(mks + (l1 - 1) * mask_stride, mkA);
+    gemm_hh<NT, PF, false, false, true, false, INM>((const f32x4*)(a.packed + a.L.wt[l1]), lane, dT, dA, w, nobias,
+                                                    st + l1 * act_stride, stl, nullptr, mkT, dscale);
+    TRACE(5 + tb_);
+    if (blk > 0) gemm_head<NT, PF, false>((const f32x4*)(a.packed + a.L.wt[l1 - 1]), nullptr, lane, w, nobias);
   }
-  if (RELU) apply_mask<NT>(dA, mkA, 1.f);
-  else mul_act_grad<NT>(dA, a.acts + rl * Hp, h, a.act);
+  if (!RELU) mul_act_grad<NT>(dA, a.acts + rl * Hp, h, a.act);
 
+  TRACE(10);
   if (a.dx) {
     const f32x4* W = (const f32x4*)(a.packed + a.L.wt[0]);
     constexpr int S = 4 * NT;
     for (int it = 0; it < a.L.T_in; ++it) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      f32x16 acc = zero16();
       if (it == 0)
-        gemm_h1<NT, true>(W, lane, dA, acc, st);
-      else
-        gemm_h1<NT, false>(W + (int64_t)it * S * 64, lane, dA, acc, nullptr);
+        gemm_h1<NT, true, false, INM>(W, lane, dA, acc, st, stl, nullptr, mkA, 1.f);
+      else   // dA is already masked in place by the first pass
+        gemm_h1<NT, false, false, IN_ASIS>(W + (int64_t)it * S * 64, lane, dA, acc, nullptr, 0u, nullptr, mkA, 1.f);
       if (live) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -515,8 +674,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
       }
     }
   } else {
+    if (RELU) apply_mask<NT>(dA, mkA, 1.f);
     store_rows<NT>(dA, a.dacts + row * Hp, h);
   }
+  TRACE(15);
+  TRACE_REAL(14);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -747,17 +909,22 @@ extern "C" size_t dmv_mlp_saved_floats(const DmvNet* net, int64_t rows) {
   if (dmv_check_net(net) != DMV_OK || rows < 0) return 0;
   const int64_t Hp = dmv_pad32(net->hidden), Ip = dmv_pad32(net->in_dim);
   const int64_t rp = (rows + 31) & ~(int64_t)31;   // whole 32-row wave tiles: the kernels store without predicates
-  return (size_t)(rp * Ip + (2 * net->nb + 1) * rp * Hp);
+  const int64_t mw = 2 * (((Hp / 32) + 1) / 2);    // sign-bit words per row and layer (two half-rows)
+  return (size_t)(rp * Ip + (2 * net->nb + 1) * rp * (Hp + mw));
 }
 
 template <int NT>
 static int launch_fwd(const FwdArgs& a, hipStream_t st) {
   const int64_t waves = (a.rows + 31) / 32;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  if (a.acts)
-    hipLaunchKernelGGL((k_mlp_fwd<NT, true>), dim3(grid), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((k_mlp_fwd<NT, false>), dim3(grid), dim3(256), 0, st, a);
+  const bool fast = a.act == DMV_ACT_RELU && !a.drop_keep;
+  if (a.acts) {
+    if (fast) hipLaunchKernelGGL((k_mlp_fwd<NT, true, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_mlp_fwd<NT, true, false>), dim3(grid), dim3(256), 0, st, a);
+  } else {
+    if (fast) hipLaunchKernelGGL((k_mlp_fwd<NT, false, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_mlp_fwd<NT, false, false>), dim3(grid), dim3(256), 0, st, a);
+  }
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
@@ -809,7 +976,9 @@ extern "C" int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t i
   a.x = x; a.ldx = ldx; a.m = m; a.ldm = ldm; a.rows = rows;
   a.y = y; a.ldy = ldy;
   a.xs = saved;
-  a.acts = saved ? saved + ((rows + 31) & ~(int64_t)31) * dmv_pad32(net->in_dim) : nullptr;
+  const int64_t rp = (rows + 31) & ~(int64_t)31;
+  a.acts = saved ? saved + rp * dmv_pad32(net->in_dim) : nullptr;
+  a.masks = saved ? (uint32_t*)(a.acts + (2 * net->nb + 1) * rp * dmv_pad32(net->hidden)) : nullptr;
   a.drop_keep = drop_keep;
   DMV_DISPATCH_NT(a.L.NT, launch_fwd, a, (hipStream_t)stream);
 }
@@ -909,6 +1078,7 @@ extern "C" int dmv_mlp_backward(const DmvNet* net, const float* packed, const fl
   b.nb = net->nb; b.hidden = net->hidden; b.act = net->act;
   b.drop_scale = 1.f / (1.f - net->dropout_p);
   b.acts = acts; b.drop_keep = drop_keep;
+  b.masks = (const uint32_t*)(acts + (2 * net->nb + 1) * rp * Hp);
   b.gy = gy; b.ldgy = ldgy; b.rows = rows;
   b.dacts = dacts; b.dx = dx; b.lddx = lddx;
   {

@@ -65,9 +65,10 @@ def test_abi_exports_every_declared_symbol():
     assert b"workspace" in l.dmv_strerror(-3)
     # pure host entry points: sizes follow the documented layout
     net = _lib.DmvNet(16, 16, 256, 2, 0, 0.0)
-    per_hidden = 2 * (8 * 32 * 256) + 256
-    assert l.dmv_mlp_packed_floats(ctypes.byref(net)) == (2 * 8 * 2 * 256 + 256) + 4 * per_hidden + (2 * 32 * 256 + 32)
-    assert l.dmv_mlp_saved_floats(ctypes.byref(net), 100) == 128 * 32 + 5 * 128 * 256  # rows padded to 32
+    # forward + transposed fragment images, then one 64-lane bias fragment per 32-wide output tile
+    per_hidden = 2 * (8 * 32 * 256) + 8 * 64
+    assert l.dmv_mlp_packed_floats(ctypes.byref(net)) == (2 * 8 * 2 * 256 + 8 * 64) + 4 * per_hidden + (2 * 32 * 256 + 64)
+    assert l.dmv_mlp_saved_floats(ctypes.byref(net), 100) == 128 * 32 + 5 * 128 * (256 + 8)  # rows padded to 32; 8 sign-bit words per row and layer
     bad = _lib.DmvNet(16, 16, 512, 2, 0, 0.0)
     assert l.dmv_mlp_packed_floats(ctypes.byref(bad)) == 0          # hidden width outside the kernels' range
 
