@@ -281,8 +281,11 @@ def main():
 
             t512 = timed(step512, 50, 10, barrier)
             extra["yaml_batch_512"] = {"ms_per_step": round(t512 * 1e3, 4), "samples_per_s": round(512 * K / t512, 1)}
-            from demiss_vae_amd.bench_extra import demiss_toy_step
+            from demiss_vae_amd.bench_extra import demiss_toy_step, missiwae_step
             extra["demiss_toy_mvb2"] = demiss_toy_step(device)
+            extra["hepmass_missiwae"] = missiwae_step(device, "UCI-hepmass", 4096, 21, 16, (42, 165, 2, 256), (16, 42, 2, 256))
+            extra["miniboone_missiwae"] = missiwae_step(device, "UCI-miniboone", 8192, 43, 32, (86, 325, 5, 256),
+                                                        (32, 86, 2, 256), dropout=0.5)
             extra["loglik_eval_K50000"] = ll
             out["extra"] = extra
         if not args.no_cpu:

@@ -4,7 +4,8 @@ import time
 
 import torch
 
-from . import estimate_iwelbo, mvb2_objectives, ModelDims, NetDims, PackedNet  # noqa: F401
+from . import estimate_iwelbo, estimate_multiple_iwelbo, mvb2_objectives, ModelDims, NetDims, PackedNet  # noqa: F401
+from .mlp import make_keep_masks
 from . import imputation as imp
 from . import parallel as P
 
@@ -20,12 +21,43 @@ def _sync_time(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
-def _packed(device, spec, seed, requires_grad):
+def _packed(device, spec, seed, requires_grad, dropout=0.0):
     from oracle.recipes import make_params
     p = make_params(spec, seed)
     ws = [p[n + ".weight"].to(device).requires_grad_(requires_grad) for n in spec.layer_names()]
     bs = [p[n + ".bias"].to(device).requires_grad_(requires_grad) for n in spec.layer_names()]
-    return PackedNet(NetDims(spec.in_dim, spec.out_dim, spec.nb, spec.hidden), ws, bs)
+    return PackedNet(NetDims(spec.in_dim, spec.out_dim, spec.nb, spec.hidden, dropout=dropout), ws, bs)
+
+
+def missiwae_step(device, name, B, D, Zd, enc_shape, dec_shape, C=5, dropout=0.0):
+    """MissSIWAE training step (stratified mixture of C Gaussians as the encoder, one importance sample per
+    component, tight bound): configs/uci_hepmass/mis50/miwae_stratified_k5_i1_encm_stl.yaml and the miniboone
+    counterpart (dropout 0.5 in both networks).  Fresh dropout masks every step, Adam included."""
+    from oracle.recipes import NetSpec, make_batch
+    enc_s, dec_s = NetSpec(*enc_shape), NetSpec(*dec_shape)
+    enc, dec = _packed(device, enc_s, 1, True, dropout), _packed(device, dec_s, 2, True, dropout)
+    dims = ModelDims(D=D, Zd=Zd, q_dist="stratified_with_eps", C=C, encoder_use_mis_mask=True)
+    X, M = make_batch(3, B, D)
+    X, M = X.to(device), M.to(device)
+    opt = torch.optim.Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True, fused=True)
+
+    def step():
+        ek = make_keep_masks(enc.dims, B, device)
+        dk = make_keep_masks(dec.dims, B * C, device)
+        bound, _ = estimate_multiple_iwelbo(dims, enc, dec, X, M, num_importance_samples_for_each_component=1, STL=True,
+                                            enc_keep=ek, dec_keep=dk)
+        opt.zero_grad(set_to_none=True)
+        (-bound).backward()
+        opt.step()
+
+    t = _sync_time(step, 20, 5)
+    macs = lambda sp: sum(n * k for n, k in sp.layer_shapes())
+    flops = 3 * 2 * B * (macs(enc_s) + C * macs(dec_s))
+    out = {"workload": f"{name} MissSIWAE C={C} I_c=1 STL step incl. Adam, B={B}, dropout={dropout}", "ms_per_step": round(t * 1e3, 4),
+           "samples_per_s": round(B * C / t, 1)}
+    if flops:
+        out["step_tflops"] = round(flops / t / 1e12, 2)
+    return out
 
 
 def demiss_toy_step(device, B=4096, K=5):

@@ -122,6 +122,13 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, uint32_t la
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_bytes, off, 0);
 }
 
+// keep-masks of one residual block for this wave's 32 rows, as a buffer: a read past the end of the masks
+// (padded features of the last rows) returns 0 and is never used (those features are identically 0)
+struct DropIn {
+  __amdgpu_buffer_rsrc_t keep;
+  uint32_t lane;   // byte offset of this lane's row + 4 h
+};
+
 // fragment `frag` (64 lanes x 16 bytes) of a weight image
 __device__ __forceinline__ f32x4 frag_load(__amdgpu_buffer_rsrc_t img, int frag, uint32_t lane_bytes) {
   return buf_load4(img, lane_bytes, (uint32_t)frag * 1024u);
@@ -134,9 +141,10 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
-template <int NT, int PF, bool BIAS>
+template <int NT, int PF, bool BIAS, bool DROP = false>
 __device__ __forceinline__ void gemm_head(const f32x4* __restrict__ Wimg, const float* __restrict__ Bimg, int lane,
-                                          f32x4 (&w)[PF + 1][NT], float (&bf)[NT]) {
+                                          f32x4 (&w)[PF + 1][NT], float (&bf)[NT], const DropIn* drop = nullptr,
+                                          uint32_t* kp = nullptr) {
   constexpr int S = 4 * NT;
   const uint32_t lb = (uint32_t)lane * 16u;
   const __amdgpu_buffer_rsrc_t img = make_rsrc(Wimg, NT * S * 1024u);
@@ -149,6 +157,10 @@ __device__ __forceinline__ void gemm_head(const f32x4* __restrict__ Wimg, const 
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       bf[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bimg, (uint32_t)lane * 4u + t * 256u, 0, 0));
+  }
+  if (DROP) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) kp[p] = __builtin_amdgcn_raw_buffer_load_b32(drop->keep, drop->lane, 8u * p, 0);
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -192,16 +204,21 @@ __device__ __forceinline__ void collect_mask(const f32x16 (&in)[NT], int s, uint
 
 // What a GEMM does to its input registers on the way in (in place, four registers per group, in the shadow of
 // the previous group's MFMAs), so that no elementwise pass over the whole state sits between two GEMMs:
-enum { IN_ASIS = 0, IN_RELU = 1, IN_MASK = 2 };   // IN_MASK: v = sign bit set ? scale * v : 0 (relu backward)
+//   IN_MASK:      v = sign bit set ? scale * v : 0           (relu backward, dropout scale folded in)
+//   IN_RELU_DROP: v = keep byte set ? scale * max(v, 0) : 0  (relu then inverted dropout; keep4 = this group's 4 bytes)
+enum { IN_ASIS = 0, IN_RELU = 1, IN_MASK = 2, IN_RELU_DROP = 3 };
 
 template <int INOP, int NT>
-__device__ __forceinline__ void in_op(f32x16 (&in)[NT], int s, const uint32_t (&mkin)[mask_words(NT)], float scale) {
+__device__ __forceinline__ void in_op(f32x16 (&in)[NT], int s, const uint32_t (&mkin)[mask_words(NT)], float scale,
+                                      uint32_t keep4 = 0u) {
   if (INOP == IN_ASIS) return;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float v = in[s >> 2][4 * (s & 3) + e];
     if (INOP == IN_RELU) {
       v = __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());   // max(v, 0) in one instruction (NaN -> 0, like fmaxf)
+    } else if (INOP == IN_RELU_DROP) {
+      v = ((keep4 >> (8 * e)) & 0xffu) ? scale * __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()) : 0.f;
     } else {
       const bool on = (mkin[s >> 3] >> (16 * ((s >> 2) & 1) + 4 * (s & 3) + e)) & 1u;
       v = on ? v * scale : 0.f;
@@ -214,7 +231,8 @@ template <int NT, int PF, bool FRESH, bool BIAS, bool ST, bool MKW, int INOP>
 __device__ __forceinline__ void gemm_hh(const f32x4* __restrict__ Wimg, int lane, f32x16 (&in)[NT],
                                         f32x16 (&acc)[NT], f32x4 (&w)[PF + 1][NT], const float (&bf)[NT],
                                         float* __restrict__ st_tile, uint32_t st_lane, uint32_t* __restrict__ mk_dst,
-                                        const uint32_t (&mkin)[mask_words(NT)], float scale) {
+                                        const uint32_t (&mkin)[mask_words(NT)], float scale,
+                                        const DropIn* drop = nullptr, uint32_t* kp = nullptr) {
   constexpr int S = 4 * NT;
   const uint32_t lb = (uint32_t)lane * 16u;
   const __amdgpu_buffer_rsrc_t img = make_rsrc(Wimg, NT * S * 1024u);
@@ -229,8 +247,10 @@ __device__ __forceinline__ void gemm_hh(const f32x4* __restrict__ Wimg, int lane
     if (s + PF < S) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) w[(s + PF) % (PF + 1)][t] = frag_load(img, t * S + s + PF, lb);
+      if (INOP == IN_RELU_DROP)
+        kp[(s + PF) % (PF + 1)] = __builtin_amdgcn_raw_buffer_load_b32(drop->keep, drop->lane, 8u * (s + PF), 0);
     }
-    in_op<INOP, NT>(in, s, mkin, scale);
+    in_op<INOP, NT>(in, s, mkin, scale, INOP == IN_RELU_DROP ? kp[s % (PF + 1)] : 0u);
     if (ST) {
       f32x4 o;
 #pragma unroll
@@ -419,10 +439,13 @@ __device__ __forceinline__ f32x4 first_layer_input4(const FwdArgs& a, int64_t r,
 // SAVE: training forward (stores the first-layer input and every hidden activation for the backward;
 // the saved buffers hold rows rounded up to a multiple of 32, so whole-wave stores need no predicate).
 // A hidden activation is written while the next GEMM consumes it (gemm_hh / gemm_h1, ST).
-// FAST: relu and no dropout (what every shipped configuration runs); the generic kernels take the activation and
-// the keep-masks at run time.
-template <int NT, bool SAVE, bool FAST>
+// MODE: relu networks (every shipped configuration) run specialised kernels, without (FWD_RELU) or with
+// (FWD_RELU_DROP) dropout inside the residual blocks; FWD_GENERIC takes the activation at run time.
+enum { FWD_GENERIC = 0, FWD_RELU = 1, FWD_RELU_DROP = 2 };
+
+template <int NT, bool SAVE, int MODE>
 __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
+  constexpr bool FAST = MODE != FWD_GENERIC;
   constexpr int PF = 1;
   const int lane = threadIdx.x & 63;
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 32;
@@ -471,7 +494,17 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
     gemm_hh<NT, PF, true, true, SAVE, SAVE, INR>((const f32x4*)(a.packed + a.L.w[l1]), lane, A, T, w, bf,
                                                  st + (l1 - 1) * act_stride, stl, mkd + (l1 - 1) * mask_stride, nomask, 1.f);
     TRACE(3 + 4 * blk);
-    gemm_head<NT, PF, true>((const f32x4*)(a.packed + a.L.w[l2]), a.packed + a.L.b[l2], lane, w, bf);
+    DropIn drop;
+    uint32_t kp[PF + 1];
+    if (MODE == FWD_RELU_DROP) {
+      // this wave's rows of block blk's keep-masks [nb][rows][hidden]
+      const int64_t left = a.rows - row0;
+      drop.keep = make_rsrc(a.drop_keep + ((int64_t)blk * a.rows + row0) * a.hidden,
+                            (uint32_t)((left < 32 ? left : 32) * a.hidden));
+      drop.lane = (uint32_t)((rl - row0) * a.hidden + 4 * h);
+    }
+    gemm_head<NT, PF, true, MODE == FWD_RELU_DROP>((const f32x4*)(a.packed + a.L.w[l2]), a.packed + a.L.b[l2], lane, w, bf,
+                                                   &drop, kp);
     if (!FAST) apply_act<NT, false>(T, a.act);
     TRACE(4 + 4 * blk);
     if (!FAST && a.drop_keep) {
@@ -485,8 +518,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
           T[t][r] *= kf;
         }
     }
-    gemm_hh<NT, PF, false, true, SAVE, SAVE, INR>((const f32x4*)(a.packed + a.L.w[l2]), lane, T, A, w, bf,
-                                                  st + l1 * act_stride, stl, mkd + l1 * mask_stride, nomask, 1.f);
+    gemm_hh<NT, PF, false, true, SAVE, SAVE, MODE == FWD_RELU_DROP ? IN_RELU_DROP : INR>(
+        (const f32x4*)(a.packed + a.L.w[l2]), lane, T, A, w, bf, st + l1 * act_stride, stl, mkd + l1 * mask_stride, nomask,
+        a.drop_scale, &drop, kp);
     TRACE(5 + 4 * blk);
     if (blk + 1 < a.nb)
       gemm_head<NT, PF, true>((const f32x4*)(a.packed + a.L.w[l2 + 1]), a.packed + a.L.b[l2 + 1], lane, w, bf);
@@ -710,10 +744,11 @@ struct WgradArgs {
 };
 
 // One block of TN x TK tiles over rows [r_begin, r_end).  Compile-time tile counts keep the loop free of
-// branches; loads are unconditional with the row clamped into the slice, so no exec-masked region (and
-// no vmcnt(0)) separates a load from its use.  A ring of 4 reduction steps (2 rows each) is kept in
-// flight: a slot is refilled with the step 4 ahead right after its MFMAs issue (one wave per SIMD, so
-// latency has to be covered by the wave's own MFMAs: 3 steps = 48 MFMAs at 4x4 tiles).
+// branches.  Operands come through buffer loads whose resource covers exactly this row slice: the row offset is
+// a scalar that advances by two rows per step, the per-lane offset never changes, and a row past the end of the
+// slice reads as zero (adds nothing), so the loop needs neither vector address arithmetic nor a tail case.  A
+// ring of reduction steps (2 rows each) is kept in flight: a slot is refilled with the step RING ahead right
+// after its MFMAs issue (one wave per SIMD, so latency has to be covered by the wave's own MFMAs).
 template <int TN, int TK>
 __device__ __forceinline__ void wgrad_block(const WgradLayer& Ly, int nb0, int kb0, int64_t r_begin, int64_t r_end,
                                             float* __restrict__ slab, int lane) {
@@ -729,20 +764,10 @@ __device__ __forceinline__ void wgrad_block(const WgradLayer& Ly, int nb0, int k
 #pragma unroll
   for (int i = 0; i < TN; ++i) bsum[i] = 0.f;
 
-  const float* Yp = Ly.dY + 32 * nb0 + j;
-  const float* Xp = Ly.X + 32 * kb0 + j;
-  const int64_t r_last = r_end - 1;
+  const uint32_t ybytes = (uint32_t)Ly.ldy * 4u, xbytes = (uint32_t)Ly.ldx * 4u;   // row pitches
+  const uint32_t yl = (uint32_t)h * ybytes + 4u * j, xl = (uint32_t)h * xbytes + 4u * j;
   // small blocks issue few MFMAs per step, so they keep more steps in flight to cover the same latency
   constexpr int RING = (TN * TK >= 12) ? 4 : 8;
-  float ya[RING][TN], xb[RING][TK];
-  auto load_step = [&](int64_t rr0, float (&yy)[TN], float (&xx)[TK]) {
-    const int64_t rr = rr0 + h;
-    const int64_t rc = rr < r_end ? rr : r_last;
-#pragma unroll
-    for (int i = 0; i < TN; ++i) yy[i] = Yp[rc * Ly.ldy + 32 * i];
-#pragma unroll
-    for (int k = 0; k < TK; ++k) xx[k] = Xp[rc * Ly.ldx + 32 * k];
-  };
   auto fma_step = [&](const float (&yy)[TN], const float (&xx)[TK]) {
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
@@ -751,39 +776,37 @@ __device__ __forceinline__ void wgrad_block(const WgradLayer& Ly, int nb0, int k
       for (int k = 0; k < TK; ++k) acc[i][k] = MFMA(yy[i], xx[k], acc[i][k]);
     }
   };
-  const int64_t n_rows = r_end - r_begin;
-  const int64_t n_steps = n_rows >> 1;       // steps with both rows inside the slice
-  const int64_t n_groups = n_steps / RING;
+  // buffer offsets are 32-bit: a slice longer than 1 GiB of either operand is walked in chunks (even row counts)
+  const int64_t chunk_rows = ((int64_t)(1u << 30) / (ybytes > xbytes ? ybytes : xbytes)) & ~(int64_t)1;
+  for (int64_t c0 = r_begin; c0 < r_end; c0 += chunk_rows) {
+    const int64_t n_rows = (r_end - c0 < chunk_rows) ? r_end - c0 : chunk_rows;
+    const __amdgpu_buffer_rsrc_t Yr = make_rsrc(Ly.dY + c0 * Ly.ldy + 32 * nb0, (uint32_t)n_rows * ybytes - 128u * nb0);
+    const __amdgpu_buffer_rsrc_t Xr = make_rsrc(Ly.X + c0 * Ly.ldx + 32 * kb0, (uint32_t)n_rows * xbytes - 128u * kb0);
+    float ya[RING][TN], xb[RING][TK];
+    auto load_step = [&](uint32_t step, float (&yy)[TN], float (&xx)[TK]) {
+      const uint32_t yo = 2u * step * ybytes, xo = 2u * step * xbytes;   // scalar
 #pragma unroll
-  for (int u = 0; u < RING; ++u) load_step(r_begin + 2 * u, ya[u], xb[u]);
-  int64_t r = r_begin;
-  for (int64_t g = 0; g < n_groups; ++g, r += 2 * RING) {
+      for (int i = 0; i < TN; ++i)
+        yy[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(Yr, yl + 128u * i, yo, 0));
 #pragma unroll
-    for (int u = 0; u < RING; ++u) {
-      fma_step(ya[u], xb[u]);
-      load_step(r + 2 * RING + 2 * u, ya[u], xb[u]);
-      // pin the program order: without it the scheduler sinks every refill to the end of the iteration
-      // and the first slot of the next iteration is waited for right after it was issued
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  // remainder: the ring already holds the next RING steps (rows clamped)
-  const int rem = (int)(n_steps % RING);
+      for (int k = 0; k < TK; ++k)
+        xx[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(Xr, xl + 128u * k, xo, 0));
+    };
+    const uint32_t n_steps = (uint32_t)((n_rows + 1) >> 1);
+    const uint32_t n_groups = (n_steps + RING - 1) / RING;   // whole groups: steps past the slice read zeros
 #pragma unroll
-  for (int u = 0; u < RING - 1; ++u)
-    if (u < rem) fma_step(ya[u], xb[u]);
-  if (n_rows & 1) {
-    // a last single row: only the h = 0 half is inside the slice
-    float yy[TN], xx[TK];
+    for (int u = 0; u < RING; ++u) load_step(u, ya[u], xb[u]);
+    uint32_t step = 0;
+    for (uint32_t g = 0; g < n_groups; ++g, step += RING) {
 #pragma unroll
-    for (int u = 0; u < RING; ++u)
-      if (u == rem) {
-#pragma unroll
-        for (int i = 0; i < TN; ++i) yy[i] = h == 0 ? ya[u][i] : 0.f;
-#pragma unroll
-        for (int k = 0; k < TK; ++k) xx[k] = h == 0 ? xb[u][k] : 0.f;
+      for (int u = 0; u < RING; ++u) {
+        fma_step(ya[u], xb[u]);
+        load_step(step + RING + u, ya[u], xb[u]);
+        // pin the program order: without it the scheduler sinks every refill to the end of the iteration
+        // and the first slot of the next iteration is waited for right after it was issued
+        __builtin_amdgcn_sched_barrier(0);
       }
-    fma_step(yy, xx);
+    }
   }
 
   const int Kp = 32 * Ly.kt;
@@ -832,12 +855,19 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(WgradArgs a) {
   const int64_t r_begin = (int64_t)split * Ly.rows_per_split;
   const int64_t r_end = min(a.rows, r_begin + Ly.rows_per_split);
   float* slab = a.slab + (int64_t)split * Ly.slab_stride;
+  TRACE(0);
+  TRACE_REAL(13);
+#ifdef DMV_TRACE
+  if (lane == 0 && wid < 8192) dmv_trace_buf[16 * wid + 1] = l * 100 + tn * 10 + tk;
+#endif
   switch (tn) {
     case 1: wgrad_dispatch_k<1>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
     case 2: wgrad_dispatch_k<2>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
     case 3: wgrad_dispatch_k<3>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
     default: wgrad_dispatch_k<4>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
   }
+  TRACE(15);
+  TRACE_REAL(14);
 }
 
 struct ReduceArgs {
@@ -917,13 +947,19 @@ template <int NT>
 static int launch_fwd(const FwdArgs& a, hipStream_t st) {
   const int64_t waves = (a.rows + 31) / 32;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  const bool fast = a.act == DMV_ACT_RELU && !a.drop_keep;
+  // the dropout-specialised kernel reads 4 keep bytes per lane and group: rows of the masks must be dword-aligned
+  const bool relu = a.act == DMV_ACT_RELU;
+  const int mode = !relu ? FWD_GENERIC
+                         : !a.drop_keep ? FWD_RELU
+                                        : ((a.hidden & 3) == 0 && ((uintptr_t)a.drop_keep & 3) == 0) ? FWD_RELU_DROP : FWD_GENERIC;
   if (a.acts) {
-    if (fast) hipLaunchKernelGGL((k_mlp_fwd<NT, true, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_mlp_fwd<NT, true, false>), dim3(grid), dim3(256), 0, st, a);
+    if (mode == FWD_RELU) hipLaunchKernelGGL((k_mlp_fwd<NT, true, FWD_RELU>), dim3(grid), dim3(256), 0, st, a);
+    else if (mode == FWD_RELU_DROP) hipLaunchKernelGGL((k_mlp_fwd<NT, true, FWD_RELU_DROP>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_mlp_fwd<NT, true, FWD_GENERIC>), dim3(grid), dim3(256), 0, st, a);
   } else {
-    if (fast) hipLaunchKernelGGL((k_mlp_fwd<NT, false, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_mlp_fwd<NT, false, false>), dim3(grid), dim3(256), 0, st, a);
+    if (mode == FWD_RELU) hipLaunchKernelGGL((k_mlp_fwd<NT, false, FWD_RELU>), dim3(grid), dim3(256), 0, st, a);
+    else if (mode == FWD_RELU_DROP) hipLaunchKernelGGL((k_mlp_fwd<NT, false, FWD_RELU_DROP>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_mlp_fwd<NT, false, FWD_GENERIC>), dim3(grid), dim3(256), 0, st, a);
   }
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;

@@ -61,3 +61,22 @@ for save in (True, False, "bwd"):
           f"{np.median(dur) * len(t) / 1024:.1f} us), shader clock = {np.median((t[:, 15] - t[:, 0]) / dur):.0f} MHz")
     order = np.argsort(r0)
     print("  start times of waves (us after first), every 512th:", np.round((r0[order][::512] - r0.min()) / 100.0, 1))
+
+# weight-gradient kernel: wave durations by (layer, tile block shape)
+gws, gbs = [torch.empty_like(w) for w in net.weights], [torch.empty_like(b) for b in net.biases]
+for _ in range(3):
+    L.check(L.lib().dmv_mlp_backward(C.byref(net.c), L.ptr(net.packed()), L.ptr(saved0), None, L.ptr(gy), gy.shape[1], rows,
+                                     L.ptr(dx), dx.shape[1], L.ptr_array(gws), L.ptr_array(gbs), 0.0, L.ptr(ws), nbytes,
+                                     L.stream_ptr()))
+torch.cuda.synchronize()
+buf = np.zeros(16 * 8192, dtype=np.int64)
+assert raw.dmv_debug_trace(buf.ctypes.data, buf.nbytes) == 0
+t = buf.reshape(8192, 16)
+t = t[(t[:, 14] > t[:, 13]) & (t[:, 1] > 0) & (t[:, 1] < 2000)]
+r0 = t[:, 13].min()
+print(f"wgrad: {len(t)} waves, span {(t[:, 14].max() - r0) / 100.0:.1f} us")
+for key in np.unique(t[:, 1]):
+    sel = t[t[:, 1] == key]
+    d = (sel[:, 14] - sel[:, 13]) / 100.0
+    print(f"  layer {key // 100} block {key % 100 // 10}x{key % 10}: {len(sel):4d} waves, duration us p10 {np.percentile(d, 10):7.1f} "
+          f"median {np.median(d):7.1f} max {d.max():7.1f}; start max {(sel[:, 13].max() - r0) / 100.0:7.1f} end max {(sel[:, 14].max() - r0) / 100.0:7.1f}")
