@@ -747,8 +747,8 @@ struct WgradArgs {
 // branches.  Operands come through buffer loads whose resource covers exactly this row slice: the row offset is
 // a scalar that advances by two rows per step, the per-lane offset never changes, and a row past the end of the
 // slice reads as zero (adds nothing), so the loop needs neither vector address arithmetic nor a tail case.  A
-// ring of reduction steps (2 rows each) is kept in flight: a slot is refilled with the step RING ahead right
-// after its MFMAs issue (one wave per SIMD, so latency has to be covered by the wave's own MFMAs).
+// ring of reduction steps (2 rows each) is kept in flight, RING - 1 steps ahead of the MFMAs (one wave per SIMD,
+// so latency has to be covered by the wave's own MFMAs).
 template <int TN, int TK>
 __device__ __forceinline__ void wgrad_block(const WgradLayer& Ly, int nb0, int kb0, int64_t r_begin, int64_t r_end,
                                             float* __restrict__ slab, int lane) {
@@ -767,7 +767,7 @@ __device__ __forceinline__ void wgrad_block(const WgradLayer& Ly, int nb0, int k
   const uint32_t ybytes = (uint32_t)Ly.ldy * 4u, xbytes = (uint32_t)Ly.ldx * 4u;   // row pitches
   const uint32_t yl = (uint32_t)h * ybytes + 4u * j, xl = (uint32_t)h * xbytes + 4u * j;
   // small blocks issue few MFMAs per step, so they keep more steps in flight to cover the same latency
-  constexpr int RING = (TN * TK >= 12) ? 4 : 8;
+  constexpr int RING = (TN * TK >= 12) ? 6 : 10;
   auto fma_step = [&](const float (&yy)[TN], const float (&xx)[TK]) {
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
@@ -794,17 +794,21 @@ __device__ __forceinline__ void wgrad_block(const WgradLayer& Ly, int nb0, int k
     };
     const uint32_t n_steps = (uint32_t)((n_rows + 1) >> 1);
     const uint32_t n_groups = (n_steps + RING - 1) / RING;   // whole groups: steps past the slice read zeros
+    // steps 0 .. RING-2 are requested up front; inside the loop the request for step s + RING - 1 is issued right
+    // before the MFMAs of step s (into the slot step s - 1 has just released)
 #pragma unroll
-    for (int u = 0; u < RING; ++u) load_step(u, ya[u], xb[u]);
+    for (int u = 0; u < RING - 1; ++u) {
+      load_step(u, ya[u], xb[u]);
+      __builtin_amdgcn_sched_barrier(0);   // in step order: the wait counters at the loop head assume it
+    }
     uint32_t step = 0;
     for (uint32_t g = 0; g < n_groups; ++g, step += RING) {
 #pragma unroll
       for (int u = 0; u < RING; ++u) {
-        fma_step(ya[u], xb[u]);
-        load_step(step + RING + u, ya[u], xb[u]);
-        // pin the program order: without it the scheduler sinks every refill to the end of the iteration
-        // and the first slot of the next iteration is waited for right after it was issued
+        load_step(step + u + RING - 1, ya[(u + RING - 1) % RING], xb[(u + RING - 1) % RING]);
+        // pin the program order (requests ahead of the MFMAs they hide under)
         __builtin_amdgcn_sched_barrier(0);
+        fma_step(ya[u], xb[u]);
       }
     }
   }
