@@ -95,6 +95,14 @@ __device__ __forceinline__ float dmv_act_grad(float y, int act) {
   }
 }
 
+// Transcendentals of the HBM-bound row kernels go through the hardware exp2 / log2 units (about 1 ulp; the
+// argument scaling adds |x| * 6e-8 relative): a libm-grade expf + log1pf pair per element made those kernels
+// ALU-bound.  log1p keeps its accuracy for small arguments through the series.
+__device__ __forceinline__ float dmv_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float dmv_log(float x) { return __logf(x); }
+__device__ __forceinline__ float dmv_log1p_pos(float t) {   // t >= 0
+  return t < 0x1p-10f ? t * (1.f - t * (0.5f - t * (1.f / 3.f))) : __logf(1.f + t);
+}
 // torch.nn.functional.softplus, beta = 1, threshold = 20
-__device__ __forceinline__ float dmv_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
-__device__ __forceinline__ float dmv_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float dmv_softplus(float x) { return x > 20.f ? x : dmv_log1p_pos(dmv_exp(x)); }
+__device__ __forceinline__ float dmv_sigmoid(float x) { return __frcp_rn(1.f + dmv_exp(-x)); }

@@ -26,6 +26,22 @@ __global__ void k_rows_scatter(float* __restrict__ dst, const int64_t* __restric
   }
 }
 
+// 16-byte variants (D % 4 == 0, aligned bases): blockIdx.y walks the rows, threads walk a row's float4 columns,
+// so no per-element division and every access is a full-width coalesced vector
+template <bool GATHER>
+__global__ void k_rows_move4(float* __restrict__ compact, const int64_t* __restrict__ idx, int64_t n, int D4,
+                             float* __restrict__ table) {
+  for (int64_t r = blockIdx.y; r < n; r += gridDim.y) {
+    const int64_t t = idx[r];
+    f32x4* c = (f32x4*)compact + r * D4;
+    f32x4* g = (f32x4*)table + t * D4;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < D4; q += gridDim.x * blockDim.x) {
+      if (GATHER) c[q] = g[q];
+      else g[q] = c[q];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // sampling tail (vgiwae/shared/vae_imputation.py:38-52 pseudo-Gibbs; :526-561, :657-666 LAIR)
 // ------------------------------------------------------------------------------------------
@@ -56,39 +72,74 @@ __device__ __forceinline__ float clamp_like_torch(float v, const float* lo, cons
   return v;
 }
 
+__device__ __forceinline__ float tail_element(const TailArgs& a, const float* dec, int d, float noise, float xo, bool obs) {
+  float xm;
+  if (a.gen_dist <= DMV_GEN_NORMAL_EPS) {
+    const float s = dmv_softplus(dec[a.D + d]) + (a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f);
+    xm = dec[d] + noise * s;
+  } else {
+    const float b = noise < dmv_sigmoid(dec[d]) ? 1.f : 0.f;
+    xm = a.gen_dist == DMV_GEN_BERN ? b : 2.f * b - 1.f;
+  }
+  float out;
+  if (!a.clip_after_blend) {
+    xm = clamp_like_torch(xm, a.clip_min, a.clip_max, d);
+    if (!isfinite(xm)) xm = xo;
+    out = obs ? xo : xm;
+  } else {
+    out = obs ? xo : xm;
+    if (a.clip_min || a.clip_max) {
+      out = clamp_like_torch(out, a.clip_min, a.clip_max, d);
+      if (!isfinite(out)) out = xo;
+    }
+  }
+  return out;
+}
+
 __global__ void k_impute_tail(TailArgs a) {
   const int64_t total = a.N * a.D;
+  const bool normal = a.gen_dist <= DMV_GEN_NORMAL_EPS;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i / a.D;
     const int d = (int)(i - n * a.D);
     const int64_t r = a.row_map ? a.row_map[n] : n;
     const float* dec = a.dec + r * a.ld_dec;
-    const float xo = a.X_old[i];
-    const bool obs = a.M[i] != 0;
-    float xm;
-    if (a.gen_dist <= DMV_GEN_NORMAL_EPS) {
-      const float e = a.noise ? a.noise[i] : dmv_philox_normal(a.seed, a.offset + (uint64_t)i);
-      const float s = dmv_softplus(dec[a.D + d]) + (a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f);
-      xm = dec[d] + e * s;
-    } else {
-      const float u = a.noise ? a.noise[i] : dmv_philox_uniform(a.seed, a.offset + (uint64_t)i);
-      const float b = u < dmv_sigmoid(dec[d]) ? 1.f : 0.f;
-      xm = a.gen_dist == DMV_GEN_BERN ? b : 2.f * b - 1.f;
-    }
-    float out;
-    if (!a.clip_after_blend) {
-      xm = clamp_like_torch(xm, a.clip_min, a.clip_max, d);
-      if (!isfinite(xm)) xm = xo;
-      out = obs ? xo : xm;
-    } else {
-      out = obs ? xo : xm;
-      if (a.clip_min || a.clip_max) {
-        out = clamp_like_torch(out, a.clip_min, a.clip_max, d);
-        if (!isfinite(out)) out = xo;
-      }
-    }
+    const float noise = a.noise ? a.noise[i]
+                                : normal ? dmv_philox_normal(a.seed, a.offset + (uint64_t)i)
+                                         : dmv_philox_uniform(a.seed, a.offset + (uint64_t)i);
+    const float out = tail_element(a, dec, d, noise, a.X_old[i], a.M[i] != 0);
     a.X_out[i] = out;
     if (a.buf) a.buf[a.idx_imp[n] * a.D + d] = out;
+  }
+}
+
+// Four consecutive columns per thread (D % 4 == 0, 16-byte aligned rows, offset % 4 == 0): one Philox call, one
+// 16-byte access per array; blockIdx.y walks the rows.  Same values as the scalar kernel.
+__global__ void k_impute_tail4(TailArgs a) {
+  const bool normal = a.gen_dist <= DMV_GEN_NORMAL_EPS;
+  const int D4 = a.D >> 2;
+  for (int64_t n = blockIdx.y; n < a.N; n += gridDim.y) {
+    const int64_t r = a.row_map ? a.row_map[n] : n;
+    const float* dec = a.dec + r * a.ld_dec;
+    float* brow = a.buf ? a.buf + a.idx_imp[n] * a.D : nullptr;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < D4; q += gridDim.x * blockDim.x) {
+      const int64_t i = n * a.D + 4 * q;
+      const f32x4 xo = *(const f32x4*)(a.X_old + i);
+      const uint32_t m4 = *(const uint32_t*)(a.M + i);
+      dmv_f4 nz;
+      if (a.noise) {
+        const f32x4 t = *(const f32x4*)(a.noise + i);
+        nz = dmv_f4{{t[0], t[1], t[2], t[3]}};
+      } else {
+        const uint64_t c = (a.offset + (uint64_t)i) >> 2;
+        nz = normal ? dmv_philox_normal4(a.seed, c) : dmv_philox_uniform4(a.seed, c);
+      }
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = tail_element(a, dec, 4 * q + e, nz.v[e], xo[e], ((m4 >> (8 * e)) & 0xffu) != 0);
+      *(f32x4*)(a.X_out + i) = o;
+      if (brow) *(f32x4*)(brow + 4 * q) = o;
+    }
   }
 }
 
@@ -135,6 +186,13 @@ __global__ void k_dropout_masks(uint8_t* __restrict__ keep, int64_t n, float p, 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     keep[i] = dmv_philox_uniform(seed, offset + (uint64_t)i) >= p ? 1 : 0;
 }
+// four masks per thread and Philox call (n % 4 == 0, offset % 4 == 0, 4-byte aligned base); same values
+__global__ void k_dropout_masks4(uint32_t* __restrict__ keep4, int64_t n4, float p, uint64_t seed, uint64_t offset) {
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+    const dmv_f4 u = dmv_philox_uniform4(seed, (offset >> 2) + (uint64_t)q);
+    keep4[q] = (u.v[0] >= p ? 1u : 0u) | (u.v[1] >= p ? 0x100u : 0u) | (u.v[2] >= p ? 0x10000u : 0u) | (u.v[3] >= p ? 0x1000000u : 0u);
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 static inline unsigned grid_for(int64_t work, int block, unsigned cap = 8192) {
@@ -146,7 +204,13 @@ static inline unsigned grid_for(int64_t work, int block, unsigned cap = 8192) {
 extern "C" int dmv_rows_gather(const float* src, const int64_t* idx, int64_t n, int32_t D, float* dst, void* stream) {
   if (!src || !idx || !dst || n < 0 || D < 1) return DMV_E_BADARG;
   if (n == 0) return DMV_OK;
-  hipLaunchKernelGGL(k_rows_gather, dim3(grid_for(n * D, 256)), dim3(256), 0, (hipStream_t)stream, src, idx, n, (int)D, dst);
+  if ((D & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const int D4 = D / 4, bx = D4 > 64 ? 256 : (D4 > 32 ? 64 : 32);   // threads per row
+    dim3 grid((unsigned)((D4 + bx - 1) / bx), (unsigned)(n > 65535 ? 65535 : n));
+    hipLaunchKernelGGL(k_rows_move4<true>, grid, dim3(bx), 0, (hipStream_t)stream, dst, idx, n, D4, const_cast<float*>(src));
+  } else {
+    hipLaunchKernelGGL(k_rows_gather, dim3(grid_for(n * D, 256)), dim3(256), 0, (hipStream_t)stream, src, idx, n, (int)D, dst);
+  }
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
@@ -154,7 +218,13 @@ extern "C" int dmv_rows_gather(const float* src, const int64_t* idx, int64_t n, 
 extern "C" int dmv_rows_scatter(float* dst, const int64_t* idx, int64_t n, int32_t D, const float* src, void* stream) {
   if (!src || !idx || !dst || n < 0 || D < 1) return DMV_E_BADARG;
   if (n == 0) return DMV_OK;
-  hipLaunchKernelGGL(k_rows_scatter, dim3(grid_for(n * D, 256)), dim3(256), 0, (hipStream_t)stream, dst, idx, n, (int)D, src);
+  if ((D & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const int D4 = D / 4, bx = D4 > 64 ? 256 : (D4 > 32 ? 64 : 32);
+    dim3 grid((unsigned)((D4 + bx - 1) / bx), (unsigned)(n > 65535 ? 65535 : n));
+    hipLaunchKernelGGL(k_rows_move4<false>, grid, dim3(bx), 0, (hipStream_t)stream, const_cast<float*>(src), idx, n, D4, dst);
+  } else {
+    hipLaunchKernelGGL(k_rows_scatter, dim3(grid_for(n * D, 256)), dim3(256), 0, (hipStream_t)stream, dst, idx, n, (int)D, src);
+  }
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
@@ -174,7 +244,14 @@ extern "C" int dmv_impute_tail(int64_t N, int32_t D, int32_t gen_dist, const flo
   a.X_old = X_old; a.M = M; a.noise = noise; a.seed = seed; a.offset = offset;
   a.clip_min = clip_min; a.clip_max = clip_max; a.clip_after_blend = clip_after_blend;
   a.X_out = X_out; a.buf = buf; a.idx_imp = idx_imp;
-  hipLaunchKernelGGL(k_impute_tail, dim3(grid_for(N * D, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  const uintptr_t al = (uintptr_t)dec | (uintptr_t)X_old | (uintptr_t)X_out | (uintptr_t)noise | (uintptr_t)buf;
+  if (D >= 64 && (D & 3) == 0 && (ld_dec & 3) == 0 && (al & 15) == 0 && ((uintptr_t)M & 3) == 0 && (offset & 3) == 0) {
+    const int D4 = D / 4, bx = D4 > 64 ? 256 : 64;
+    dim3 grid((unsigned)((D4 + bx - 1) / bx), (unsigned)(N > 65535 ? 65535 : N));
+    hipLaunchKernelGGL(k_impute_tail4, grid, dim3(bx), 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(k_impute_tail, dim3(grid_for(N * D, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  }
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
@@ -192,7 +269,11 @@ extern "C" int dmv_categorical_draw(int32_t B, int32_t P, int32_t K, const float
 extern "C" int dmv_dropout_masks(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
   if (!keep || n < 0 || !(p >= 0.f && p < 1.f)) return DMV_E_BADARG;
   if (n == 0) return DMV_OK;
-  hipLaunchKernelGGL(k_dropout_masks, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, keep, n, p, seed, offset);
+  if ((n & 3) == 0 && (offset & 3) == 0 && ((uintptr_t)keep & 3) == 0)
+    hipLaunchKernelGGL(k_dropout_masks4, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t*)keep, n / 4, p,
+                       seed, offset);
+  else
+    hipLaunchKernelGGL(k_dropout_masks, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, keep, n, p, seed, offset);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }

@@ -21,11 +21,11 @@ __device__ __forceinline__ float q_sigma(const float* enc, const QAddr& q, int64
 }
 __device__ __forceinline__ float log_normal(float x, float mu, float sigma) {
   const float d = x - mu;
-  return -(d * d) / (2.f * sigma * sigma) - logf(sigma) - LOG_SQRT_2PI;
+  return -(d * d) / (2.f * sigma * sigma) - dmv_log(sigma) - LOG_SQRT_2PI;
 }
 // -BCEWithLogits(l, v) = -((1 - v) l - logsigmoid(l)),  logsigmoid(l) = min(l, 0) - log1p(exp(-|l|))
 __device__ __forceinline__ float log_bern(float v, float l) {
-  const float ls = fminf(l, 0.f) - log1pf(expf(-fabsf(l)));
+  const float ls = fminf(l, 0.f) - dmv_log1p_pos(dmv_exp(-fabsf(l)));
   return -((1.f - v) * l - ls);
 }
 
@@ -93,6 +93,7 @@ struct TermsArgs {
   const float* enc;
   float* terms;     // [5][N]
   float* comp_lp;   // nullable [N][mix_C]: log N(z_n; mu_{b,c}, sigma_{b,c}) summed over j
+  int vec4;         // Bernoulli decoder with D % 4 == 0 and 16-byte aligned rows
 };
 
 template <int R>
@@ -109,6 +110,20 @@ __global__ void k_obj_terms(TermsArgs a) {
   const uint8_t* M = a.M + xrow * a.D;
 
   float gm = 0.f, gf = 0.f;
+  if (a.vec4) {
+    // wide rows (Bernoulli images): 16 bytes of logits / data and 4 mask bytes per lane and iteration
+    for (int q = r; q < (a.D >> 2); q += R) {
+      const f32x4 l4 = *(const f32x4*)(dec + 4 * q);
+      const f32x4 x4 = *(const f32x4*)(X + 4 * q);
+      const uint32_t m4 = *(const uint32_t*)(M + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lp = log_bern(a.gen_dist == DMV_GEN_BERN ? x4[e] : (x4[e] + 1.f) * 0.5f, l4[e]);
+        gf += lp;
+        gm += ((m4 >> (8 * e)) & 0xffu) ? lp : 0.f;
+      }
+    }
+  } else
   for (int d = r; d < a.D; d += R) {
     float lp;
     const float x = X[d];
@@ -389,6 +404,38 @@ __global__ void k_obj_bwd_dec(BwdDecArgs a) {
   }
 }
 
+// Bernoulli decoders with wide, aligned rows (D % 4 == 0, ld_ddec == ld_dec rows of whole float4): blockIdx.y
+// walks the rows, threads walk a row's float4 columns -- no per-element division, 16-byte accesses
+__global__ void k_obj_bwd_dec_bern4(BwdDecArgs a) {
+  const float gs = a.gscale ? a.gscale[0] : 1.f;
+  const int D4 = a.D >> 2, W4 = (int)(a.ld_ddec >> 2);
+  for (int64_t n = blockIdx.y; n < a.N; n += gridDim.y) {
+    const int g = (int)(n % a.G);
+    const int64_t b = (n / a.G) % a.B;
+    const int64_t xrow = a.x_per_component ? (b * a.G + g) : b;
+    const float w = gs * (a.wgt ? a.wgt[n] : 1.f);
+    const float* dec = a.dec + n * a.ld_dec;
+    const float* X = a.X + xrow * a.D;
+    const uint8_t* M = a.M + xrow * a.D;
+    f32x4* out = (f32x4*)(a.d_dec + n * a.ld_ddec);
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < W4; q += gridDim.x * blockDim.x) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (q < D4) {
+        const f32x4 l4 = *(const f32x4*)(dec + 4 * q);
+        const f32x4 x4 = *(const f32x4*)(X + 4 * q);
+        const uint32_t m4 = *(const uint32_t*)(M + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = a.gen_dist == DMV_GEN_BERN ? x4[e] : (x4[e] + 1.f) * 0.5f;
+          const float coef = w * ((((m4 >> (8 * e)) & 0xffu) ? a.base_m : 0.f) + a.base_f);
+          o[e] = coef * (v - dmv_sigmoid(l4[e]));
+        }
+      }
+      out[q] = o;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // backward, latent side: gradient w.r.t. the encoder output (mu, raw sigma, mixture logits)
 // one thread per (b, g', j) plus one per (b, g') logit
@@ -621,6 +668,8 @@ extern "C" int dmv_obj_terms(const DmvObjCfg* cfg, int32_t q_kind, int32_t mix_C
   a.q_kind = q_kind; a.mix_C = mix_C; a.q = qaddr(cfg);
   a.dec = dec; a.ld_dec = ld_dec; a.X = X; a.M = M; a.Z = Z; a.ldz = ldz; a.enc = enc;
   a.terms = terms; a.comp_lp = comp_lp;
+  a.vec4 = cfg->gen_dist >= DMV_GEN_BERN && (cfg->D & 3) == 0 && (ld_dec & 3) == 0 &&
+           ((((uintptr_t)dec | (uintptr_t)X) & 15) == 0) && (((uintptr_t)M & 3) == 0);
   hipStream_t st = (hipStream_t)stream;
   const int span = cfg->D > cfg->Zd ? cfg->D : cfg->Zd;
   if (span <= 8) {
@@ -701,7 +750,15 @@ extern "C" int dmv_obj_backward_dec(const DmvObjCfg* cfg, const float* dec, int6
   a.gen_dist = cfg->gen_dist; a.x_per_component = cfg->x_per_component;
   a.dec = dec; a.ld_dec = ld_dec; a.X = X; a.M = M; a.wgt = wgt; a.gscale = gscale;
   a.base_m = base_m; a.base_f = base_f; a.d_dec = d_dec; a.ld_ddec = ld_ddec;
-  hipLaunchKernelGGL(k_obj_bwd_dec, dim3(grid_for(a.N * ld_ddec, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  const bool vec4 = cfg->gen_dist >= DMV_GEN_BERN && cfg->D >= 64 && (cfg->D & 3) == 0 && (ld_dec & 3) == 0 && (ld_ddec & 3) == 0 &&
+                    ((((uintptr_t)dec | (uintptr_t)X | (uintptr_t)d_dec) & 15) == 0) && (((uintptr_t)M & 3) == 0);
+  if (vec4) {
+    const int W4 = (int)(ld_ddec / 4), bx = W4 > 64 ? 256 : 64;
+    dim3 grid((unsigned)((W4 + bx - 1) / bx), (unsigned)(a.N > 65535 ? 65535 : a.N));
+    hipLaunchKernelGGL(k_obj_bwd_dec_bern4, grid, dim3(bx), 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(k_obj_bwd_dec, dim3(grid_for(a.N * ld_ddec, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  }
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }

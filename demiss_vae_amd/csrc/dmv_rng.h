@@ -1,7 +1,8 @@
 // Counter-based RNG for the device samplers: Philox4x32-10 (Salmon et al., SC'11) keyed by the 64-bit
-// seed, counter = the 64-bit element index; one call yields four 32-bit words.  Normals by Box-Muller.
-// Every element of a launch draws from its own counter, so results do not depend on the launch
-// geometry and a backward pass can regenerate the same noise.
+// seed.  One call yields four 32-bit words = the draws of four consecutive elements: element idx uses
+// counter idx >> 2 (normals: Box-Muller on word pairs, cos for even idx, sin for odd).  The value of an
+// element depends only on (seed, idx), not on the launch geometry or on whether a kernel asks for one
+// element or for an aligned group of four, so a backward pass can regenerate the same noise.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,15 +29,25 @@ __host__ __device__ inline dmv_u4 dmv_philox4x32_10(uint64_t seed, uint64_t ctr_
 // uniform in (0, 1]: never 0, so log() is finite
 __host__ __device__ inline float dmv_u01(uint32_t w) { return ((float)(w >> 8) + 1.0f) * (1.0f / 16777216.0f); }
 
-// standard normal for element `idx` of stream `seed` (one Philox call per element; two words used)
+struct dmv_f4 { float v[4]; };
+
+// standard normals for elements 4 q .. 4 q + 3 of stream `seed`
+__device__ inline dmv_f4 dmv_philox_normal4(uint64_t seed, uint64_t q) {
+  const dmv_u4 r = dmv_philox4x32_10(seed, q, 0x6e6f726dull /* "norm" */);
+  const float r0 = sqrtf(-2.f * __logf(dmv_u01(r.x))), r1 = sqrtf(-2.f * __logf(dmv_u01(r.z)));
+  const float a0 = 2.f * dmv_u01(r.y), a1 = 2.f * dmv_u01(r.w);
+  return dmv_f4{{r0 * cospif(a0), r0 * sinpif(a0), r1 * cospif(a1), r1 * sinpif(a1)}};
+}
 __device__ inline float dmv_philox_normal(uint64_t seed, uint64_t idx) {
-  const dmv_u4 r = dmv_philox4x32_10(seed, idx, 0x6e6f726dull /* "norm" */);
-  const float u1 = dmv_u01(r.x), u2 = dmv_u01(r.y);
-  return sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
+  return dmv_philox_normal4(seed, idx >> 2).v[idx & 3];
 }
 
-// uniform in [0, 1) for element `idx`
+// uniforms in [0, 1) for elements 4 q .. 4 q + 3
+__device__ inline dmv_f4 dmv_philox_uniform4(uint64_t seed, uint64_t q) {
+  const dmv_u4 r = dmv_philox4x32_10(seed, q, 0x756e6966ull /* "unif" */);
+  const float k = 1.0f / 16777216.0f;
+  return dmv_f4{{(float)(r.x >> 8) * k, (float)(r.y >> 8) * k, (float)(r.z >> 8) * k, (float)(r.w >> 8) * k}};
+}
 __device__ inline float dmv_philox_uniform(uint64_t seed, uint64_t idx) {
-  const dmv_u4 r = dmv_philox4x32_10(seed, idx, 0x756e6966ull /* "unif" */);
-  return (float)(r.x >> 8) * (1.0f / 16777216.0f);
+  return dmv_philox_uniform4(seed, idx >> 2).v[idx & 3];
 }

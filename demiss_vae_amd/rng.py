@@ -30,5 +30,5 @@ def next_offset(n: int):
     if _seed is None:
         set_seed(torch.initial_seed())
     off = _offset
-    _offset += int(n)
+    _offset += (int(n) + 3) & ~3     # ranges start on a multiple of 4: one generator call serves 4 elements
     return _seed, off
