@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32768, help="datapoints per GPU per step")
+    ap.add_argument("--with-conv", action="store_true",
+                    help="also time the image DeMissVAE step with convolutional trunks (MIOpen warm-up takes a while)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--kernels-only", action="store_true",
@@ -287,6 +289,9 @@ def main():
             extra["miniboone_missiwae"] = missiwae_step(device, "UCI-miniboone", 8192, 43, 32, (86, 325, 5, 256),
                                                         (32, 86, 2, 256), dropout=0.5)
             extra["loglik_eval_K50000"] = ll
+            if args.with_conv:
+                from demiss_vae_amd.bench_extra import mnist_demiss_step
+                extra["mnist_demiss_mvb2"] = mnist_demiss_step(device)
             out["extra"] = extra
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()

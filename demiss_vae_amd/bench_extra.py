@@ -111,3 +111,54 @@ def loglik_eval_rate(device, B=50, K=50000, batches=4):
     t = _sync_time(run, 2, 1)
     return {"workload": f"refit test_step, gas shapes, B={B} x K={K} per batch", "ms_per_batch": round(t / batches * 1e3, 3),
             "samples_per_s": round(batches * B * K / t, 1)}
+
+
+def mnist_demiss_step(device, B=200, K=5):
+    """DeMissVAE on binarised 28x28 images (configs/mnist_bin/compare/q50/mvb2vae_noencm_pg_k5_stl.yaml: full-size
+    convolutional trunks as torch modules, Bernoulli{-1,+1} decoder, mvb2 + STL, one pseudo-Gibbs sweep per step with
+    write-back into the device-resident imputation buffer, two backward calls, clip, Adam).  Synthetic images."""
+    from vgiwae.models import MVBVAE, MVB_OBJECTIVE
+    from vgiwae.shared.vae_enums import DISTRIBUTION
+    from vgiwae.shared.vae_resnet import ResNetDecoder, ResNetEncoder
+    torch.manual_seed(20220118)
+    dec = ResNetDecoder(output_shape=[1, 28, 28], layers=[2, 2, 2, 2], layer_widths=[128, 64, 32, 32],
+                        layer_upscale=[7, None, None, None], upscale_factor=7, downscaled_resolution=[4, 4], latent_dim=50,
+                        dropout_prob=0.3)
+    enc = ResNetEncoder(input_shape=[1, 28, 28], layers=[2, 2, 2, 2], layer_widths=[32, 64, 128, 256], latent_dim=100,
+                        dropout_prob=0.3)
+    model = MVBVAE(generator_network=dec, generator_distribution=DISTRIBUTION.bern_m1_p1, var_latent_network=enc,
+                   var_latent_distribution=DISTRIBUTION.normal_with_eps, num_latent_samples=1, lr_generator=1e-4, lr_latent=1e-4,
+                   amsgrad_generator=True, amsgrad_latent=True, var_latent_STL=True, kl_analytic=False,
+                   mvb_objective=MVB_OBJECTIVE["mvb2"]).to(device).train()
+    N, D = 4000, 784
+    g = torch.Generator().manual_seed(1)
+    X = (torch.rand(N, D, generator=g) < 0.13).float() * 2 - 1
+    M = torch.ones(N, 28, 28, dtype=torch.bool)
+    quad = torch.randint(0, 4, (N, 2), generator=g)                 # two (possibly equal) quadrants missing per image
+    for q in range(4):
+        r, c = (q // 2) * 14, (q % 2) * 14
+        sel = (quad == q).any(1)
+        M[sel, r:r + 14, c:c + 14] = False
+    M = M.reshape(N, D).to(device)
+    buf = imp.ImputationBuffer(X, K, device)
+    params = list(dec.parameters()) + list(enc.parameters())
+    opt = torch.optim.Adam(params, lr=1e-4, amsgrad=True)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(0)
+    dims = model.model_dims()
+
+    def step():
+        index = torch.randint(0, N, (B,), device=device, generator=gen)
+        Xt, idx = buf.gather(index)
+        Mk = M[index].unsqueeze(1).expand(B, K, D).contiguous()
+        Xt = imp.pseudo_gibbs(dims, model.predict_var_latent_params, dec, Xt, Mk, num_iterations=1, buf=buf, idx_imp=idx)
+        gen_obj, enc_obj = model.estimate_mvb2_objectives(Xt, Mk)
+        opt.zero_grad(set_to_none=True)
+        (-gen_obj.mean()).backward(retain_graph=True, inputs=list(dec.parameters()))
+        (-enc_obj.mean()).backward(inputs=list(enc.parameters()))
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+
+    t = _sync_time(step, 10, 3)
+    return {"workload": f"mnist_bin DeMissVAE mvb2 step (conv trunks in torch/MIOpen), B={B}, K={K}", "ms_per_step": round(t * 1e3, 3),
+            "samples_per_s": round(B * K / t, 1)}

@@ -95,7 +95,9 @@ class ImputationBuffer:
 
 
 # ------------------------------------------------------------------------------------------ shared pieces
-def _encode_rows(dims: ModelDims, enc: PackedNet, X2, M2, enc_keep):
+def _encode_rows(dims: ModelDims, enc, X2, M2, enc_keep):
+    if not isinstance(enc, PackedNet):      # caller-supplied torch module (convolutional trunks)
+        return enc(X2, M2.bool()).reshape(X2.shape[0], -1).contiguous().float()
     in_mode = L.IN_CONCAT if dims.encoder_use_mis_mask else L.IN_PLAIN
     y, _ = mlp_forward(enc, X2, dims.D, X2.shape[0], in_mode=in_mode, D=dims.D, m=M2, ldm=dims.D, save=False,
                        drop_keep=enc_keep)
@@ -126,8 +128,8 @@ def _tail(dims, dec_out, row_map, X_old, M, noise, clip_min, clip_max, clip_afte
     return X_out
 
 
-def _keep(net: PackedNet, rows, training, device):
-    if not training or net.dims.dropout <= 0:
+def _keep(net, rows, training, device):
+    if not isinstance(net, PackedNet) or not training or net.dims.dropout <= 0:
         return None
     n = net.dims.nb * rows * net.dims.hidden
     keep = torch.empty(n, dtype=torch.uint8, device=device)
@@ -162,7 +164,10 @@ def pseudo_gibbs(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_i
         else:
             seed, off = rng.next_offset(N * dims.Zd)
             L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, dims.Zd, None, L.ptr(Z), None, st))
-        dec_out, _ = mlp_forward(dec, Z, dims.Zd, N, save=False, drop_keep=_keep(dec, N, training, dev))
+        if isinstance(dec, PackedNet):
+            dec_out, _ = mlp_forward(dec, Z, dims.Zd, N, save=False, drop_keep=_keep(dec, N, training, dev))
+        else:
+            dec_out = dec(Z).reshape(N, -1).contiguous().float()
         last = t == num_iterations - 1
         Xc = _tail(dims, dec_out, None, Xc, Mu, noise_x[t] if noise_x is not None else None, cmin, cmax, False,
                    buf if last else None, idx_imp.reshape(-1).contiguous() if (last and idx_imp is not None) else None)

@@ -96,6 +96,47 @@ def test_refit_test_step_matches_reference():
         assert abs(val.item() - float(g["est_loglik"])) < 0.01          # north-star: within 0.01 nats
 
 
+@pytest.mark.parametrize("tag", ["noencm", "encm"])
+def test_conv_trunk_demissvae_matches_reference(tag):
+    """DeMissVAE with convolutional trunks (the MNIST / Omniglot configs at reduced widths): the trunks are torch
+    modules with the reference's state_dict, everything around them runs in the kernels.  One pseudo-Gibbs sweep,
+    the two mvb2 objectives and the two backward calls against the reference's numbers.  Tolerances are wider than
+    for the MLP path: the convolutions run in MIOpen here and in the CPU backend in the fixture."""
+    import vgiwae.models as models
+    from vgiwae.models import MVB_OBJECTIVE
+    from vgiwae.shared.vae_enums import DISTRIBUTION
+    from vgiwae.shared.vae_imputation import VAESampler_PseudoGibbs
+    from vgiwae.shared.vae_resnet import ResNetDecoder, ResNetEncoder
+    g = gu.load(f"resnet_mvb2_{tag}")
+    B, K, D, Zd, use_mask = int(g["B"]), int(g["K"]), int(g["D"]), int(g["Zd"]), bool(g["use_mask"])
+    enc = ResNetEncoder(input_shape=[1, 28, 28], layers=[1, 1], layer_widths=[4, 8], latent_dim=2 * Zd, dropout_prob=0.0,
+                        expect_miss_mask_as_extra_chennel=use_mask)
+    dec = ResNetDecoder(output_shape=[1, 28, 28], layers=[1, 1], layer_upscale=[None, None], layer_widths=[8, 4],
+                        downscaled_resolution=[4, 4], latent_dim=Zd, upscale_factor=2, dropout_prob=0.0)
+    enc.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.keys() if k.startswith("enc.")})
+    dec.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.keys() if k.startswith("dec.")})
+    model = models.MVBVAE(generator_network=dec, generator_distribution=DISTRIBUTION.bern_m1_p1, var_latent_network=enc,
+                          var_latent_distribution=DISTRIBUTION.normal_with_eps, num_latent_samples=1, lr_generator=1e-4,
+                          lr_latent=1e-4, encoder_use_mis_mask=use_mask, var_latent_STL=True, kl_analytic=False,
+                          mvb_objective=MVB_OBJECTIVE["mvb2"]).cuda().train()
+    assert not model.fused
+    Xt, Mk = torch.from_numpy(g["Xt"]).cuda(), torch.from_numpy(g["M"]).cuda()
+    sampler = VAESampler_PseudoGibbs(num_iterations=1)
+    X_new = sampler(Xt.clone(), Mk, model=model, eps_z=torch.from_numpy(g["eps_z"])[None].cuda(),
+                    noise_x=torch.from_numpy(g["u_x"])[None].cuda())
+    ref_new = torch.from_numpy(g["X_new"]).cuda()
+    assert torch.equal(X_new[Mk], ref_new[Mk])                               # observed entries untouched, bit-exact
+    flips = (X_new != ref_new).float().mean().item()                          # a draw flips only where u ~ sigmoid(logit)
+    assert flips < 2e-3, flips
+    gen_obj, enc_obj = model.estimate_mvb2_objectives(ref_new, Mk, eps=torch.from_numpy(g["eps"]).cuda())
+    torch.testing.assert_close(gen_obj.cpu(), torch.from_numpy(g["gen_obj"]), rtol=2e-4, atol=2e-3)
+    torch.testing.assert_close(enc_obj.cpu(), torch.from_numpy(g["enc_obj"]), rtol=2e-4, atol=2e-3)
+    (-gen_obj.mean()).backward(retain_graph=True, inputs=list(dec.parameters()))
+    (-enc_obj.mean()).backward(inputs=list(enc.parameters()))
+    assert gu.check_grads(g, "genc", {k: v.grad for k, v in enc.named_parameters() if v.grad is not None}, 5e-3, 1e-5, floor=2e-3) > 5
+    assert gu.check_grads(g, "gdec", {k: v.grad for k, v in dec.named_parameters() if v.grad is not None}, 5e-3, 1e-5, floor=2e-3) > 5
+
+
 def test_short_training_run_learns():
     """A few hundred Adam steps of MissIWAE on synthetic correlated data: the bound improves markedly."""
     from oracle.recipes import NetSpec, make_params, make_mask

@@ -103,3 +103,31 @@ def test_model_classes_construct_on_cpu_and_forward_is_gpu_only():
     with pytest.raises(NotImplementedError):
         VAESampler_LAIR(1, 1, 0, "smis", "global_resampling")
     assert VAESampler_PseudoGibbs(num_iterations=1).num_iterations == 1
+
+
+def test_conv_trunks_load_reference_state_dicts():
+    """The convolutional trunks take the reference's state_dict keys and shapes unchanged (strict load), and map
+    [.., 784] <-> latent parameters with the reference's shape conventions."""
+    from vgiwae.shared.vae_resnet import ResNetDecoder, ResNetEncoder
+    for tag, use_mask in (("noencm", False), ("encm", True)):
+        g = gu.load(f"resnet_mvb2_{tag}")
+        Zd = int(g["Zd"])
+        enc = ResNetEncoder(input_shape=[1, 28, 28], layers=[1, 1], layer_widths=[4, 8], latent_dim=2 * Zd,
+                            expect_miss_mask_as_extra_chennel=use_mask)
+        dec = ResNetDecoder(output_shape=[1, 28, 28], layers=[1, 1], layer_upscale=[None, None], layer_widths=[8, 4],
+                            downscaled_resolution=[4, 4], latent_dim=Zd, upscale_factor=2)
+        enc.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("enc.")}, strict=True)
+        dec.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dec.")}, strict=True)
+        X = torch.from_numpy(g["Xt"])
+        M = torch.from_numpy(g["M"]).float()
+        with torch.no_grad():
+            p = enc(X, M) if use_mask else enc(X)
+            assert p.shape == (X.shape[0], X.shape[1], 2 * Zd)
+            assert dec(p[..., :Zd]).shape == X.shape
+    # the full-size trunks of configs/mnist_bin/compare/q50/mvb2vae_noencm_pg_k5_stl.yaml
+    dec = ResNetDecoder(output_shape=[1, 28, 28], layers=[2, 2, 2, 2], layer_widths=[128, 64, 32, 32],
+                        layer_upscale=[7, None, None, None], upscale_factor=7, downscaled_resolution=[4, 4], latent_dim=50,
+                        dropout_prob=0.3).eval()
+    with torch.no_grad():
+        assert dec(torch.zeros(2, 50)).shape == (2, 784)
+    assert "layers.0.0.upsample.0.1.weight" in dec.state_dict() and "layers.3.0.upsample.0.weight" not in dec.state_dict()

@@ -397,6 +397,56 @@ def cases_mvb(out):
          B=64, nz=1, seed=20220120, objective="mvb2", STL=True, store_inputs=False)
 
 
+def cases_resnet(out):
+    """DeMissVAE (mvb2, STL, pseudo-Gibbs x1) with small convolutional trunks on 28x28 Bernoulli{-1,+1} images: the
+    structure of configs/mnist_bin/compare/q50/mvb2vae_noencm_pg_k5_stl.yaml at reduced widths, dropout off."""
+    import vgiwae.models as models
+    from vgiwae.models.mvbvae import MVB_OBJECTIVE
+    from vgiwae.shared.vae_resnet import ResNetEncoder, ResNetDecoder
+    from vgiwae.shared.vae_imputation import VAESampler_PseudoGibbs
+    seed, B, K, D, Zd = 7000, 6, 3, 784, 6
+    for tag, use_mask in (("noencm", False), ("encm", True)):
+        torch.manual_seed(seed)
+        enc = ResNetEncoder(input_shape=[1, 28, 28], layers=[1, 1], layer_widths=[4, 8], latent_dim=2 * Zd, dropout_prob=0.0,
+                            expect_miss_mask_as_extra_chennel=use_mask)
+        dec = ResNetDecoder(output_shape=[1, 28, 28], layers=[1, 1], layer_upscale=[None, None], layer_widths=[8, 4],
+                            downscaled_resolution=[4, 4], latent_dim=Zd, upscale_factor=2, dropout_prob=0.0)
+        enc_sd = {k: v.clone() for k, v in enc.state_dict().items()}
+        dec_sd = {k: v.clone() for k, v in dec.state_dict().items()}
+        model = models.MVBVAE(generator_network=dec, generator_distribution=dist_enum("bern_m1_p1"), var_latent_network=enc,
+                              var_latent_distribution=dist_enum("normal_with_eps"), num_latent_samples=1, lr_generator=1e-4,
+                              lr_latent=1e-4, encoder_use_mis_mask=use_mask, var_latent_STL=True, kl_analytic=False,
+                              mvb_objective=MVB_OBJECTIVE["mvb2"])
+        model.train()
+        X, M = make_batch(seed + 2, B, D, binary=True)
+        fill, _ = make_batch(seed + 6, B * K, D, binary=True)
+        Mk = M[:, None, :].expand(B, K, D).contiguous()
+        Xt = torch.where(Mk, X[:, None, :].expand(B, K, D), fill.reshape(B, K, D)).contiguous()
+        # one pseudo-Gibbs sweep (no grad), then the two objectives and the two backward calls
+        eps_z, u_x = make_noise(seed + 10, B, K, Zd), make_uniform(seed + 20, B, K, D)
+        noise = Noise()
+        noise.normal, noise.uniform = [eps_z.clone()], [u_x.clone()]
+        sampler = VAESampler_PseudoGibbs(num_iterations=1)
+        with injected(noise), torch.no_grad():
+            X_new = sampler(Xt.clone(), Mk, model=model)
+        # the sweep ran the trunks in training mode: batch-norm running statistics moved; the objectives below
+        # start from those (kept in the fixture so that the order of operations can be replayed)
+        eps = make_noise(seed + 3, 1, B, K, Zd)
+        noise = Noise()
+        noise.normal = [eps.clone()]
+        with injected(noise):
+            gen_obj, enc_obj = model.estimate_mvb2_objectives(X_new, Mk)
+        (-gen_obj.mean()).backward(retain_graph=True, inputs=list(dec.parameters()))
+        (-enc_obj.mean()).backward(inputs=list(enc.parameters()))
+        arrays = dict(seed=seed, B=B, K=K, D=D, Zd=Zd, use_mask=use_mask, Xt=Xt, M=Mk, eps_z=eps_z, u_x=u_x, X_new=X_new,
+                      eps=eps, gen_obj=gen_obj, enc_obj=enc_obj)
+        arrays.update({f"enc.{k}": v.numpy() for k, v in enc_sd.items()})
+        arrays.update({f"dec.{k}": v.numpy() for k, v in dec_sd.items()})
+        arrays.update(grads_to_dict("genc", enc))
+        arrays.update(grads_to_dict("gdec", dec))
+        save(out, f"resnet_mvb2_{tag}", **arrays)
+
+
 class _Duck:
     """What the reference's samplers need from `model` is exactly these five names."""
     pass
@@ -670,6 +720,7 @@ def main():
         "loglik": lambda: cases_loglik(args.out),
         "masks": lambda: cases_masks(args.out, args.ref),
         "dmis": lambda: cases_dmis_known_answer(args.out),
+        "resnet": lambda: cases_resnet(args.out),
     }
     for name, fn in groups.items():
         if args.only and name not in args.only.split(","):

@@ -65,12 +65,14 @@ def estimate_iwelbo(model, batch, var_latent_STL: bool = False, var_latent_DREG:
     streaming = sample_stratifieddistr_without_stratification_norsample or \
         (not torch.is_grad_enabled() and num_latent_samples == 1 and num_importance_samples >= 1024)
     if streaming:
-        assert num_latent_samples == 1
+        assert num_latent_samples == 1 and m.fused, "the streaming estimator runs the packed residual MLPs"
         val, _ = estimate_loglik(dims, enc, dec, X, M, num_importance_samples=num_importance_samples, eps=eps,
                                  comp_idx=comp_idx)
         return val
-    ek, dk = m.dropout_masks(X.shape[0], num_latent_samples * num_importance_samples * X.shape[0])
-    bound, _ = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=num_latent_samples,
-                                   num_importance_samples=num_importance_samples, STL=var_latent_STL,
-                                   DREG=var_latent_DREG, eps=eps, enc_keep=ek, dec_keep=dk)
+    fn, fused = m.estimator("estimate_iwelbo")
+    kw = {}
+    if fused:
+        kw["enc_keep"], kw["dec_keep"] = m.dropout_masks(X.shape[0], num_latent_samples * num_importance_samples * X.shape[0])
+    bound, _ = fn(dims, enc, dec, X, M, num_latent_samples=num_latent_samples, num_importance_samples=num_importance_samples,
+                  STL=var_latent_STL, DREG=var_latent_DREG, eps=eps, **kw)
     return bound

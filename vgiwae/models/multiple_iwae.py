@@ -81,8 +81,10 @@ def estimate_multiple_iwelbo(model, batch, var_latent_STL: bool = False, var_lat
     m = _inner(model)
     dims, enc, dec = m.engine()
     I = num_importance_samples_for_each_component
-    ek, dk = m.dropout_masks(X.shape[0], num_latent_samples * I * X.shape[0] * dims.C)
-    bound, _ = dmv.estimate_multiple_iwelbo(dims, enc, dec, X, M, num_latent_samples=num_latent_samples,
-                                            num_importance_samples_for_each_component=I, STL=var_latent_STL,
-                                            looser=use_looser_bound, eps=eps, enc_keep=ek, dec_keep=dk)
+    fn, fused = m.estimator("estimate_multiple_iwelbo")
+    kw = {}
+    if fused:
+        kw["enc_keep"], kw["dec_keep"] = m.dropout_masks(X.shape[0], num_latent_samples * I * X.shape[0] * dims.C)
+    bound, _ = fn(dims, enc, dec, X, M, num_latent_samples=num_latent_samples, num_importance_samples_for_each_component=I,
+                  STL=var_latent_STL, looser=use_looser_bound, eps=eps, **kw)
     return bound

@@ -44,7 +44,9 @@ def estimate_multiple_elbo(model, batch, kl_analytic: bool = False, var_latent_S
     X, M = batch[:2]
     m = _inner(model)
     dims, enc, dec = m.engine()
-    ek, dk = m.dropout_masks(X.shape[0], num_latent_samples * X.shape[0] * dims.C)
-    bound, _ = dmv.estimate_multiple_elbo(dims, enc, dec, X, M, num_latent_samples=num_latent_samples,
-                                          STL=var_latent_STL, eps=eps, enc_keep=ek, dec_keep=dk)
+    fn, fused = m.estimator("estimate_multiple_elbo")
+    kw = {}
+    if fused:
+        kw["enc_keep"], kw["dec_keep"] = m.dropout_masks(X.shape[0], num_latent_samples * X.shape[0] * dims.C)
+    bound, _ = fn(dims, enc, dec, X, M, num_latent_samples=num_latent_samples, STL=var_latent_STL, eps=eps, **kw)
     return bound

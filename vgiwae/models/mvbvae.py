@@ -38,31 +38,32 @@ class MVBVAE(VAE):
 
     # ---- objectives on imputed batches Xt [B,K,D], M [B,K,D]
     def _masks(self, Xt):
+        """keep-mask keywords of the fused estimators (the caller-network engine runs torch's own dropout)"""
+        if not self.fused:
+            return {}
         B, K = Xt.shape[:2]
-        return self.dropout_masks(B * K, self.hparams.num_latent_samples * B * K)
+        ek, dk = self.dropout_masks(B * K, self.hparams.num_latent_samples * B * K)
+        return {"enc_keep": ek, "dec_keep": dk}
 
     def estimate_mvb2_objectives(self, Xt, M, eps=None):
         dims, enc, dec = self.engine()
-        ek, dk = self._masks(Xt)
-        return dmv.mvb2_objectives(dims, enc, dec, Xt, M, num_latent_samples=self.hparams.num_latent_samples,
-                                   STL=self.hparams.var_latent_STL, kl_analytic=self.hparams.kl_analytic, eps=eps,
-                                   enc_keep=ek, dec_keep=dk)
+        return self.estimator("mvb2_objectives")[0](dims, enc, dec, Xt, M, num_latent_samples=self.hparams.num_latent_samples,
+                                                    STL=self.hparams.var_latent_STL, kl_analytic=self.hparams.kl_analytic,
+                                                    eps=eps, **self._masks(Xt))
 
     def estimate_cvi_objective(self, Xt, M, eps=None):
         assert not self.hparams.kl_analytic, "Analytic KL not possible with the CVI objective"
         dims, enc, dec = self.engine()
-        ek, dk = self._masks(Xt)
-        return dmv.cvi_objective(dims, enc, dec, Xt, M, num_latent_samples=self.hparams.num_latent_samples,
-                                 STL=self.hparams.var_latent_STL, eps=eps, enc_keep=ek, dec_keep=dk)
+        return self.estimator("cvi_objective")[0](dims, enc, dec, Xt, M, num_latent_samples=self.hparams.num_latent_samples,
+                                                  STL=self.hparams.var_latent_STL, eps=eps, **self._masks(Xt))
 
     def estimate_mvb_objective(self, Xt, M, eps=None):
         """Complete-data ELBO of every imputed copy.  The reference's method of this name raises AttributeError
         (vgiwae/models/mvbvae.py:186,188), so this follows its documented intent; parity unpinned."""
         dims, enc, dec = self.engine()
-        ek, dk = self._masks(Xt)
-        return dmv.mvb_objective(dims, enc, dec, Xt, M, num_latent_samples=self.hparams.num_latent_samples,
-                                 STL=self.hparams.var_latent_STL, kl_analytic=self.hparams.kl_analytic, eps=eps,
-                                 enc_keep=ek, dec_keep=dk)
+        return self.estimator("mvb_objective")[0](dims, enc, dec, Xt, M, num_latent_samples=self.hparams.num_latent_samples,
+                                                  STL=self.hparams.var_latent_STL, kl_analytic=self.hparams.kl_analytic,
+                                                  eps=eps, **self._masks(Xt))
 
     def _objective_step(self, Xt, M, stage, optimise):
         kind = self.hparams.mvb_objective

@@ -52,23 +52,41 @@ class VAE(ImputerModuleBase, PLEstimateTotalTrainSteps):
         q = h.var_latent_distribution
         if q.name.startswith("reparametrised") or q.name.startswith("cont_bern") or q.name.startswith("bern"):
             raise NotImplementedError(f"variational distribution {q} has no HIP kernel")
-        out = self.generator_network.output_dim
+        net = self.generator_network
+        out = net.output_dim if hasattr(net, "output_dim") else int(torch.tensor(net.output_shape).prod())
         D = out // 2 if gen in (DISTRIBUTION.normal, DISTRIBUTION.normal_with_eps) else out
         return dmv.ModelDims(D=D, Zd=self.latent_dims, gen_dist=gen.name, q_dist=engine_name(q),
                              C=max(1, mixture_components(q)), encoder_use_mis_mask=bool(h.encoder_use_mis_mask))
 
+    @property
+    def fused(self) -> bool:
+        """Both networks are residual MLPs: the whole step runs inside the library.  Otherwise (convolutional
+        trunks) the networks stay torch modules and the kernels take their outputs (demiss_vae_amd/external.py)."""
+        return isinstance(self.generator_network, ResidualFCNetwork) and isinstance(self.var_latent_network, ResidualFCNetwork)
+
     def engine(self):
-        """(ModelDims, encoder PackedNet, decoder PackedNet) for the fused pipelines."""
-        if not (isinstance(self.generator_network, ResidualFCNetwork) and isinstance(self.var_latent_network, ResidualFCNetwork)):
-            raise NotImplementedError("the fused pipelines cover ResidualFCNetwork encoders / decoders")
-        return self.model_dims(), self.var_latent_network.packed_net(), self.generator_network.packed_net()
+        """(ModelDims, encoder, decoder): packed networks for the fused pipelines, else two callables
+        encode(X2 [rows, D], M2 [rows, D]) and decode(Z [N, Zd])."""
+        if self.fused:
+            return self.model_dims(), self.var_latent_network.packed_net(), self.generator_network.packed_net()
+        return self.model_dims(), self.predict_var_latent_params, self.generator_network
 
     def dropout_masks(self, enc_rows: int, dec_rows: int):
         return self.var_latent_network.keep_masks(enc_rows), self.generator_network.keep_masks(dec_rows)
 
+    def estimator(self, name: str):
+        """The estimator `name` of the fused or of the caller-network engine, with keep-masks bound in."""
+        if self.fused:
+            return getattr(dmv, name), True
+        from demiss_vae_amd import external
+        return getattr(external, name), False
+
     # ------------------------------------------------------------------ reference helper surface
     def predict_var_latent_params(self, X, M):
         if self.hparams.encoder_use_mis_mask:
+            from vgiwae.shared.vae_resnet import ResNetEncoder
+            if isinstance(self.var_latent_network, ResNetEncoder):
+                return self.var_latent_network(X, M.to(X.dtype))                    # mask as an extra image channel
             return self.var_latent_network(torch.cat([X, M.to(X.dtype)], dim=-1))   # all of X, then all of M
         return self.var_latent_network(X)
 
@@ -167,7 +185,10 @@ def estimate_elbo(model, batch, kl_analytic: bool = False, var_latent_STL: bool 
     X, M = batch[:2]
     m = _inner(model)
     dims, enc, dec = m.engine()
-    ek, dk = m.dropout_masks(X.shape[0], num_latent_samples * X.shape[0])
-    bound, _ = dmv.estimate_elbo(dims, enc, dec, X, M, num_latent_samples=num_latent_samples, kl_analytic=kl_analytic,
-                                 STL=var_latent_STL, eps=eps, enc_keep=ek, dec_keep=dk)
+    fn, fused = m.estimator("estimate_elbo")
+    kw = {}
+    if fused:
+        kw["enc_keep"], kw["dec_keep"] = m.dropout_masks(X.shape[0], num_latent_samples * X.shape[0])
+    bound, _ = fn(dims, enc, dec, X, M, num_latent_samples=num_latent_samples, kl_analytic=kl_analytic,
+                  STL=var_latent_STL, eps=eps, **kw)
     return bound
