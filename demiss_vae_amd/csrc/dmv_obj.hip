@@ -560,6 +560,108 @@ __global__ void k_obj_bwd_latent(BwdLatArgs a) {
   a.d_enc[b * a.q.sb + gp * a.q.sg + a.q.raw_off + j] = gs * acc_sg * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
 }
 
+// ------------------------------------------------------------------------------------------
+// Implicit reparameterisation gradients of mixture samples
+// (vgiwae/shared/reparametrized_mixture_same_family.py:27-191).  z ~ sum_k pi_k N(mu_k, diag sigma_k^2) is drawn
+// ancestrally; its pathwise derivative is dz/dphi = -J^-1 dT/dphi with the distributional transform
+//   T_i(z) = sum_k w_ik Phi((z_i - mu_ki) / sigma_ki),   w_ik = softmax_k(logit_k + sum_{j<i} log N(z_j; mu_kj, sigma_kj))
+// and J = dT/dz (lower triangular).  For a loss gradient g = dL/dz the parameter gradient is -u^T dT/dphi with
+// J^T u = g.  Both the back substitution and the vector-Jacobian product collapse into one sweep j = Zd-1 .. 0
+// with K running sums A_k = sum_{i>j} u_i w_ik (Phi_ik - T_i):
+//   u_j        = (g_j - sum_k d_kj A_k) / sum_k w_jk pdf_jk,          d_kj = -(z_j - mu_kj) / sigma_kj^2
+//   dL/dmu_kj   = u_j w_jk pdf_jk + A_k d_kj
+//   dL/dsig_kj  = u_j w_jk pdf_jk a_jk - A_k ((z_j - mu_kj)^2 / sigma_kj^3 - 1 / sigma_kj),   a = (z - mu) / sigma
+//   dL/dlogit_k = -sum_j u_j w_jk (Phi_jk - T_j)
+// i.e. O(K Zd) per sample instead of the reference's Zd x Zd Jacobian and triangular solve.
+// g_j = dZ[n][j] + wgt[n] (base_prior (-z_j) + base_qmix dlog q_mix(z)/dz_j).
+// One thread per datapoint walks its S samples in order (fixed summation order, no atomics); the prefix sums
+// live in ws [B][K][Zd + 1].
+// ------------------------------------------------------------------------------------------
+struct BwdImplicitArgs {
+  int B, S, Zd, K;
+  QAddr q;
+  float base_prior, base_qmix;
+  const float* enc;
+  const float* Z;
+  int64_t ldz;
+  const float* dZ;      // nullable
+  int64_t ld_dz;
+  const float* wgt;     // nullable
+  float* ws;
+  float* d_enc;
+};
+
+__global__ void k_obj_bwd_latent_implicit(BwdImplicitArgs a) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const int K = a.K, Zd = a.Zd;
+  const float* enc = a.enc + b * a.q.sb;
+  float* out = a.d_enc + b * a.q.sb;
+  float* pre = a.ws + b * (int64_t)K * (Zd + 1);
+  for (int k = 0; k < K; ++k) {
+    out[a.q.logit_off + k] = 0.f;
+    for (int j = 0; j < Zd; ++j) { out[k * a.q.sg + j] = 0.f; out[k * a.q.sg + a.q.raw_off + j] = 0.f; }
+  }
+  float A[64];
+  for (int s = 0; s < a.S; ++s) {
+    const int64_t n = (int64_t)s * a.B + b;
+    const float* z = a.Z + n * a.ldz;
+    const float w_n = a.wgt ? a.wgt[n] : 1.f;
+    // prefix sums of the components' log densities
+    for (int k = 0; k < K; ++k) {
+      float acc = 0.f;
+      pre[k * (Zd + 1)] = 0.f;
+      for (int j = 0; j < Zd; ++j) {
+        const float sg = dmv_softplus(enc[k * a.q.sg + a.q.raw_off + j]) + a.q.eps;
+        acc += log_normal(z[j], enc[k * a.q.sg + j], sg);
+        pre[k * (Zd + 1) + j + 1] = acc;
+      }
+    }
+    // responsibilities of the whole sample (for d log q_mix / dz)
+    float tm = -INFINITY;
+    for (int k = 0; k < K; ++k) tm = fmaxf(tm, enc[a.q.logit_off + k] + pre[k * (Zd + 1) + Zd]);
+    float tz = 0.f;
+    for (int k = 0; k < K; ++k) tz += expf(enc[a.q.logit_off + k] + pre[k * (Zd + 1) + Zd] - tm);
+    for (int k = 0; k < K; ++k) A[k] = 0.f;
+    for (int j = Zd - 1; j >= 0; --j) {
+      float wm = -INFINITY;
+      for (int k = 0; k < K; ++k) wm = fmaxf(wm, enc[a.q.logit_off + k] + pre[k * (Zd + 1) + j]);
+      float wz = 0.f;
+      for (int k = 0; k < K; ++k) wz += expf(enc[a.q.logit_off + k] + pre[k * (Zd + 1) + j] - wm);
+      float T = 0.f, pj = 0.f, dq = 0.f, dA = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float mu = enc[k * a.q.sg + j];
+        const float sg = dmv_softplus(enc[k * a.q.sg + a.q.raw_off + j]) + a.q.eps;
+        const float al = (z[j] - mu) / sg;
+        const float w = expf(enc[a.q.logit_off + k] + pre[k * (Zd + 1) + j] - wm) / wz;
+        const float cdf = 0.5f * (1.f + erff(al * 0.70710678118654752f));
+        const float pdf = expf(-0.5f * al * al) * 0.3989422804014327f / sg;
+        const float d = -al / sg;
+        const float r = expf(enc[a.q.logit_off + k] + pre[k * (Zd + 1) + Zd] - tm) / tz;
+        T += w * cdf; pj += w * pdf; dq += r * d; dA += d * A[k];
+      }
+      const float g = (a.dZ ? a.dZ[n * a.ld_dz + j] : 0.f) + w_n * (a.base_prior * (-z[j]) + a.base_qmix * dq);
+      const float u = (g - dA) / pj;
+      for (int k = 0; k < K; ++k) {
+        const float mu = enc[k * a.q.sg + j];
+        const float raw = enc[k * a.q.sg + a.q.raw_off + j];
+        const float sg = dmv_softplus(raw) + a.q.eps;
+        const float al = (z[j] - mu) / sg;
+        const float w = expf(enc[a.q.logit_off + k] + pre[k * (Zd + 1) + j] - wm) / wz;
+        const float cdf = 0.5f * (1.f + erff(al * 0.70710678118654752f));
+        const float pdf = expf(-0.5f * al * al) * 0.3989422804014327f / sg;
+        const float d = -al / sg;
+        out[k * a.q.sg + j] += u * w * pdf + A[k] * d;
+        const float gs = u * w * pdf * al - A[k] * (al * al / sg - 1.f / sg);
+        out[k * a.q.sg + a.q.raw_off + j] += gs * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
+        const float e = u * w * (cdf - T);
+        out[a.q.logit_off + k] -= e;
+        A[k] += e;
+      }
+    }
+  }
+}
+
 // analytic -KL(N(mu,sigma)||N(0,1)) summed over j, per (b, g):  models/vae.py:404-406
 struct KlArgs { int B, G, Zd; QAddr q; const float* enc; float* kl; };
 __global__ void k_kl(KlArgs a) {
@@ -723,6 +825,28 @@ extern "C" int dmv_obj_combine(const DmvObjCfg* cfg, const float* coef5, const f
     hipLaunchKernelGGL(k_mean, dim3(1), dim3(256), 0, st, (const float*)obj, BG, 1.f / (float)BG, mean_out);
     DMV_HIP_CHECK_LAUNCH();
   }
+  return DMV_OK;
+}
+
+extern "C" size_t dmv_obj_implicit_ws_floats(const DmvObjCfg* cfg, int32_t mix_C) {
+  if (check_cfg(cfg) != DMV_OK || mix_C < 1) return 0;
+  return (size_t)cfg->B * mix_C * (cfg->Zd + 1);
+}
+
+extern "C" int dmv_obj_backward_latent_implicit(const DmvObjCfg* cfg, int32_t mix_C, const float* enc, const float* Z,
+                                                int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
+                                                float base_prior, float base_qmix, float* ws, float* d_enc, void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (!enc || !Z || !ws || !d_enc || ldz < cfg->Zd || (dZ && ld_dz < cfg->Zd)) return DMV_E_BADARG;
+  if (cfg->G != 1) return DMV_E_BADARG;              // one ancestral sample per row
+  if (mix_C < 1 || mix_C > 64) return DMV_E_UNSUPPORTED;
+  BwdImplicitArgs a;
+  a.B = cfg->B; a.S = cfg->nz * cfg->I; a.Zd = cfg->Zd; a.K = mix_C; a.q = qaddr(cfg);
+  a.base_prior = base_prior; a.base_qmix = base_qmix;
+  a.enc = enc; a.Z = Z; a.ldz = ldz; a.dZ = dZ; a.ld_dz = ld_dz; a.wgt = wgt; a.ws = ws; a.d_enc = d_enc;
+  hipLaunchKernelGGL(k_obj_bwd_latent_implicit, dim3((unsigned)((cfg->B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+  DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
 

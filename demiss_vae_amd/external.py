@@ -20,7 +20,7 @@ import torch
 
 from . import _lib as L
 from . import rng
-from .objectives import ModelDims, _Plan, _bound, _combine, _kl, _latent_params, _u8
+from .objectives import ModelDims, _Plan, _bound, _combine, _kl, _latent_params, _u8, _implicit_d_enc, reparam_components
 
 
 class _State:
@@ -48,7 +48,7 @@ def _setup(dims: ModelDims, plan: _Plan, X, M, enc_out):
     if demiss:
         cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = K * ldE, ldE, Zd, 0
         q_kind, mix_C = L.Q_IMPUTATION, K
-    elif dims.q_is_mixture:
+    elif dims.q_is_mixture or dims.q_is_reparam:
         cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, Zd, dims.C * Zd, 2 * dims.C * Zd
         q_kind, mix_C = L.Q_STRATIFIED, dims.C
     else:
@@ -58,23 +58,29 @@ def _setup(dims: ModelDims, plan: _Plan, X, M, enc_out):
     c.Xc, c.Mu = X.contiguous().float(), _u8(M)
     c.plan, c.dims = plan, dims
     c.zscale = None
+    c.reparam = dims.q_is_reparam
+    if c.reparam:
+        assert plan.kind == "iwae" and not plan.DREG, "reparametrised mixtures: ELBO (MC KL) and IWAE bounds only"
     return c
 
 
 class _Sample(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, c, enc_out, eps):
+    def forward(ctx, c, enc_out, eps, comp_idx):
         lib, st = L.lib(), L.stream_ptr()
         Zd, N = c.dims.Zd, c.N
         enc = enc_out.detach().contiguous().float()
         Z = torch.empty((N, Zd), dtype=torch.float32, device=enc.device)
+        if c.reparam:
+            assert c.plan.STL or not enc_out.requires_grad, "reparametrised mixtures are trained with var_latent_STL"
+            comp_idx, eps = reparam_components(c.dims, c.cfg, enc, comp_idx, eps)
         if eps is not None:
             used = eps.reshape(N, Zd).contiguous().float()
-            L.check(lib.dmv_latent_sample(C.byref(c.cfg), L.ptr(enc), L.ptr(used), 0, 0, Zd, None, L.ptr(Z), None, st))
+            L.check(lib.dmv_latent_sample(C.byref(c.cfg), L.ptr(enc), L.ptr(used), 0, 0, Zd, L.ptr(comp_idx), L.ptr(Z), None, st))
         else:
             used = torch.empty((N, Zd), dtype=torch.float32, device=enc.device)
             seed, off = rng.next_offset(N * Zd)
-            L.check(lib.dmv_latent_sample(C.byref(c.cfg), L.ptr(enc), None, seed, off, Zd, None, L.ptr(Z), L.ptr(used), st))
+            L.check(lib.dmv_latent_sample(C.byref(c.cfg), L.ptr(enc), None, seed, off, Zd, L.ptr(comp_idx), L.ptr(Z), L.ptr(used), st))
         c.enc_out, c.Z, c.eps = enc, Z, used
         ctx.c = c
         return Z
@@ -84,12 +90,14 @@ class _Sample(torch.autograd.Function):
         c = ctx.c
         lib, st = L.lib(), L.stream_ptr()
         dZ = dZ.contiguous().float()
+        if c.reparam:
+            return None, _implicit_d_enc(c, dZ, None, 0.0, 0.0), None, None
         d_enc = torch.zeros_like(c.enc_out)
         p = _latent_params(w=0.0, use_zscale=c.plan.DREG)
         L.check(lib.dmv_obj_backward_latent(C.byref(c.cfg), C.byref(p), L.ptr(c.enc_out), L.ptr(c.Z), L.ptr(c.eps), c.Z.shape[1],
                                             L.ptr(dZ), dZ.shape[1], None, L.ptr(c.zscale), None, None, None, None, None,
                                             L.ptr(d_enc), st))
-        return None, d_enc, None
+        return None, d_enc, None, None
 
 
 class _Objective(torch.autograd.Function):
@@ -162,6 +170,8 @@ class _Objective(torch.autograd.Function):
             g_b = gouts[0].float().contiguous()
             wt = (c.wgt.reshape(S, B, G) * g_b.reshape(1, B, 1)).reshape(-1).contiguous()
             dec_part(wt, 1.0, 0.0)
+            if c.reparam:
+                return None, d_dec, _implicit_d_enc(c, None, wt, 1.0, -1.0)
             mixture = c.q_kind == L.Q_STRATIFIED
             dl = (c.dlogit * g_b.reshape(B, 1)).contiguous() if mixture else None
             if mixture:
@@ -202,11 +212,11 @@ class _Objective(torch.autograd.Function):
         return None, d_dec, d_enc
 
 
-def evaluate(dims: ModelDims, plan: _Plan, enc_out, decoder, X, M, eps=None):
+def evaluate(dims: ModelDims, plan: _Plan, enc_out, decoder, X, M, eps=None, comp_idx=None):
     """Runs one objective with the caller's networks.  enc_out [rows, P] is the encoder output (rows = B, or B*K
     for the DeMissVAE objectives); decoder maps Z [N, Zd] to [N, P_dec].  Returns the tuple of outputs."""
     c = _setup(dims, plan, X, M, enc_out)
-    Z = _Sample.apply(c, enc_out, eps)
+    Z = _Sample.apply(c, enc_out, eps, comp_idx)
     dec_out = decoder(Z)
     return _Objective.apply(c, dec_out.reshape(c.N, -1), enc_out)
 
@@ -223,22 +233,22 @@ def _enc_out(dims, plan, encode, X, M):
     return encode(Xin.float(), M.reshape(-1, D)).reshape(Xin.shape[0], -1)
 
 
-def _ext(dims, plan, encode, decode, X, M, eps):
-    return evaluate(dims, plan, _enc_out(dims, plan, encode, X, M), decode, X, M, eps)
+def _ext(dims, plan, encode, decode, X, M, eps, comp_idx=None):
+    return evaluate(dims, plan, _enc_out(dims, plan, encode, X, M), decode, X, M, eps, comp_idx)
 
 
 def estimate_iwelbo(dims, encode, decode, X, M, *, num_latent_samples=1, num_importance_samples=1, STL=False, DREG=False,
-                    eps=None):
+                    eps=None, comp_idx=None):
     assert not (STL and DREG), "Cannot use STL and DREG gradients at the same time."
     plan = _Plan("iwae", num_latent_samples, num_importance_samples, STL=STL, DREG=DREG)
-    (per_b,) = _ext(dims, plan, encode, decode, X, M, eps)
+    (per_b,) = _ext(dims, plan, encode, decode, X, M, eps, comp_idx)
     return per_b.mean(), per_b
 
 
-def estimate_elbo(dims, encode, decode, X, M, *, num_latent_samples=1, kl_analytic=True, STL=False, eps=None):
+def estimate_elbo(dims, encode, decode, X, M, *, num_latent_samples=1, kl_analytic=True, STL=False, eps=None, comp_idx=None):
     assert not (STL and kl_analytic), '"Sticking the Landing" cannot be used with analytical KL.'
     plan = _Plan("elbo_analytic", num_latent_samples, 1) if kl_analytic else _Plan("iwae", num_latent_samples, 1, STL=STL)
-    (per_b,) = _ext(dims, plan, encode, decode, X, M, eps)
+    (per_b,) = _ext(dims, plan, encode, decode, X, M, eps, comp_idx)
     return per_b.mean(), per_b
 
 

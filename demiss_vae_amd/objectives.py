@@ -30,7 +30,7 @@ class ModelDims:
     D: int
     Zd: int
     gen_dist: str = "normal_with_eps"    # normal | normal_with_eps | bern | bern_m1_p1
-    q_dist: str = "normal_with_eps"      # normal | normal_with_eps | stratified | stratified_with_eps
+    q_dist: str = "normal_with_eps"      # normal | normal_with_eps | stratified[_with_eps] | reparam[_with_eps]
     C: int = 1
     encoder_use_mis_mask: bool = False
 
@@ -40,7 +40,13 @@ class ModelDims:
 
     @property
     def q_is_mixture(self):
+        """stratified mixture: one sample row per component"""
         return self.q_dist.startswith("stratified")
+
+    @property
+    def q_is_reparam(self):
+        """mixture sampled ancestrally (one row per datapoint) with implicit reparameterisation gradients"""
+        return self.q_dist.startswith("reparam")
 
     @property
     def dec_params(self):
@@ -104,10 +110,12 @@ def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, 
     cfg.x_per_component = 1 if demiss else 0
     if demiss:
         cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = K * ldE, ldE, Zd, 0
-    elif dims.q_is_mixture:
+    elif dims.q_is_mixture or dims.q_is_reparam:
         cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, Zd, dims.C * Zd, 2 * dims.C * Zd
     else:
         cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, 0, Zd, 0
+    if dims.q_is_reparam:
+        comp_idx, eps = reparam_components(dims, cfg, enc_out, comp_idx, eps)
 
     # ---- z = mu + sigma * eps
     Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
@@ -127,7 +135,7 @@ def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, 
     # ---- per-sample terms
     if demiss:
         q_kind, mix_C = L.Q_IMPUTATION, K
-    elif dims.q_is_mixture:
+    elif dims.q_is_mixture or dims.q_is_reparam:
         q_kind, mix_C = L.Q_STRATIFIED, dims.C
     else:
         q_kind, mix_C = L.Q_OWN, 1
@@ -141,7 +149,28 @@ def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, 
     c.Xc, c.Mu, c.enc_out, c.enc_saved, c.Z, c.eps, c.dec_out, c.dec_saved = Xc, Mu, enc_out, enc_saved, Z, eps_used, dec_out, dec_saved
     c.terms, c.comp_lp, c.enc_rows = terms, comp_lp, enc_rows
     c.enc_keep, c.dec_keep = enc_keep, dec_keep
+    c.reparam = dims.q_is_reparam
     return c
+
+
+def reparam_components(dims: ModelDims, cfg, enc_out, comp_idx, eps):
+    """Ancestral sampling of a mixture encoder: the component of every sample row (n = s*B + b), drawn from the
+    encoder's logits on the device unless given, and the noise of that component when explicit noise
+    [S.., B, C, Zd] is given (MixtureSameFamily.sample draws all components, then gathers)."""
+    B, S, Cn, Zd = cfg.B, cfg.nz * cfg.I, dims.C, dims.Zd
+    dev = enc_out.device
+    if comp_idx is None:
+        logits = enc_out[:, 2 * Cn * Zd:2 * Cn * Zd + Cn].contiguous()
+        draws = torch.empty((B, S), dtype=torch.int64, device=dev)
+        seed, off = rng.next_offset(B * S)
+        L.check(L.lib().dmv_categorical_draw(B, Cn, S, L.ptr(logits), None, seed, off, L.ptr(draws), L.stream_ptr()))
+        comp_idx = draws.t().contiguous().reshape(-1)
+    else:
+        comp_idx = comp_idx.reshape(-1).to(torch.int64).contiguous()
+    if eps is not None and eps.numel() == S * B * Cn * Zd:
+        e = eps.reshape(S * B, Cn, Zd)
+        eps = torch.gather(e, 1, comp_idx.view(-1, 1, 1).expand(-1, 1, Zd)).squeeze(1).contiguous()
+    return comp_idx, eps
 
 
 def _bound(c, plan: _Plan, training: bool):
@@ -151,7 +180,7 @@ def _bound(c, plan: _Plan, training: bool):
     per_b = torch.empty(B, dtype=torch.float32, device=dev)
     wgt = torch.empty(N, dtype=torch.float32, device=dev) if training else None
     zscale = torch.empty(N, dtype=torch.float32, device=dev) if (training and plan.DREG) else None
-    mixture = c.q_kind == L.Q_STRATIFIED
+    mixture = c.q_kind == L.Q_STRATIFIED and not getattr(c, "reparam", False)
     dlogit = torch.zeros((B, G), dtype=torch.float32, device=dev) if (training and mixture) else None
     kind = L.BOUND_WEIGHTED if plan.looser else L.BOUND_LSE
     L.check(lib.dmv_obj_bound(C.byref(c.cfg), kind, c.q_kind, 1 if (mixture and not plan.looser) else 0,
@@ -199,6 +228,18 @@ def _enc_side(c, enc: PackedNet, p: L.DmvLatentBwd, dZ, wgt_total, zscale, dlogi
     return grads
 
 
+def _implicit_d_enc(c, dZ, wgt, base_prior, base_qmix):
+    """Encoder-output gradient through ancestrally sampled mixture latents (implicit reparameterisation)."""
+    lib, st = L.lib(), L.stream_ptr()
+    Cn = c.mix_C
+    ws = torch.empty(lib.dmv_obj_implicit_ws_floats(C.byref(c.cfg), Cn), dtype=torch.float32, device=c.enc_out.device)
+    d_enc = torch.zeros_like(c.enc_out)
+    L.check(lib.dmv_obj_backward_latent_implicit(C.byref(c.cfg), Cn, L.ptr(c.enc_out), L.ptr(c.Z), c.Z.shape[1], L.ptr(dZ),
+                                                 dZ.shape[1] if dZ is not None else 0, L.ptr(wgt), base_prior, base_qmix,
+                                                 L.ptr(ws), L.ptr(d_enc), st))
+    return d_enc
+
+
 def _latent_params(**kw):
     p = L.DmvLatentBwd()
     p.base_prior = kw.get("prior", 0.0)
@@ -217,9 +258,12 @@ class _FusedObjective(torch.autograd.Function):
     """outputs: (per-datapoint bound [B],) or (generator objective [B,K], encoder objective [B,K])."""
 
     @staticmethod
-    def forward(ctx, dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, *params):
-        training = any(ctx.needs_input_grad[9:])
-        c = _forward_core(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, training)
+    def forward(ctx, dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx, *params):
+        training = any(ctx.needs_input_grad[10:])
+        if dims.q_is_reparam:
+            assert plan.kind == "iwae" and not plan.DREG, "reparametrised mixtures: ELBO (MC KL) and IWAE bounds only"
+            assert plan.STL or not training, "reparametrised mixtures are trained with var_latent_STL (as every config does)"
+        c = _forward_core(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, training, comp_idx=comp_idx)
         ctx.c, ctx.dims, ctx.plan, ctx.enc, ctx.dec = c, dims, plan, enc, dec
         ctx.set_materialize_grads(False)
         k = plan.kind
@@ -262,6 +306,11 @@ class _FusedObjective(torch.autograd.Function):
             g_b = gouts[0].float().contiguous()
             wt = (c.wgt.reshape(S, B, G) * g_b.reshape(1, B, 1)).reshape(-1).contiguous()
             dZ, g_dec_params = _dec_side(c, dec, wt, 1.0, 0.0, True, True)
+            if c.reparam:
+                d_enc = _implicit_d_enc(c, dZ, wt, 1.0, -1.0)
+                _, g_enc_params = mlp_backward(enc, c.enc_saved, d_enc, c.enc_rows, need_dx=False, need_param_grads=True,
+                                               drop_keep=c.enc_keep)
+                return (None,) * 10 + tuple(g_enc_params) + tuple(g_dec_params)
             mixture = c.q_kind == L.Q_STRATIFIED
             dl = (c.dlogit * g_b.reshape(B, 1)).contiguous() if mixture else None
             if mixture:
@@ -304,34 +353,36 @@ class _FusedObjective(torch.autograd.Function):
                 else:
                     p = _latent_params(prior=1.0, qown=-1.0, own_live=not plan.STL)
                     g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, None)
-        return (None,) * 9 + tuple(g_enc_params) + tuple(g_dec_params)
+        return (None,) * 10 + tuple(g_enc_params) + tuple(g_dec_params)
 
 
-def _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep):
-    return _FusedObjective.apply(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, *enc.params(), *dec.params())
+def _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx=None):
+    return _FusedObjective.apply(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx, *enc.params(), *dec.params())
 
 
 # ------------------------------------------------------------------------------------------ public API
 def estimate_iwelbo(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_latent_samples=1,
-                    num_importance_samples=1, STL=False, DREG=False, eps=None, enc_keep=None, dec_keep=None):
-    """IWAE bound averaged over the batch, and the per-datapoint bounds.  eps [nz, I, B, Zd]."""
+                    num_importance_samples=1, STL=False, DREG=False, eps=None, enc_keep=None, dec_keep=None, comp_idx=None):
+    """IWAE bound averaged over the batch, and the per-datapoint bounds.  eps [nz, I, B, Zd]; for a reparametrised
+    mixture encoder eps [nz, I, B, C, Zd] and comp_idx [nz, I, B] (drawn on the device when omitted)."""
     assert not (STL and DREG), "Cannot use STL and DREG gradients at the same time."
     assert not dims.q_is_mixture
     plan = _Plan("iwae", num_latent_samples, num_importance_samples, STL=STL, DREG=DREG)
-    (per_b,) = _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep)
+    (per_b,) = _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx)
     return per_b.mean(), per_b
 
 
 def estimate_elbo(dims, enc, dec, X, M, *, num_latent_samples=1, kl_analytic=True, STL=False, eps=None,
-                  enc_keep=None, dec_keep=None):
-    """VAE ELBO with analytic or Monte-Carlo KL.  eps [nz, B, Zd]."""
+                  enc_keep=None, dec_keep=None, comp_idx=None):
+    """VAE ELBO with analytic or Monte-Carlo KL.  eps [nz, B, Zd] (reparametrised mixture: [nz, B, C, Zd] and
+    comp_idx [nz, B])."""
     assert not (STL and kl_analytic), '"Sticking the Landing" cannot be used with analytical KL.'
     assert not dims.q_is_mixture
     if kl_analytic:
         plan = _Plan("elbo_analytic", num_latent_samples, 1)
     else:
         plan = _Plan("iwae", num_latent_samples, 1, STL=STL)   # logsumexp over a single sample = identity
-    (per_b,) = _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep)
+    (per_b,) = _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx)
     return per_b.mean(), per_b
 
 

@@ -193,6 +193,19 @@ int dmv_obj_backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const f
                             const float* zscale, const float* comp_lp, const float* qmix, const float* dlogit,
                             const float* kl_wgt, const float* gscale, float* d_enc, void* stream);
 
+/* Latent-side backward for a mixture encoder sampled ancestrally with implicit reparameterisation gradients
+ * (vgiwae/shared/reparametrized_mixture_same_family.py:27-191 rsample + _distributional_transform; used by the
+ * reparametrised_mixture* variational families, vgiwae/models/vae.py:108-260).  Rows n = s*B + b (G must be 1),
+ * encoder output addressed like a stratified mixture of mix_C components.  Computes the gradient, w.r.t. the
+ * encoder output (all components' mu, raw sigma and the logits), of
+ *   sum_n <g_n, z_n>,  g_n = dZ[n] + wgt[n] * (base_prior * d log p(z)/dz + base_qmix * d log q_mix(z)/dz)
+ * through z only (the "sticking the landing" form: q's own parameters are not differentiated directly).
+ * ws: dmv_obj_implicit_ws_floats(cfg, mix_C) floats.  d_enc: written for every addressed entry. */
+size_t dmv_obj_implicit_ws_floats(const DmvObjCfg* cfg, int32_t mix_C);
+int dmv_obj_backward_latent_implicit(const DmvObjCfg* cfg, int32_t mix_C, const float* enc, const float* Z,
+                                     int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
+                                     float base_prior, float base_qmix, float* ws, float* d_enc, void* stream);
+
 /* Streaming logsumexp for the K-sample log-likelihood (test/refit_encoder_using_iwae_and_estimate_loglik.py
  * :189-222): folds a chunk of Kc samples per datapoint (terms of that chunk, rows k*B + b) into
  * run_max / run_sum [B] (initialise to -inf / 0).  log-lik_b = run_max + log(run_sum) - log(K). */

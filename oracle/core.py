@@ -443,3 +443,71 @@ def loglik_eval(spec: ModelSpec, enc_params, dec_params, X, M, eps, comp_idx=Non
         K = log_w.shape[1]
         per_b = (torch.logsumexp(log_w, dim=1) - math.log(K)).mean(0)
         return per_b.mean(), per_b
+
+
+# ------------------------------------------------------------------------------------------
+# mixture encoder sampled ancestrally, implicit reparameterisation gradients
+# (vgiwae/shared/reparametrized_mixture_same_family.py:27-191; vgiwae/models/vae.py:209-256)
+# ------------------------------------------------------------------------------------------
+def distributional_transform(z, mu, sigma, logits):
+    """T_i(z) = sum_k w_ik Phi((z_i - mu_ki)/sigma_ki), w_ik = softmax_k(logit_k + sum_{j<i} log N(z_j; mu_kj, sigma_kj))
+    (reparametrized_mixture_same_family.py:119-172).  z [..., Zd]; mu, sigma [..., C, Zd]; logits [..., C]."""
+    zc = z.unsqueeze(-2)
+    lp = log_normal(zc, mu, sigma)                                  # [..., C, Zd]
+    excl = torch.cumsum(lp, dim=-1) - lp                            # exclusive prefix sums
+    w = torch.softmax(logits.unsqueeze(-1) + excl, dim=-2)
+    cdf = 0.5 * (1.0 + torch.erf((zc - mu) / (sigma * math.sqrt(2.0))))
+    return (w * cdf).sum(-2)
+
+
+def reparam_mixture_rsample(mu, sigma, logits, comp_idx, eps):
+    """Value: z = mu_c + sigma_c eps_c for the recorded component draws c (MixtureSameFamily.sample draws every
+    component and gathers).  Gradient: z + (s - s.detach()) with s = -J^-1 T(z), J = dT/dz evaluated at z
+    (reparametrized_mixture_same_family.py:61-113).  mu, sigma [B, C, Zd]; logits [B, C]; comp_idx [S.., B];
+    eps [S.., B, C, Zd]."""
+    C, Zd = mu.shape[-2], mu.shape[-1]
+    idx = comp_idx[..., None, None].expand(*comp_idx.shape, 1, Zd)
+    z_all = mu + sigma * eps
+    z = torch.gather(z_all, -2, idx).squeeze(-2).detach()            # [S.., B, Zd]
+    if not (mu.requires_grad or logits.requires_grad):
+        return z
+    lead = z.shape[:-1]
+    zf = z.reshape(-1, Zd)
+    muf = mu.expand(*lead, C, Zd).reshape(-1, C, Zd)
+    sgf = sigma.expand(*lead, C, Zd).reshape(-1, C, Zd)
+    lgf = logits.expand(*lead, C).reshape(-1, C)
+    T = distributional_transform(zf, muf, sgf, lgf)                 # differentiable w.r.t. the parameters
+    with torch.enable_grad():
+        zj = zf.clone().requires_grad_(True)
+        Tj = distributional_transform(zj, muf.detach(), sgf.detach(), lgf.detach())
+        rows = [torch.autograd.grad(Tj[:, i].sum(), zj, retain_graph=True)[0] for i in range(Zd)]
+    J = torch.stack(rows, dim=1).detach()                           # [N, Zd(i), Zd(j)], lower triangular
+    s_ = -torch.linalg.solve_triangular(J, T.unsqueeze(-1), upper=False).squeeze(-1)
+    return (zf + (s_ - s_.detach())).reshape(*lead, Zd)
+
+
+def mixture_logprob(Z, mu, sigma, logits):
+    """MixtureSameFamily.log_prob: logsumexp_c(log pi_c + sum_j log N(z_j; mu_cj, sigma_cj))."""
+    lp = log_normal(Z.unsqueeze(-2), mu, sigma).sum(-1)
+    return torch.logsumexp(lp + torch.log_softmax(logits, dim=-1), dim=-1)
+
+
+def estimate_iwelbo_reparam_mixture(spec: ModelSpec, enc_params, dec_params, X, M, eps, comp_idx, *, STL=True):
+    """IWAE bound (vgiwae/models/iwae.py:70-154) for a reparametrised-mixture encoder.  eps [nz, I, B, C, Zd],
+    comp_idx [nz, I, B].  With a single importance sample this is the Monte-Carlo-KL ELBO of vgiwae/models/vae.py:
+    412-445 (pass eps [nz, 1, B, C, Zd])."""
+    Mf = M.to(X.dtype)
+    p = _encode(spec, enc_params, X * Mf, M, None)
+    mu, sigma, logits = q_heads(spec, p)
+    Z = reparam_mixture_rsample(mu, sigma, logits, comp_idx, eps)
+    g = mlp_forward(dec_params, Z, spec.dec, None)
+    gen = (gen_logprob(spec, g, X) * Mf).sum(-1)
+    prior = log_std_normal(Z).sum(-1)
+    if STL:
+        q = mixture_logprob(Z, mu.detach(), sigma.detach(), logits.detach())
+    else:
+        q = mixture_logprob(Z, mu, sigma, logits)
+    log_w = gen + prior - q
+    per_zb = torch.logsumexp(log_w, dim=1) - math.log(log_w.shape[1])
+    per_b = per_zb.mean(0)
+    return per_b.mean(), per_b

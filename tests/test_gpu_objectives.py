@@ -124,3 +124,50 @@ def test_philox_noise_statistics():
     assert abs(torch.corrcoef(torch.stack([e[:-1, 0], e[1:, 0]]))[0, 1].item()) < 0.02
     sp0 = float(torch.nn.functional.softplus(torch.zeros(())))
     torch.testing.assert_close(Z.cpu(), (eps * sp0).cpu(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("engine", ["fused", "caller_networks"])
+@pytest.mark.parametrize("name", gu.names("reparam_"))
+def test_reparametrised_mixture(name, engine):
+    """Mixture encoder sampled ancestrally with implicit reparameterisation gradients (the reparametrised_mixture*
+    families; vgiwae/shared/reparametrized_mixture_same_family.py), STL, through both engines: the fused residual
+    MLP pipeline and the caller-network one (here the same networks as plain torch functions).  Encoder-side
+    tolerance as in the oracle test: the reference's fp32 triangular solve is itself only good to ~1e-3."""
+    import dataclasses
+    import demiss_vae_amd as dmv
+    import gpu_util as G
+    from demiss_vae_amd import external
+    from oracle import core
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(g)
+    q = "reparam_with_eps" if bool(g["with_eps"]) else "reparam"
+    dims = dataclasses.replace(G.model_dims(spec), q_dist=q)
+    X, M = (t.cuda() for t in gu.batch_of(g))
+    eps, comp = torch.from_numpy(g["eps"]).cuda(), torch.from_numpy(g["comp_idx"]).cuda()
+    nz, I, is_vae = int(g["nz"]), int(g["I"]), str(g["cls"]) == "VAE"
+    if engine == "fused":
+        enc, dec = G.packed_net(spec.enc, enc_p), G.packed_net(spec.dec, dec_p)
+        fn, a, b = dmv, enc, dec
+    else:
+        ep = {k: v.cuda().requires_grad_(True) for k, v in enc_p.items()}
+        dp = {k: v.cuda().requires_grad_(True) for k, v in dec_p.items()}
+        fn = external
+        a = lambda X2, M2: core.mlp_forward(ep, torch.cat([X2, M2.to(X2.dtype)], -1), spec.enc)
+        b = lambda Z: core.mlp_forward(dp, Z, spec.dec)
+    if is_vae:
+        bound, _ = fn.estimate_elbo(dims, a, b, X, M, num_latent_samples=nz, kl_analytic=False, STL=True, eps=eps, comp_idx=comp)
+    else:
+        bound, _ = fn.estimate_iwelbo(dims, a, b, X, M, num_latent_samples=nz, num_importance_samples=I, STL=True, eps=eps,
+                                      comp_idx=comp)
+    (-bound).backward()
+    np.testing.assert_allclose(bound.item(), float(g["bound"]), rtol=RT_B)
+    if engine == "fused":
+        genc, gdec = G.grads_of(enc, spec.enc), G.grads_of(dec, spec.dec)
+    else:
+        genc, gdec = {k: v.grad for k, v in ep.items()}, {k: v.grad for k, v in dp.items()}
+    assert gu.check_grads(g, "genc", genc, 2e-3, AT_G, floor=2e-4) > 0
+    assert gu.check_grads(g, "gdec", gdec, RT_G, AT_G) > 0
+    # device-drawn components and noise: finite and in the neighbourhood of the explicit-noise bound
+    if engine == "fused":
+        b2, _ = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=4, num_importance_samples=8, STL=True)
+        assert torch.isfinite(b2) and abs(b2.item() - float(g["bound"])) < 0.5 * abs(float(g["bound"])) + 5

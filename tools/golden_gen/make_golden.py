@@ -397,6 +397,50 @@ def cases_mvb(out):
          B=64, nz=1, seed=20220120, objective="mvb2", STL=True, store_inputs=False)
 
 
+def _reparam(out, name, *, cls, D, Zd, C, B, I, nz, seed, with_eps=True):
+    """VAE / IWAE whose encoder is a mixture sampled ancestrally with implicit reparameterisation gradients
+    (the reparametrised_mixture* families), STL as in every shipped config."""
+    from vgiwae.shared.vae_enums import DISTRIBUTION
+    from vgiwae.models.iwae import estimate_iwelbo
+    from vgiwae.models.vae import estimate_elbo
+    enc_spec, dec_spec = NetSpec(2 * D, 2 * C * Zd + C, 2, 32), NetSpec(Zd, 2 * D, 2, 32)
+    enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+    import vgiwae.models as models
+    qd = DISTRIBUTION[f"reparametrised_mixture{C}_normal" + ("_with_eps" if with_eps else "")]
+    kw = dict(num_importance_samples=I) if cls == "IWAE" else dict(kl_analytic=False)
+    model = getattr(models, cls)(generator_network=ref_net(dec_spec, dec_p), generator_distribution=dist_enum("normal_with_eps"),
+                                 var_latent_network=ref_net(enc_spec, enc_p), var_latent_distribution=qd,
+                                 num_latent_samples=nz, lr_generator=1e-3, lr_latent=1e-3, encoder_use_mis_mask=True,
+                                 var_latent_STL=True, **kw)
+    model.train()
+    X, M = make_batch(seed + 2, B, D)
+    shape = (nz, I, B, C, Zd) if cls == "IWAE" else (nz, B, C, Zd)
+    eps = make_noise(seed + 3, *shape)
+    noise = Noise()
+    noise.normal = [eps.clone()]
+    with injected(noise):
+        if cls == "IWAE":
+            bound = estimate_iwelbo(model, (X, M), var_latent_STL=True, num_latent_samples=nz, num_importance_samples=I)
+        else:
+            bound = estimate_elbo(model, (X, M), kl_analytic=False, var_latent_STL=True, num_latent_samples=nz)
+    (-bound).backward()
+    arrays = dict(seed=seed, B=B, I=I, nz=nz, D=D, Zd=Zd, C=C, with_eps=with_eps, cls=cls, bound=bound, X=X, M=M, eps=eps,
+                  comp_idx=noise.cat_draws[0],
+                  enc_spec=np.array([enc_spec.in_dim, enc_spec.out_dim, enc_spec.nb, enc_spec.hidden]),
+                  dec_spec=np.array([dec_spec.in_dim, dec_spec.out_dim, dec_spec.nb, dec_spec.hidden]))
+    arrays.update(params_to_dict("enc", enc_p))
+    arrays.update(params_to_dict("dec", dec_p))
+    arrays.update(grads_to_dict("genc", model.var_latent_network))
+    arrays.update(grads_to_dict("gdec", model.generator_network))
+    save(out, name, **arrays)
+
+
+def cases_reparam(out):
+    _reparam(out, "reparam_iwae_C5", cls="IWAE", D=8, Zd=6, C=5, B=10, I=3, nz=1, seed=8000)
+    _reparam(out, "reparam_vae_C5", cls="VAE", D=8, Zd=6, C=5, B=10, I=1, nz=2, seed=8100)
+    _reparam(out, "reparam_iwae_C15_noeps", cls="IWAE", D=5, Zd=3, C=15, B=7, I=4, nz=2, seed=8200, with_eps=False)
+
+
 def cases_resnet(out):
     """DeMissVAE (mvb2, STL, pseudo-Gibbs x1) with small convolutional trunks on 28x28 Bernoulli{-1,+1} images: the
     structure of configs/mnist_bin/compare/q50/mvb2vae_noencm_pg_k5_stl.yaml at reduced widths, dropout off."""
@@ -721,6 +765,7 @@ def main():
         "masks": lambda: cases_masks(args.out, args.ref),
         "dmis": lambda: cases_dmis_known_answer(args.out),
         "resnet": lambda: cases_resnet(args.out),
+        "reparam": lambda: cases_reparam(args.out),
     }
     for name, fn in groups.items():
         if args.only and name not in args.only.split(","):

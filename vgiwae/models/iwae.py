@@ -73,6 +73,8 @@ def estimate_iwelbo(model, batch, var_latent_STL: bool = False, var_latent_DREG:
     kw = {}
     if fused:
         kw["enc_keep"], kw["dec_keep"] = m.dropout_masks(X.shape[0], num_latent_samples * num_importance_samples * X.shape[0])
+    if comp_idx is not None:
+        kw["comp_idx"] = comp_idx
     bound, _ = fn(dims, enc, dec, X, M, num_latent_samples=num_latent_samples, num_importance_samples=num_importance_samples,
                   STL=var_latent_STL, DREG=var_latent_DREG, eps=eps, **kw)
     return bound

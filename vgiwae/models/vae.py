@@ -50,7 +50,7 @@ class VAE(ImputerModuleBase, PLEstimateTotalTrainSteps):
         if gen not in (DISTRIBUTION.normal, DISTRIBUTION.normal_with_eps, DISTRIBUTION.bern, DISTRIBUTION.bern_m1_p1):
             raise NotImplementedError(f"generator distribution {gen} has no HIP kernel")
         q = h.var_latent_distribution
-        if q.name.startswith("reparametrised") or q.name.startswith("cont_bern") or q.name.startswith("bern"):
+        if q.name.startswith("cont_bern") or q.name.startswith("bern"):
             raise NotImplementedError(f"variational distribution {q} has no HIP kernel")
         net = self.generator_network
         out = net.output_dim if hasattr(net, "output_dim") else int(torch.tensor(net.output_shape).prod())
@@ -180,7 +180,7 @@ def _inner(model):
 
 
 def estimate_elbo(model, batch, kl_analytic: bool = False, var_latent_STL: bool = False, num_latent_samples: int = 1,
-                  eps=None):
+                  eps=None, comp_idx=None):
     """Batch-mean ELBO (vgiwae/models/vae.py:447-473) through the fused pipeline."""
     X, M = batch[:2]
     m = _inner(model)
@@ -189,6 +189,8 @@ def estimate_elbo(model, batch, kl_analytic: bool = False, var_latent_STL: bool 
     kw = {}
     if fused:
         kw["enc_keep"], kw["dec_keep"] = m.dropout_masks(X.shape[0], num_latent_samples * X.shape[0])
+    if comp_idx is not None:
+        kw["comp_idx"] = comp_idx
     bound, _ = fn(dims, enc, dec, X, M, num_latent_samples=num_latent_samples, kl_analytic=kl_analytic,
                   STL=var_latent_STL, eps=eps, **kw)
     return bound

@@ -32,4 +32,6 @@ def engine_name(distribution) -> str:
     name = distribution.name
     if name.startswith("stratified_mixture"):
         return "stratified_with_eps" if name.endswith("with_eps") else "stratified"
+    if name.startswith("reparametrised_mixture"):
+        return "reparam_with_eps" if name.endswith("with_eps") else "reparam"
     return name
