@@ -67,6 +67,8 @@ SIGNATURES = {
                                           _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmv_obj_implicit_ws_floats": (_SZ, [C.POINTER(DmvObjCfg), _I32]),
     "dmv_obj_backward_latent_implicit": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _P, _P, _I64, _P, _I64, _P, _F, _F, _P, _P, _P]),
+    "dmv_grid_marginal_ws_floats": (_SZ, [_I64, _I32]),
+    "dmv_grid_marginal": (C.c_int, [_I32, _I32, _I64, _P, _I64, _P, _I32, _P, _P, _P, _P, _P, _P]),
     "dmv_lse_update": (C.c_int, [_I32, _I64, _P, _I32, _P, _P, _P]),
     "dmv_rows_gather": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "dmv_rows_scatter": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),

@@ -716,6 +716,89 @@ __global__ void k_lse_update(LseArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Marginal log-probability by numerical integration over a latent grid
+// (vgiwae/shared/vae_marginal_logprob.py:194-307): for every datapoint
+//   log p(x_o) ~= logsumexp_z [ log p(z) + log dz + sum_d M_d log p(x_d | z) ]      (and the same without the mask)
+// with the decoder evaluated once per grid point.  k_grid_prep turns the decoder outputs into three numbers per
+// (grid point, dimension) so that the B x Nz x D inner loop is a fused multiply-add; k_grid_marginal runs one
+// block per datapoint with an online (max, sum-exp) per thread and a block reduction.
+// ------------------------------------------------------------------------------------------
+struct GridArgs {
+  int64_t Nz;
+  int D, B, gen_dist;
+  const float* dec;
+  int64_t ld_dec;
+  const float* logw;     // [Nz] log prior + log cell volume
+  const float* X;
+  const uint8_t* M;
+  float* ws;             // [Nz][D][3]
+  float* out_obs;
+  float* out_full;       // nullable
+};
+
+__global__ void k_grid_prep(GridArgs a) {
+  const int64_t total = a.Nz * a.D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t z = i / a.D;
+    const int d = (int)(i - z * a.D);
+    const float* dec = a.dec + z * a.ld_dec;
+    float p0, p1, c;
+    if (a.gen_dist <= DMV_GEN_NORMAL_EPS) {
+      const float s = dmv_softplus(dec[a.D + d]) + (a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f);
+      p0 = dec[d]; p1 = 1.f / (2.f * s * s); c = -logf(s) - LOG_SQRT_2PI;
+    } else {
+      const float l = dec[d];
+      p0 = l; p1 = 0.f; c = fminf(-l, 0.f) - log1pf(expf(-fabsf(l)));      // log(1 - sigmoid(l)): log p(x = 0)
+    }
+    a.ws[3 * i + 0] = p0; a.ws[3 * i + 1] = p1; a.ws[3 * i + 2] = c;
+  }
+}
+
+__global__ void k_grid_marginal(GridArgs a) {
+  const int b = blockIdx.x;
+  const float* X = a.X + (int64_t)b * a.D;
+  const uint8_t* M = a.M + (int64_t)b * a.D;
+  const bool normal = a.gen_dist <= DMV_GEN_NORMAL_EPS;
+  float mo = -INFINITY, so = 0.f, mf = -INFINITY, sf = 0.f;
+  for (int64_t z = threadIdx.x; z < a.Nz; z += blockDim.x) {
+    const float* w = a.ws + z * a.D * 3;
+    float lo = a.logw[z], lf = lo;
+    for (int d = 0; d < a.D; ++d) {
+      const float x = X[d];
+      float lp;
+      if (normal) { const float df = x - w[3 * d]; lp = w[3 * d + 2] - df * df * w[3 * d + 1]; }
+      else { const float v = a.gen_dist == DMV_GEN_BERN ? x : (x + 1.f) * 0.5f; lp = w[3 * d + 2] + v * w[3 * d]; }
+      lf += lp;
+      lo += M[d] ? lp : 0.f;
+    }
+    float nm = fmaxf(mo, lo);
+    if (nm > -INFINITY) { so = so * expf(mo - nm) + expf(lo - nm); mo = nm; }
+    nm = fmaxf(mf, lf);
+    if (nm > -INFINITY) { sf = sf * expf(mf - nm) + expf(lf - nm); mf = nm; }
+  }
+  __shared__ float sh[4][256];
+  sh[0][threadIdx.x] = mo; sh[1][threadIdx.x] = so; sh[2][threadIdx.x] = mf; sh[3][threadIdx.x] = sf;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      for (int q = 0; q < 2; ++q) {
+        const float m1 = sh[2 * q][threadIdx.x], m2 = sh[2 * q][threadIdx.x + o];
+        const float nm = fmaxf(m1, m2);
+        if (nm > -INFINITY) {
+          sh[2 * q + 1][threadIdx.x] = sh[2 * q + 1][threadIdx.x] * expf(m1 - nm) + sh[2 * q + 1][threadIdx.x + o] * expf(m2 - nm);
+          sh[2 * q][threadIdx.x] = nm;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    a.out_obs[b] = sh[0][0] + logf(sh[1][0]);
+    if (a.out_full) a.out_full[b] = sh[2][0] + logf(sh[3][0]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 static int check_cfg(const DmvObjCfg* c) {
@@ -919,6 +1002,28 @@ extern "C" int dmv_lse_update(int32_t B, int64_t Kc, const float* terms, int32_t
   a.B = B; a.Kc = Kc; a.gm = terms; a.pr = terms + 2 * N; a.q = terms + (int64_t)q_term * N;
   a.run_max = run_max; a.run_sum = run_sum;
   hipLaunchKernelGGL(k_lse_update, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+extern "C" size_t dmv_grid_marginal_ws_floats(int64_t Nz, int32_t D) {
+  return (Nz < 0 || D < 1) ? 0 : (size_t)Nz * D * 3;
+}
+
+extern "C" int dmv_grid_marginal(int32_t gen_dist, int32_t D, int64_t Nz, const float* dec, int64_t ld_dec,
+                                 const float* logw, int32_t B, const float* X, const uint8_t* M, float* ws,
+                                 float* out_obs, float* out_full, void* stream) {
+  if (gen_dist < DMV_GEN_NORMAL || gen_dist > DMV_GEN_BERN_M1P1) return DMV_E_UNSUPPORTED;
+  if (D < 1 || Nz < 1 || B < 0 || !dec || !logw || !X || !M || !ws || !out_obs) return DMV_E_BADARG;
+  if (ld_dec < (gen_dist <= DMV_GEN_NORMAL_EPS ? 2 * D : D)) return DMV_E_BADARG;
+  if (B == 0) return DMV_OK;
+  GridArgs a;
+  a.Nz = Nz; a.D = D; a.B = B; a.gen_dist = gen_dist; a.dec = dec; a.ld_dec = ld_dec; a.logw = logw; a.X = X; a.M = M;
+  a.ws = ws; a.out_obs = out_obs; a.out_full = out_full;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_grid_prep, dim3(grid_for(Nz * D, 256)), dim3(256), 0, st, a);
+  DMV_HIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_grid_marginal, dim3((unsigned)B), dim3(256), 0, st, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }

@@ -206,6 +206,16 @@ int dmv_obj_backward_latent_implicit(const DmvObjCfg* cfg, int32_t mix_C, const 
                                      int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
                                      float base_prior, float base_qmix, float* ws, float* d_enc, void* stream);
 
+/* Marginal log-probability of incomplete (and complete) datapoints by numerical integration over a latent grid
+ * (vgiwae/shared/vae_marginal_logprob.py:194-307, get_marginal_logprob_for_Zgrid): dec [Nz][ld_dec] are the decoder
+ * outputs at the Nz grid points, logw [Nz] = log p(z) + log(cell volume).
+ *   out_obs[b]  = logsumexp_z(logw_z + sum_d M_bd log p(x_bd | z));   out_full[b] (nullable): the same without M.
+ * ws: dmv_grid_marginal_ws_floats(Nz, D) floats. */
+size_t dmv_grid_marginal_ws_floats(int64_t Nz, int32_t D);
+int dmv_grid_marginal(int32_t gen_dist, int32_t D, int64_t Nz, const float* dec, int64_t ld_dec, const float* logw,
+                      int32_t B, const float* X, const uint8_t* M, float* ws, float* out_obs, float* out_full,
+                      void* stream);
+
 /* Streaming logsumexp for the K-sample log-likelihood (test/refit_encoder_using_iwae_and_estimate_loglik.py
  * :189-222): folds a chunk of Kc samples per datapoint (terms of that chunk, rows k*B + b) into
  * run_max / run_sum [B] (initialise to -inf / 0).  log-lik_b = run_max + log(run_sum) - log(K). */

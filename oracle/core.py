@@ -511,3 +511,38 @@ def estimate_iwelbo_reparam_mixture(spec: ModelSpec, enc_params, dec_params, X, 
     per_zb = torch.logsumexp(log_w, dim=1) - math.log(log_w.shape[1])
     per_b = per_zb.mean(0)
     return per_b.mean(), per_b
+
+
+# ------------------------------------------------------------------------------------------
+# marginal log-probability on a latent grid (vgiwae/shared/vae_marginal_logprob.py:8-51, 66-90, 194-307)
+# ------------------------------------------------------------------------------------------
+def latent_grid(latent_dim, grid_min=None, grid_max=None, grid_steps=None):
+    """(Z [Nz, latent_dim], cell volume).  1-d: linspace(min, max, steps) (end points included) with cell
+    (max - min)/steps; 2-d: the lower-left corners min + i (max - min)/steps, i < steps, on both axes."""
+    import numpy as np
+    if latent_dim == 1:
+        lo, hi, steps = -15, 15, 4000
+    elif latent_dim == 2:
+        lo, hi, steps = -10, 10, 500
+    else:
+        raise NotImplementedError("numerical integration over more than 2 latent dimensions")
+    lo = grid_min if grid_min is not None else lo
+    hi = grid_max if grid_max is not None else hi
+    steps = grid_steps if grid_steps is not None else steps
+    if latent_dim == 1:
+        return torch.linspace(lo, hi, steps=steps).reshape(-1, 1), (hi - lo) / steps
+    z0, z1 = np.mgrid[lo:hi:(hi - lo) / steps, lo:hi:(hi - lo) / steps]
+    Z = torch.tensor(np.stack([z0, z1], -1)).float().reshape(-1, 2)
+    return Z, ((hi - lo) / steps) ** 2
+
+
+def grid_marginal_logprob(spec: ModelSpec, dec_params, X, M, grid_min=None, grid_max=None, grid_steps=None):
+    """(log p(x_o), log p(x)) per datapoint by summing over the grid."""
+    Z, dz = latent_grid(spec.Zd, grid_min, grid_max, grid_steps)
+    prior = log_std_normal(Z).sum(-1, keepdim=True)                       # [Nz, 1]
+    g = mlp_forward(dec_params, Z, spec.dec, None).unsqueeze(1)           # [Nz, 1, P]
+    comp = gen_logprob(spec, g, X)                                        # [Nz, B, D]
+    joint_obs = prior + (comp * M.to(comp.dtype)).sum(-1)
+    joint_full = prior + comp.sum(-1)
+    ldz = math.log(dz)
+    return torch.logsumexp(joint_obs + ldz, dim=0), torch.logsumexp(joint_full + ldz, dim=0)

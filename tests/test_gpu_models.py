@@ -137,6 +137,36 @@ def test_conv_trunk_demissvae_matches_reference(tag):
     assert gu.check_grads(g, "gdec", {k: v.grad for k, v in dec.named_parameters() if v.grad is not None}, 5e-3, 1e-5, floor=2e-3) > 5
 
 
+@pytest.mark.parametrize("name", gu.names("marginal_"))
+def test_grid_marginal_logprob_matches_reference(name):
+    """The toy configs' evaluation metric: log p(x_o) and log p(x) by integrating over the latent grid."""
+    import gpu_util as G
+    from demiss_vae_amd.marginal import grid_marginal_logprob
+    g = gu.load(name)
+    spec, _, dec_p = gu.model_case(g)
+    X, M = gu.batch_of(g)
+    lo = None if np.isnan(g["grid_min"]) else float(g["grid_min"])
+    hi = None if np.isnan(g["grid_max"]) else float(g["grid_max"])
+    obs, full = grid_marginal_logprob(G.model_dims(spec), G.packed_net(spec.dec, dec_p, requires_grad=False), X.cuda(), M.cuda(),
+                                      compute_complete=True, grid_min=lo, grid_max=hi, grid_steps=int(g["grid_steps"]))
+    np.testing.assert_allclose(obs.cpu().numpy(), g["marginal_obs"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(full.cpu().numpy(), g["marginal_full"], rtol=1e-5, atol=2e-5)
+
+
+def test_marglogprob_class_logs_the_metric():
+    g = gu.load("mvb_toy_full")
+    spec, enc_p, dec_p = gu.model_case(g)
+    from vgiwae.models import MVB_OBJECTIVE
+    model = _build("MVBVAEMargLogprob", spec, enc_p, dec_p, num_latent_samples=1, var_latent_STL=True, kl_analytic=False,
+                   mvb_objective=MVB_OBJECTIVE["mvb2"], marginal_eval_freq=5, latent_grid_steps=100, mvb_update_val_imps=False)
+    logged = {}
+    model.log = lambda k, v, **kw: logged.__setitem__(k, float(v))
+    X, M = gu.batch_of(g)
+    model.eval()
+    model.validation_step((X.cuda(), M.cuda(), torch.arange(X.shape[0]).cuda()), 0)
+    assert np.isfinite(logged["marginal_logprob/val"]) and logged["complete_marginal_logprob/val"] < logged["marginal_logprob/val"]
+
+
 def test_short_training_run_learns():
     """A few hundred Adam steps of MissIWAE on synthetic correlated data: the bound improves markedly."""
     from oracle.recipes import NetSpec, make_params, make_mask

@@ -257,3 +257,15 @@ def test_reparametrised_mixture_bound_and_grads(name):
     # floor of 2e-4 of the tensor's largest entry; the decoder side keeps the usual tolerance
     assert gu.check_grads(g, "genc", {k: v.grad for k, v in ep.items()}, 2e-3, 2e-6, floor=2e-4) > 0
     assert gu.check_grads(g, "gdec", {k: v.grad for k, v in dp.items()}, 1e-4, 2e-6) > 0
+
+
+@pytest.mark.parametrize("name", gu.names("marginal_"))
+def test_grid_marginal_logprob(name):
+    g = gu.load(name)
+    spec, _, dec_p = gu.model_case(g)
+    X, M = gu.batch_of(g)
+    lo = None if np.isnan(g["grid_min"]) else float(g["grid_min"])
+    hi = None if np.isnan(g["grid_max"]) else float(g["grid_max"])
+    obs, full = core.grid_marginal_logprob(spec, dec_p, X, M, lo, hi, int(g["grid_steps"]))
+    np.testing.assert_allclose(obs.numpy(), g["marginal_obs"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(full.numpy(), g["marginal_full"], rtol=1e-5, atol=1e-5)

@@ -441,6 +441,29 @@ def cases_reparam(out):
     _reparam(out, "reparam_iwae_C15_noeps", cls="IWAE", D=5, Zd=3, C=15, B=7, I=4, nz=2, seed=8200, with_eps=False)
 
 
+def cases_marginal(out):
+    """Grid marginal log-probability diagnostic of the toy configs (vae_marginal_logprob.get_marginal_logprob)."""
+    from vgiwae.shared.vae_marginal_logprob import get_marginal_logprob
+    for name, D, Zd, steps, lo, hi, gen in (("marginal_2d", 5, 2, 40, None, None, "normal"),
+                                           ("marginal_2d_range", 5, 2, 30, -4.0, 4.0, "normal_with_eps"),
+                                           ("marginal_1d", 4, 1, 300, None, None, "normal")):
+        seed = 9000 + 10 * steps
+        enc_spec, dec_spec = NetSpec(D, 2 * Zd, 2, 32), NetSpec(Zd, 2 * D, 3, 32)
+        enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+        model = build_model("VAE", enc_spec, dec_spec, enc_p, dec_p, gen, "normal", kl_analytic=True)
+        model.eval()
+        X, M = make_batch(seed + 2, 12, D)
+        with torch.inference_mode():
+            obs, full = get_marginal_logprob(model, (X, M), compute_complete=True, grid_min=lo, grid_max=hi, grid_steps=steps)
+        arrays = dict(seed=seed, D=D, Zd=Zd, B=12, gen_dist=gen, q_dist="normal", grid_steps=steps,
+                      grid_min=np.nan if lo is None else lo, grid_max=np.nan if hi is None else hi, X=X, M=M,
+                      marginal_obs=obs, marginal_full=full,
+                      enc_spec=np.array([D, 2 * Zd, 2, 32]), dec_spec=np.array([Zd, 2 * D, 3, 32]))
+        arrays.update(params_to_dict("enc", enc_p))
+        arrays.update(params_to_dict("dec", dec_p))
+        save(out, name, **arrays)
+
+
 def cases_resnet(out):
     """DeMissVAE (mvb2, STL, pseudo-Gibbs x1) with small convolutional trunks on 28x28 Bernoulli{-1,+1} images: the
     structure of configs/mnist_bin/compare/q50/mvb2vae_noencm_pg_k5_stl.yaml at reduced widths, dropout off."""
@@ -766,6 +789,7 @@ def main():
         "dmis": lambda: cases_dmis_known_answer(args.out),
         "resnet": lambda: cases_resnet(args.out),
         "reparam": lambda: cases_reparam(args.out),
+        "marginal": lambda: cases_marginal(args.out),
     }
     for name, fn in groups.items():
         if args.only and name not in args.only.split(","):

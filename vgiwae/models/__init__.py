@@ -1,10 +1,10 @@
 """Model classes named by the YAML configs (reference: vgiwae/models/__init__.py:1-12).
 
 The `*_FID`, `*MargLogprob` and `*GradVar` names are the reference's diagnostic wrappers
-(models/vae_fid.py:174-180, vae_marglogprob.py:140-146, vae_gradvar.py:51-57).  Their diagnostics
-(FID against a pre-trained encoder checkpoint, grid marginal log-probability for 2-d latents, gradient
-variance) are outside the accelerated path: the classes here accept and record the same keyword
-arguments so configs instantiate, train and evaluate exactly like their base class, and skip the diagnostic."""
+(models/vae_fid.py:174-180, vae_marglogprob.py:140-146, vae_gradvar.py:51-57).  The `*MargLogprob` classes
+compute the grid marginal log-probability of the batch on the device (demiss_vae_amd/marginal.py) and log it
+under the reference's metric names; the posterior-divergence extras of that wrapper, FID (needs a pre-trained
+encoder checkpoint) and the gradient-variance probe are accepted as keyword arguments, recorded, and skipped."""
 from .vae import VAE
 from .iwae import IWAE
 from .mvbvae import MVBVAE, MVB_OBJECTIVE
@@ -22,6 +22,22 @@ _DIAGNOSTIC_KWARGS = {
 }
 
 
+def _marginal_logprob(self, batch, stage):
+    """marginal_logprob/<stage> and complete_marginal_logprob/<stage> (models/vae_marglogprob.py:38-52, 88-100)"""
+    import torch
+    from demiss_vae_amd.marginal import grid_marginal_logprob
+    h = self.hparams
+    last = getattr(getattr(self, "trainer", None), "max_epochs", None)
+    if not (self.current_epoch % h.marginal_eval_freq == 0 or (last is not None and self.current_epoch == last - 1)):
+        return
+    with torch.no_grad():
+        obs, full = grid_marginal_logprob(self.model_dims(), self.generator_network.packed_net(), batch[0], batch[1],
+                                          compute_complete=True, grid_min=h.latent_grid_min, grid_max=h.latent_grid_max,
+                                          grid_steps=h.latent_grid_steps)
+    self.log(f"marginal_logprob/{stage}", obs.mean(), on_step=False, on_epoch=True, prog_bar=True, logger=True)
+    self.log(f"complete_marginal_logprob/{stage}", full.mean(), on_step=False, on_epoch=True, prog_bar=True, logger=True)
+
+
 def _with_ignored_diagnostics(base, suffix):
     defaults = _DIAGNOSTIC_KWARGS[suffix]
 
@@ -29,9 +45,24 @@ def _with_ignored_diagnostics(base, suffix):
         extra = {k: kwargs.pop(k, v) for k, v in defaults.items()}
         base.__init__(self, *args, **kwargs)
         self.hparams.update(extra)
+        if suffix == "MargLogprob" and extra["latent_grid_min"] is not None and extra["latent_grid_max"] is not None:
+            assert extra["latent_grid_min"] < extra["latent_grid_max"]
     name = base.__name__ + suffix
-    return type(name, (base,), {"__init__": __init__, "__doc__": f"{base.__name__} (the {suffix} diagnostic is skipped)",
-                                "__module__": __name__})
+    members = {"__init__": __init__, "__doc__": f"{base.__name__} with the {suffix} wrapper's keyword arguments",
+               "__module__": __name__}
+    if suffix == "MargLogprob":
+        def training_step(self, batch, batch_idx):
+            out = base.training_step(self, batch, batch_idx)
+            if self.hparams.marginal_eval_train:
+                _marginal_logprob(self, batch, "train")
+            return out
+
+        def validation_step(self, batch, batch_idx):
+            out = base.validation_step(self, batch, batch_idx)
+            _marginal_logprob(self, batch, "val")
+            return out
+        members.update(training_step=training_step, validation_step=validation_step)
+    return type(name, (base,), members)
 
 
 for _base in (VAE, IWAE, MVBVAE, MultipleIWAE, MultipleVAE):
