@@ -283,6 +283,21 @@ def main():
 
             t512 = timed(step512, 50, 10, barrier)
             extra["yaml_batch_512"] = {"ms_per_step": round(t512 * 1e3, 4), "samples_per_s": round(512 * K / t512, 1)}
+            # the same step recorded once in a HIP graph (noise refilled outside the recording)
+            opt3 = torch.optim.Adam(p2, lr=1e-3, amsgrad=True, fused=True, capturable=True)
+            eps512 = torch.empty(1, K, 512, dims2.Zd, device=device)
+
+            def body512():
+                opt3.zero_grad(set_to_none=True)
+                b, _ = dmv.estimate_iwelbo(dims2, enc2, dec2, X2, M2, num_latent_samples=1, num_importance_samples=K, STL=True,
+                                           eps=eps512)
+                (-b).backward()
+                torch.nn.utils.clip_grad_norm_(p2, 5.0, foreach=True)
+                opt3.step()
+
+            g512 = dmv.GraphedStep(body512, refresh=lambda: eps512.normal_(), nets=(enc2, dec2))
+            tg = timed(g512, 200, 20, barrier)
+            extra["yaml_batch_512_hip_graph"] = {"ms_per_step": round(tg * 1e3, 4), "samples_per_s": round(512 * K / tg, 1)}
             from demiss_vae_amd.bench_extra import demiss_toy_step, missiwae_step
             extra["demiss_toy_mvb2"] = demiss_toy_step(device)
             extra["hepmass_missiwae"] = missiwae_step(device, "UCI-hepmass", 4096, 21, 16, (42, 165, 2, 256), (16, 42, 2, 256))

@@ -5,3 +5,4 @@ from ._lib import lib, lib_path  # noqa: F401
 from .mlp import NetDims, PackedNet, ResidualMLPFunction, mlp_forward, mlp_backward, make_keep_masks  # noqa: F401
 from .objectives import (ModelDims, estimate_elbo, estimate_iwelbo, estimate_multiple_elbo,  # noqa: F401
                          estimate_multiple_iwelbo, mvb2_objectives, cvi_objective, mvb_objective)
+from .graph import GraphedStep  # noqa: F401

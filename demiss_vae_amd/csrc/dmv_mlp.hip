@@ -557,6 +557,216 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Small batches: one workgroup (4 waves) per 32-row tile.
+//
+// With one wave per tile a network pass is a serial chain of 2 nb + 2 GEMMs (about 130 us at hidden 256) and a
+// batch of a few thousand rows leaves most SIMDs idle.  Here the four waves of a workgroup share a tile: every
+// wave holds the whole input state of a layer (B operands) but computes only TW = ceil(NT / 4) of its NT output
+// tiles, so a layer issues a quarter of the MFMAs per wave; the output slices are exchanged through LDS
+// ([tile][register quad][lane] float4: conflict-free) with one barrier pair per layer.  Same accumulation order per
+// output as the one-wave kernels (bit-identical results), same saved-activation / sign-bit layout.
+// relu networks without dropout only; anything else takes the one-wave kernels.
+// ------------------------------------------------------------------------------------------
+// up to this many 32-row tiles (one full round of 256 workgroups x 4 waves, twice over) a tile gets a whole workgroup
+#ifndef DMV_COOP_MAX_TILES
+#define DMV_COOP_MAX_TILES 512
+#endif
+
+template <int NT>
+struct Coop {
+  static constexpr int TW = (NT + 3) / 4;
+  static constexpr int LDS_BYTES = NT * 4 * 64 * 16;
+};
+
+// acc[i] (+)= W[tile t0 + i] in, i < TW (tiles past NT are skipped); fragments one group ahead
+template <int NT, bool FRESH, bool BIAS>
+__device__ __forceinline__ void coop_gemm(const f32x4* __restrict__ Wimg, const float* __restrict__ Bimg, int lane, int t0,
+                                          const f32x16 (&in)[NT], f32x16 (&acc)[Coop<NT>::TW]) {
+  constexpr int S = 4 * NT, TW = Coop<NT>::TW;
+  const uint32_t lb = (uint32_t)lane * 16u;
+  const __amdgpu_buffer_rsrc_t img = make_rsrc(Wimg, NT * S * 1024u);
+  f32x4 w[2][TW];
+  const uint32_t tile_bytes = (uint32_t)S * 1024u;
+  // tiles past NT read outside the resource and come back as zeros: their MFMAs are harmless, never stored
+#pragma unroll
+  for (int i = 0; i < TW; ++i) w[0][i] = buf_load4(img, lb, (uint32_t)(t0 + i) * tile_bytes);
+  if (BIAS) {
+    const __amdgpu_buffer_rsrc_t bimg = make_rsrc(Bimg, NT * 256u);
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+      const float bf = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bimg, (uint32_t)lane * 4u, (uint32_t)(t0 + i) * 256u, 0));
+      acc[i] = MFMA(bf, 1.f, FRESH ? zero16() : acc[i]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    if (s + 1 < S) {
+#pragma unroll
+      for (int i = 0; i < TW; ++i) w[(s + 1) & 1][i] = buf_load4(img, lb, (uint32_t)(t0 + i) * tile_bytes + (uint32_t)(s + 1) * 1024u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float b = in[s >> 2][4 * (s & 3) + e];
+#pragma unroll
+      for (int i = 0; i < TW; ++i)
+        acc[i] = MFMA(w[s & 1][i][e], b, (FRESH && !BIAS && s == 0 && e == 0) ? zero16() : acc[i]);
+    }
+  }
+}
+
+// all-gather of the waves' output slices: afterwards every wave holds all NT tiles in `full`
+template <int NT>
+__device__ __forceinline__ void coop_exchange(float* lds, int lane, int t0, const f32x16 (&slice)[Coop<NT>::TW], f32x16 (&full)[NT]) {
+  constexpr int TW = Coop<NT>::TW;
+  f32x4* L4 = (f32x4*)lds;
+  __syncthreads();                                   // previous readers are done with the buffer
+#pragma unroll
+  for (int i = 0; i < TW; ++i)
+    if (t0 + i < NT) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = slice[i][4 * q + e];
+        L4[((t0 + i) * 4 + q) * 64 + lane] = o;
+      }
+    }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = L4[(t * 4 + q) * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) full[t][4 * q + e] = v[e];
+    }
+}
+
+// slice[i] = full[wv * TW + i]: the tile number is wave-uniform but not a compile-time constant, and register
+// arrays cannot be indexed at run time, so the wave's case is picked from an unrolled loop over the four waves
+template <int NT>
+__device__ __forceinline__ void coop_own_slice(const f32x16 (&full)[NT], int wv, f32x16 (&slice)[Coop<NT>::TW]) {
+  constexpr int TW = Coop<NT>::TW;
+#pragma unroll
+  for (int ww = 0; ww < 4; ++ww)
+    if (ww == wv) {
+#pragma unroll
+      for (int i = 0; i < TW; ++i)
+        if (ww * TW + i < NT) slice[i] = full[ww * TW + i < NT ? ww * TW + i : 0];
+    }
+}
+
+// relu on a slice; with SAVE also the slice's rows of the saved activation and its sign-bit word
+template <int NT, bool SAVE>
+__device__ __forceinline__ void coop_relu_save(f32x16 (&slice)[Coop<NT>::TW], int t0, float* act_row, uint32_t* mask_row) {
+  constexpr int TW = Coop<NT>::TW;
+#pragma unroll
+  for (int i = 0; i < TW; ++i) {
+    uint32_t bits = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      slice[i][r] = __builtin_amdgcn_fmed3f(slice[i][r], 0.f, __builtin_inff());
+      bits |= (slice[i][r] > 0.f ? 1u : 0u) << r;
+    }
+    if (SAVE && t0 + i < NT) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = slice[i][4 * q + e];
+        *(f32x4*)(act_row + 32 * (t0 + i) + 8 * q) = o;
+      }
+      // word (t >> 1) holds tiles 2 (t >> 1) and 2 (t >> 1) + 1 in its low / high half
+      uint16_t* half = (uint16_t*)(mask_row + ((t0 + i) >> 1)) + ((t0 + i) & 1);
+      *half = (uint16_t)bits;
+    }
+  }
+}
+
+template <int NT, bool SAVE>
+__global__ __launch_bounds__(256, 1) void k_mlp_fwd_coop(FwdArgs a) {
+  constexpr int TW = Coop<NT>::TW, Hp = 32 * NT, MW = mask_words(NT);
+  __shared__ __attribute__((aligned(16))) float lds[Coop<NT>::LDS_BYTES / 4];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t0 = wv * TW;
+  const int64_t row0 = (int64_t)blockIdx.x * 32;
+  const int m = lane & 31, h = lane >> 5;
+  const int64_t row = row0 + m;
+  const bool live = row < a.rows;
+  const int64_t rl = live ? row : a.rows - 1;
+  const int64_t rp = (a.rows + 31) & ~(int64_t)31;
+  const int64_t act_stride = rp * Hp, mask_stride = rp * 2 * MW;
+  float* act_row = SAVE ? a.acts + row * Hp + 4 * h : nullptr;              // layer 0; + l * act_stride
+  uint32_t* mask_row = SAVE ? a.masks + (row * 2 + h) * MW : nullptr;       // layer 0; + l * mask_stride
+
+  f32x16 A[NT], T[NT], acc[TW];
+
+  // ---- initial layer: this wave's output tiles from the (tiny) network input
+  {
+    const float* B0 = a.packed + a.L.b[0];
+    const f32x4* W = (const f32x4*)(a.packed + a.L.w[0]);
+    const int S = a.L.S_in;
+    const __amdgpu_buffer_rsrc_t img = make_rsrc(W, (uint32_t)(NT * S) * 1024u);
+    const __amdgpu_buffer_rsrc_t bimg = make_rsrc(B0, NT * 256u);
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+      acc[i] = MFMA(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bimg, (uint32_t)lane * 4u, (uint32_t)(t0 + i) * 256u, 0)),
+                    1.f, zero16());
+    float* xs_row = SAVE ? a.xs + row * (32 * a.L.T_in) + 4 * h : nullptr;
+    for (int s = 0; s < S; ++s) {
+      const f32x4 b = first_layer_input4(a, rl, 8 * s + 4 * h);
+      if (SAVE && wv == 0) *(f32x4*)(xs_row + 8 * s) = b;
+      f32x4 w[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) w[i] = buf_load4(img, (uint32_t)lane * 16u, (uint32_t)((t0 + i) * S + s) * 1024u);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TW; ++i) acc[i] = MFMA(w[i][e], b[e], acc[i]);
+    }
+  }
+  coop_relu_save<NT, SAVE>(acc, t0, act_row, mask_row);
+  coop_exchange<NT>(lds, lane, t0, acc, A);
+
+  // ---- residual blocks
+  for (int blk = 0; blk < a.nb; ++blk) {
+    const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
+    coop_gemm<NT, true, true>((const f32x4*)(a.packed + a.L.w[l1]), a.packed + a.L.b[l1], lane, t0, A, acc);
+    coop_relu_save<NT, SAVE>(acc, t0, act_row + l1 * act_stride, mask_row + l1 * mask_stride);
+    coop_exchange<NT>(lds, lane, t0, acc, T);
+    // this wave's slice of the residual stream becomes the accumulator of the second GEMM
+    coop_own_slice<NT>(A, wv, acc);
+    coop_gemm<NT, false, true>((const f32x4*)(a.packed + a.L.w[l2]), a.packed + a.L.b[l2], lane, t0, T, acc);
+    coop_relu_save<NT, SAVE>(acc, t0, act_row + l2 * act_stride, mask_row + l2 * mask_stride);
+    coop_exchange<NT>(lds, lane, t0, acc, A);
+  }
+
+  // ---- final layer: output tiles round-robin over the waves
+  {
+    const int lf = a.L.nl - 1;
+    const f32x4* W = (const f32x4*)(a.packed + a.L.w[lf]);
+    const float* Bf = a.packed + a.L.b[lf];
+    constexpr int S = 4 * NT;
+    uint32_t nomask[MW];
+    for (int ot = wv; ot < a.L.OT; ot += 4) {
+      f32x16 o16 = MFMA(Bf[ot * 64 + lane], 1.f, zero16());
+      gemm_h1<NT, false, false, IN_ASIS>(W + (int64_t)ot * S * 64, lane, A, o16, nullptr, 0u, nullptr, nomask, 1.f);
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = o16[4 * q + e];
+          *(f32x4*)(a.y + row * a.ldy + 32 * ot + 8 * q + 4 * h) = o;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward: input-gradient chain (writes the per-layer output gradients the weight-gradient
 // GEMMs consume)
 // ------------------------------------------------------------------------------------------
@@ -713,6 +923,102 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
   }
   TRACE(15);
   TRACE_REAL(14);
+}
+
+// relu backward on a slice (sign bits of the saved activation of that layer), then its rows of the layer-gradient
+// buffer
+template <int NT>
+__device__ __forceinline__ void coop_mask_store(f32x16 (&slice)[Coop<NT>::TW], int t0, const uint32_t* mask_row, float scale,
+                                                float* dact_row) {
+  constexpr int TW = Coop<NT>::TW;
+#pragma unroll
+  for (int i = 0; i < TW; ++i)
+    if (t0 + i < NT) {
+      const uint32_t bits = ((const uint16_t*)mask_row)[t0 + i];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slice[i][r] = ((bits >> r) & 1u) ? slice[i][r] * scale : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = slice[i][4 * q + e];
+        *(f32x4*)(dact_row + 32 * (t0 + i) + 8 * q) = o;
+      }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k_mlp_bwd_coop(BwdArgs a) {
+  constexpr int TW = Coop<NT>::TW, Hp = 32 * NT, MW = mask_words(NT);
+  __shared__ __attribute__((aligned(16))) float lds[Coop<NT>::LDS_BYTES / 4];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t0 = wv * TW;
+  const int64_t row0 = (int64_t)blockIdx.x * 32;
+  const int m = lane & 31, h = lane >> 5;
+  const int64_t row = row0 + m;
+  const bool live = row < a.rows;
+  const int64_t rl = live ? row : a.rows - 1;
+  const int64_t rp = (a.rows + 31) & ~(int64_t)31;
+  const int64_t act_stride = rp * Hp, mask_stride = rp * 2 * MW;
+  const int lf = a.L.nl - 1;
+  float* dact_row = a.dacts + row * Hp + 4 * h;
+  const uint32_t* mask_row = a.masks + (row * 2 + h) * MW;
+  const float dscale = a.drop_keep ? a.drop_scale : 1.f;
+
+  f32x16 dA[NT], dT[NT], acc[TW];
+  // ---- this wave's tiles of Wf^T gy
+  {
+    const f32x4* W = (const f32x4*)(a.packed + a.L.wt[lf]);
+    const int S = a.L.S_out;
+    const __amdgpu_buffer_rsrc_t img = make_rsrc(W, (uint32_t)(NT * S) * 1024u);
+    const float* gyr = a.gy + rl * a.ldgy + 4 * h;
+#pragma unroll
+    for (int i = 0; i < TW; ++i) acc[i] = zero16();
+    for (int s = 0; s < S; ++s) {
+      f32x4 b = *(const f32x4*)(gyr + 8 * s);
+      if (!live) b = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 w[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) w[i] = buf_load4(img, (uint32_t)lane * 16u, (uint32_t)((t0 + i) * S + s) * 1024u);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TW; ++i) acc[i] = MFMA(w[i][e], b[e], acc[i]);
+    }
+  }
+  coop_mask_store<NT>(acc, t0, mask_row + (lf - 1) * mask_stride, 1.f, dact_row + (lf - 1) * act_stride);
+  coop_exchange<NT>(lds, lane, t0, acc, dA);
+
+  for (int blk = a.nb - 1; blk >= 0; --blk) {
+    const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
+    coop_gemm<NT, true, false>((const f32x4*)(a.packed + a.L.wt[l2]), nullptr, lane, t0, dA, acc);
+    coop_mask_store<NT>(acc, t0, mask_row + l1 * mask_stride, dscale, dact_row + l1 * act_stride);
+    coop_exchange<NT>(lds, lane, t0, acc, dT);
+    coop_own_slice<NT>(dA, wv, acc);                                        // skip path
+    coop_gemm<NT, false, false>((const f32x4*)(a.packed + a.L.wt[l1]), nullptr, lane, t0, dT, acc);
+    coop_mask_store<NT>(acc, t0, mask_row + (l1 - 1) * mask_stride, 1.f, dact_row + (l1 - 1) * act_stride);
+    coop_exchange<NT>(lds, lane, t0, acc, dA);
+  }
+
+  if (a.dx) {
+    const f32x4* W = (const f32x4*)(a.packed + a.L.wt[0]);
+    constexpr int S = 4 * NT;
+    uint32_t nomask[MW];
+    for (int it = wv; it < a.L.T_in; it += 4) {
+      f32x16 o16 = zero16();
+      gemm_h1<NT, false, false, IN_ASIS>(W + (int64_t)it * S * 64, lane, dA, o16, nullptr, 0u, nullptr, nomask, 1.f);
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = o16[4 * q + e];
+          *(f32x4*)(a.dx + row * a.lddx + 32 * it + 8 * q + 4 * h) = o;
+        }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -951,6 +1257,13 @@ template <int NT>
 static int launch_fwd(const FwdArgs& a, hipStream_t st) {
   const int64_t waves = (a.rows + 31) / 32;
   const unsigned grid = (unsigned)((waves + 3) / 4);
+  // small batches: four waves per 32-row tile (relu, no dropout)
+  if (a.act == DMV_ACT_RELU && !a.drop_keep && waves <= DMV_COOP_MAX_TILES) {
+    if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_coop<NT, true>), dim3((unsigned)waves), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_mlp_fwd_coop<NT, false>), dim3((unsigned)waves), dim3(256), 0, st, a);
+    DMV_HIP_CHECK_LAUNCH();
+    return DMV_OK;
+  }
   // the dropout-specialised kernel reads 4 keep bytes per lane and group: rows of the masks must be dword-aligned
   const bool relu = a.act == DMV_ACT_RELU;
   const int mode = !relu ? FWD_GENERIC
@@ -973,7 +1286,9 @@ template <int NT>
 static int launch_bwd(const BwdArgs& a, hipStream_t st) {
   const int64_t waves = (a.rows + 31) / 32;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  if (a.act == DMV_ACT_RELU)
+  if (a.act == DMV_ACT_RELU && waves <= DMV_COOP_MAX_TILES)
+    hipLaunchKernelGGL((k_mlp_bwd_coop<NT>), dim3((unsigned)waves), dim3(256), 0, st, a);
+  else if (a.act == DMV_ACT_RELU)
     hipLaunchKernelGGL((k_mlp_bwd<NT, true>), dim3(grid), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((k_mlp_bwd<NT, false>), dim3(grid), dim3(256), 0, st, a);

@@ -61,6 +61,11 @@ class PackedNet:
             out += [w, b]
         return out
 
+    def invalidate(self):
+        """Forget the fragment image: the next use re-packs.  Needed when the parameters changed without torch
+        noticing (an optimiser step replayed inside a captured graph does not bump tensor versions)."""
+        self._stamp = None
+
     def _current_stamp(self):
         return tuple((t.data_ptr(), t._version) for t in self.params())
 

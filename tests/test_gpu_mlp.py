@@ -66,3 +66,34 @@ def test_mlp_empty_and_errors():
     assert y.shape == (0, 4)
     with pytest.raises(RuntimeError):
         dmv.PackedNet(dmv.NetDims(4, 4, 1, 512), net.weights, net.biases)   # hidden width the kernels do not cover
+
+
+def test_small_batch_and_large_batch_kernels_agree_bitwise():
+    """Up to 512 row tiles a tile is shared by the four waves of a workgroup; beyond, one wave owns a tile for the
+    whole network.  Both accumulate every output in the same order: identical bits for outputs and input gradients
+    (the golden cases above run the small-batch kernels; this ties the large-batch ones to them)."""
+    import demiss_vae_amd as dmv
+    from demiss_vae_amd.mlp import ResidualMLPFunction
+    from oracle.recipes import NetSpec, make_params
+    import gpu_util as G
+    torch.manual_seed(0)
+    for spec in (NetSpec(16, 16, 2, 256), NetSpec(5, 4, 3, 200)):
+        p = make_params(spec, 11)
+        rows = 512 * 32 + 700                     # above the small-batch limit, ragged last tile
+        x = torch.randn(rows, spec.in_dim, device="cuda")
+        gy = torch.randn(rows, spec.out_dim, device="cuda")
+        outs = []
+        for chunks in (1, 3):
+            net = G.packed_net(spec, p)
+            ys, dxs = [], []
+            for xc, gc in zip(x.chunk(chunks), gy.chunk(chunks)):
+                xc = xc.clone().requires_grad_(True)
+                y = ResidualMLPFunction.apply(net, None, xc, *net.params())
+                y.backward(gc)
+                ys.append(y.detach())
+                dxs.append(xc.grad)
+            outs.append((torch.cat(ys), torch.cat(dxs), [w.grad.clone() for w in net.weights]))
+        (y1, dx1, gw1), (y3, dx3, gw3) = outs
+        assert torch.equal(y1, y3) and torch.equal(dx1, dx3)
+        for a, b in zip(gw1, gw3):                 # weight gradients: different row slicing, same values to rounding
+            torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * float(a.abs().max()))
