@@ -567,10 +567,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
 // output as the one-wave kernels (bit-identical results), same saved-activation / sign-bit layout.
 // relu networks without dropout only; anything else takes the one-wave kernels.
 // ------------------------------------------------------------------------------------------
-// up to this many 32-row tiles (one full round of 256 workgroups x 4 waves, twice over) a tile gets a whole workgroup
-#ifndef DMV_COOP_MAX_TILES
-#define DMV_COOP_MAX_TILES 512
-#endif
+// Which kernel family runs a batch of `tiles` 32-row tiles: the chip holds 1024 one-wave tiles or 256 four-wave
+// tiles per round, and a four-wave pass takes about a third of a one-wave pass (47 us against 140 us at hidden
+// 256), so the four-wave kernels win while ceil(tiles / 256) * 0.34 < ceil(tiles / 1024): small batches, and batches
+// just past a multiple of 1024 tiles whose last one-wave round would run almost empty.
+static inline bool dmv_use_coop(int64_t tiles) {
+  const int64_t coop_rounds = (tiles + 255) / 256, one_rounds = (tiles + 1023) / 1024;
+  return coop_rounds * 34 < one_rounds * 100;
+}
 
 template <int NT>
 struct Coop {
@@ -1258,7 +1262,7 @@ static int launch_fwd(const FwdArgs& a, hipStream_t st) {
   const int64_t waves = (a.rows + 31) / 32;
   const unsigned grid = (unsigned)((waves + 3) / 4);
   // small batches: four waves per 32-row tile (relu, no dropout)
-  if (a.act == DMV_ACT_RELU && !a.drop_keep && waves <= DMV_COOP_MAX_TILES) {
+  if (a.act == DMV_ACT_RELU && !a.drop_keep && dmv_use_coop(waves)) {
     if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_coop<NT, true>), dim3((unsigned)waves), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_mlp_fwd_coop<NT, false>), dim3((unsigned)waves), dim3(256), 0, st, a);
     DMV_HIP_CHECK_LAUNCH();
@@ -1286,7 +1290,7 @@ template <int NT>
 static int launch_bwd(const BwdArgs& a, hipStream_t st) {
   const int64_t waves = (a.rows + 31) / 32;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  if (a.act == DMV_ACT_RELU && waves <= DMV_COOP_MAX_TILES)
+  if (a.act == DMV_ACT_RELU && dmv_use_coop(waves))
     hipLaunchKernelGGL((k_mlp_bwd_coop<NT>), dim3((unsigned)waves), dim3(256), 0, st, a);
   else if (a.act == DMV_ACT_RELU)
     hipLaunchKernelGGL((k_mlp_bwd<NT, true>), dim3(grid), dim3(256), 0, st, a);

@@ -14,6 +14,7 @@ import torch.nn as nn
 try:  # pragma: no cover - depends on the environment
     import pytorch_lightning as _pl
     LightningModule = _pl.LightningModule
+    LightningDataModule = _pl.LightningDataModule
     HAVE_LIGHTNING = True
 except Exception:  # ModuleNotFoundError here; any import-time failure means "not usable"
     HAVE_LIGHTNING = False
@@ -113,5 +114,15 @@ except Exception:  # ModuleNotFoundError here; any import-time failure means "no
                                         gradient_clip_algorithm=None):
             self.clip_gradients(optimizer, gradient_clip_val=gradient_clip_val,
                                 gradient_clip_algorithm=gradient_clip_algorithm)
+
+    class LightningDataModule:
+        def __init__(self, *args, **kwargs):
+            self._hparams_store = _HParams()
+
+        @property
+        def hparams(self):
+            return self._hparams_store
+
+        save_hyperparameters = LightningModule.save_hyperparameters
 
 STEP_OUTPUT = Any

@@ -1,0 +1,347 @@
+"""Runs a reference YAML config without PyTorch Lightning (reference entry point: train.py:11-113).
+
+    python -m demiss_vae_amd.run --config configs/uci_gas/mis50/iwae_i5_encm_stl.yaml [--data.data_root DIR]
+                                 [--trainer.max_epochs N] [--trainer.max_steps N] [--any.dotted.key VALUE ...]
+
+The YAML is read as it is: `class_path` / `init_args` nodes are instantiated recursively, strings are turned into
+the enum members the constructors annotate (what jsonargparse does for the reference), `data:` builds the
+MissingDataModule, `trainer:` supplies max_epochs / max_steps / gradient clipping.  The loop is the part of
+Lightning's fit loop these models use: setup hooks, automatic or manual optimisation, per-step schedulers,
+gradient clipping through the model's hook, a validation pass per epoch, epoch means of everything passed to
+`self.log`, a final checkpoint (state_dict + hyper-parameters).  One process per GPU; under torchrun the gradients
+are all-reduced (demiss_vae_amd.parallel) and each rank trains on its own fixed part of the training split."""
+import argparse
+import enum
+import importlib
+import inspect
+import json
+import os
+import random
+import time
+import types
+
+import numpy as np
+import torch
+import yaml
+
+from . import parallel as P
+
+
+# ------------------------------------------------------------------------------------------ instantiation
+def _annotations(cls):
+    """parameter name -> annotated type (Enum classes, float, int), collected over the constructors of the whole
+    MRO (keyword arguments travel up through **kwargs)"""
+    out = {}
+    for k in inspect.getmro(cls):
+        init = k.__dict__.get("__init__")
+        if init is None:
+            continue
+        try:
+            sig = inspect.signature(init)
+        except (TypeError, ValueError):
+            continue
+        for name, p in sig.parameters.items():
+            ann = p.annotation
+            if isinstance(ann, str):
+                ann = getattr(importlib.import_module(k.__module__), ann, None)
+            if ann in (float, int) or (inspect.isclass(ann) and issubclass(ann, enum.Enum)):
+                out.setdefault(name, ann)
+    return out
+
+
+def _coerce(ann, v):
+    """what jsonargparse does with the annotation: enum members by name (or value), numbers out of the strings
+    YAML 1.1 leaves behind for literals like 1e-4"""
+    if v is None or isinstance(v, ann):
+        return v
+    if issubclass(ann, enum.Enum):
+        try:
+            return ann[v]
+        except KeyError:
+            return ann(v)
+    if ann is float and isinstance(v, (str, int)) and not isinstance(v, bool):
+        return float(v)
+    if ann is int and isinstance(v, str):
+        return int(v)
+    return v
+
+
+def instantiate(node):
+    """Builds the object a `class_path` node describes; other values pass through."""
+    if isinstance(node, dict) and "class_path" in node:
+        module, _, name = node["class_path"].rpartition(".")
+        cls = getattr(importlib.import_module(module), name)
+        return construct(cls, node.get("init_args") or {})
+    if isinstance(node, dict):
+        return {k: instantiate(v) for k, v in node.items()}
+    if isinstance(node, list):
+        return [instantiate(v) for v in node]
+    return node
+
+
+def construct(cls, kwargs):
+    ann = _annotations(cls)
+    built = {}
+    for k, v in kwargs.items():
+        v = instantiate(v)
+        built[k] = _coerce(ann[k], v) if k in ann else v
+    return cls(**built)
+
+
+def _set_dotted(cfg, dotted, value):
+    keys = dotted.split(".")
+    node = cfg
+    for k in keys[:-1]:
+        node = node.setdefault(k, {})
+    node[keys[-1]] = yaml.safe_load(value)
+
+
+def load_config(path, overrides=()):
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    for k, v in overrides:
+        _set_dotted(cfg, k, v)
+    return cfg
+
+
+# ------------------------------------------------------------------------------------------ the loop
+class _Means:
+    def __init__(self):
+        self.sum, self.n = {}, {}
+
+    def add(self, logged):
+        for k, v in logged.items():
+            v = float(v)
+            self.sum[k] = self.sum.get(k, 0.0) + v
+            self.n[k] = self.n.get(k, 0) + 1
+
+    def result(self, suffix=None):
+        return {k: self.sum[k] / self.n[k] for k in sorted(self.sum) if suffix is None or k.endswith(suffix)}
+
+
+def seed_everything(seed):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def init_distributed():
+    """joins the job torchrun started (one process per GPU, RCCL); a plain `python -m` run is a world of one"""
+    import torch.distributed as dist
+    if int(os.environ.get("WORLD_SIZE", 1)) > 1 and not dist.is_initialized():
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+
+
+def fit(model, datamodule, trainer_cfg, log=print):
+    from . import rng
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    max_epochs = trainer_cfg.get("max_epochs")
+    max_steps = trainer_cfg.get("max_steps", -1)
+    max_steps = -1 if max_steps is None else max_steps
+    clip_val, clip_alg = trainer_cfg.get("gradient_clip_val"), trainer_cfg.get("gradient_clip_algorithm")
+    datamodule.setup("fit")
+    train_loader = datamodule.train_dataloader()
+    trainer = types.SimpleNamespace(max_epochs=max_epochs, max_steps=max_steps, datamodule=datamodule,
+                                    num_training_batches=len(train_loader), accumulate_grad_batches=1)
+    model.trainer = trainer
+    model.set_datamodule(datamodule)
+    model.to(dev)
+    rng.set_seed(torch.initial_seed() + P.rank())
+    model.setup("fit")
+    conf = model.configure_optimizers()
+    opt = conf["optimizer"] if isinstance(conf, dict) else conf
+    sched = conf.get("lr_scheduler", {}).get("scheduler") if isinstance(conf, dict) else None
+    model._optimizers, model._schedulers = opt, sched
+    params = [p for g in opt.param_groups for p in g["params"]]
+    model.on_train_start()
+    step, epoch, history, t0 = 0, 0, [], time.time()
+    done = False
+    while not done and (max_epochs in (None, -1) or epoch < max_epochs):
+        model.current_epoch = epoch
+        model.train()
+        model.on_train_epoch_start()
+        means = _Means()
+        for i, batch in enumerate(train_loader):
+            model._logged = {}
+            if model.automatic_optimization:
+                loss = model.training_step(batch, i)
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                P.allreduce_grads(params)
+                model.configure_gradient_clipping(opt, 0, gradient_clip_val=clip_val, gradient_clip_algorithm=clip_alg)
+                opt.step()
+                if sched is not None:
+                    sched.step()
+            else:
+                model.training_step(batch, i)      # the model steps its optimiser itself (two-loss DeMissVAE step)
+            means.add(model._logged)
+            step += 1
+            model.global_step = step
+            if max_steps != -1 and step >= max_steps:
+                done = True
+                break
+        model.on_train_epoch_end()
+        model.eval()
+        model._logged = {}
+        vmeans = _Means()
+        with torch.no_grad():
+            for i, batch in enumerate(datamodule.val_dataloader()):
+                model._logged = {}
+                model.validation_step(batch, i)
+                vmeans.add(model._logged)
+        model.on_validation_epoch_end()
+        row = {"epoch": epoch, "step": step, "time_s": round(time.time() - t0, 2), **means.result("/train"), **vmeans.result("/val")}
+        history.append(row)
+        if P.rank() == 0:
+            log(json.dumps(row))
+        epoch += 1
+    model.on_train_end()
+    return history
+
+
+def test(model, datamodule, log=print):
+    """One pass over the test split through `test_step` (what trainer.test does for these models); returns the means
+    of everything logged, weighted by batch size."""
+    datamodule.setup("test")
+    model.eval()
+    tot, n = {}, 0
+    with torch.no_grad():
+        for i, batch in enumerate(datamodule.test_dataloader()):
+            model._logged = {}
+            model.test_step(batch, i)
+            b = batch[0].shape[0]
+            for k, v in model._logged.items():
+                tot[k] = tot.get(k, 0.0) + float(v) * b
+            n += b
+    out = {k: v / n for k, v in sorted(tot.items())}
+    if P.rank() == 0:
+        log(json.dumps(out))
+    return out
+
+
+def _plain(v):
+    if isinstance(v, enum.Enum):
+        return v.name
+    if isinstance(v, (list, tuple)):
+        return [_plain(x) for x in v]
+    return v
+
+
+def next_version_dir(exp_dir):
+    """<exp_dir>/lightning_logs/version_<n>, n = the first unused one (the layout the refit configs' model_path names)"""
+    base = os.path.join(exp_dir, "lightning_logs")
+    n = 0
+    while os.path.exists(os.path.join(base, f"version_{n}")):
+        n += 1
+    return os.path.join(base, f"version_{n}")
+
+
+def save_checkpoint(model, path, model_config=None, extra=None):
+    """state_dict + the primitive hyper-parameters + the YAML node that rebuilds the model: tensors and plain
+    containers only, so `torch.load(weights_only=True)` reads it back."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    hp = {k: _plain(v) for k, v in model.hparams.items()
+          if isinstance(v, (int, float, str, bool, type(None), enum.Enum, list, tuple))}
+    torch.save({"state_dict": model.state_dict(), "hyper_parameters": hp, "model_config": model_config, **(extra or {})}, path)
+
+
+def load_model(path, model_class=None):
+    """Rebuilds a model from a checkpoint of save_checkpoint; `model_class` (a name in vgiwae.models) replaces the
+    class the checkpoint was trained as, the way the reference's refit script picks the class to load with
+    (refit_encoder_using_iwae_and_estimate_loglik.py:100-125)."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    node = dict(ckpt["model_config"])
+    if model_class is not None:
+        # keyword arguments of a diagnostic wrapper the checkpoint was trained under mean nothing to another class
+        from vgiwae.models import _DIAGNOSTIC_KWARGS
+        keep = next((set(kw) for suffix, kw in _DIAGNOSTIC_KWARGS.items() if model_class.endswith(suffix)), set())
+        drop = set().union(*_DIAGNOSTIC_KWARGS.values()) - keep
+        node["class_path"] = "vgiwae.models." + model_class
+        node["init_args"] = {k: v for k, v in (node.get("init_args") or {}).items() if k not in drop}
+    model = instantiate(node)
+    model.load_state_dict(ckpt["state_dict"])
+    return model
+
+
+def resolve_model_path(template, exp_dir, load_best=False):
+    """fills `seed_{}` with this run's seed part and `version_{}` with the newest version on disk
+    (refit_encoder_using_iwae_and_estimate_loglik.py:103-122)"""
+    seed_part = exp_dir.split("seed_")[1].split("/")[0]
+    path = template.format(seed_part, "{}")
+    if "version_{}" in path:
+        root = path.split("version_")[0]
+        versions = sorted((int(v.split("version_")[1]) for v in os.listdir(root) if v.startswith("version_")), reverse=True)
+        if len(versions) > 1:
+            print(f"Multiple versions in {path}")
+        path = path.format(versions[0])
+    if load_best:
+        folder = path.split("last.ckpt")[0]
+        best = [m for m in os.listdir(folder) if not m.startswith("last.ckpt")]
+        assert len(best) == 1, f"Found multiple models in {folder}"
+        path = os.path.join(folder, best[0])
+    return path
+
+
+def _parse_overrides(rest):
+    overrides, it = [], iter(rest)
+    for tok in it:
+        assert tok.startswith("--"), f"unexpected argument {tok}"
+        if "=" in tok:
+            k, v = tok[2:].split("=", 1)
+        else:
+            k, v = tok[2:], next(it)
+        overrides.append((k, v))
+    return overrides
+
+
+def main(argv=None, log=print):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--config", required=True)
+    args, rest = ap.parse_known_args(argv)
+    cfg = load_config(args.config, _parse_overrides(rest))
+    init_distributed()
+    seed_everything(cfg["seed_everything"])
+    from vgiwae.data import MissingDataModule
+    trainer_cfg = dict(cfg.get("trainer") or {})
+    exp_dir = "{}/seed_m{}_d{}".format(cfg["experiment_subdir_base"], cfg["seed_everything"], cfg["data"].get("setup_seed"))
+    exp_dir = os.path.join(trainer_cfg.get("default_root_dir") or ".", exp_dir)
+    log("Experiment directory: " + exp_dir)
+    datamodule = construct(MissingDataModule, cfg["data"])
+    refit = "refit_model" in cfg
+    if refit:
+        # the reference's second entry point: refit the encoder of a trained model, then the K-sample test estimate
+        from vgiwae.test.refit_encoder_using_iwae_and_estimate_loglik import RefitEncoderUsingIWAE
+        model = construct(RefitEncoderUsingIWAE, cfg["refit_model"])
+        path = resolve_model_path(cfg["model_path"], exp_dir, cfg.get("load_best_model", False))
+        log("Using pre-trained model from: " + path)
+        model.set_model(load_model(path, cfg.get("model_class")))
+        model_config = {**torch.load(path, map_location="cpu", weights_only=True)["model_config"]}
+        if cfg.get("model_class"):
+            model_config["class_path"] = "vgiwae.models." + cfg["model_class"]
+    else:
+        model = instantiate(cfg["model"])
+        model_config = cfg["model"]
+    seed_everything(cfg["seed_everything"])      # same generator state at the start of fitting whatever was built
+    history = fit(model, datamodule, trainer_cfg, log=log)
+    results = {}
+    if refit and cfg.get("run_test", True):
+        log("Estimating test-log-likelihood.")
+        results = test(model, datamodule, log=log)
+    if P.rank() == 0:
+        out = next_version_dir(exp_dir)
+        save_checkpoint(model, os.path.join(out, "checkpoints", "last.ckpt"), model_config,
+                        {"epoch": len(history), "global_step": history[-1]["step"] if history else 0})
+        with open(os.path.join(out, "metrics.jsonl"), "w") as f:
+            for row in history:
+                f.write(json.dumps(row) + "\n")
+            if results:
+                f.write(json.dumps(results) + "\n")
+    if P.world() > 1:
+        torch.distributed.destroy_process_group()
+    return history, results
+
+
+if __name__ == "__main__":
+    main()

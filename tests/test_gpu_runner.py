@@ -1,0 +1,143 @@
+"""The YAML runner end to end on the device: a DeMissVAE config (manual optimisation, imputation buffers, grid
+marginal metric), an IWAE config (automatic optimisation, cosine schedule, clipping), then the refit-and-test config
+over the IWAE run's checkpoint (reference entry points: train.py:40-113,
+refit_encoder_using_iwae_and_estimate_loglik.py:46-138).  Data are synthetic files in a temporary directory."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_data_module import CONFIG
+
+pytestmark = pytest.mark.gpu
+
+IWAE_CONFIG = """
+seed_everything: 20220118
+experiment_subdir_base: logs/toy/iwae_i5
+data:
+  setup_seed: 20220118
+  dataset: toy_mog2_large
+  batch_size: 128
+  missingness: 'uniform'
+  total_miss_train: 0.5
+  total_miss_val: 0.5
+  pre_imputation: 'oracle'
+  pre_impute_val: false
+model:
+  class_path: vgiwae.models.IWAE
+  init_args:
+    var_latent_STL: True
+    num_latent_samples: 1
+    num_importance_samples: 5
+    lr_generator: 1e-3
+    lr_latent: 1e-3
+    use_lr_scheduler: True
+    generator_network:
+      class_path: vgiwae.shared.neural_nets.ResidualFCNetwork
+      init_args: {input_dim: 2, output_dim: 10, num_residual_blocks: 1, residual_block_dim: 64}
+    generator_distribution: normal_with_eps
+    var_latent_network:
+      class_path: vgiwae.shared.neural_nets.ResidualFCNetwork
+      init_args: {input_dim: 10, output_dim: 4, num_residual_blocks: 1, residual_block_dim: 64}
+    var_latent_distribution: normal_with_eps
+    encoder_use_mis_mask: True
+trainer:
+  max_epochs: 6
+  gradient_clip_val: 5
+  gradient_clip_algorithm: norm
+"""
+
+REFIT_CONFIG = """
+seed_everything: 20220118
+experiment_subdir_base: logs/toy/refit/iwae_i5
+data:
+  setup_seed: 20220118
+  dataset: toy_mog2_large
+  use_test_instead_train: True
+  batch_size: 128
+  test_batch_size: 50
+  missingness: 'uniform'
+  total_miss_train: 0.5
+  total_miss_val: 0.5
+  total_miss_test: 0.0
+  pre_imputation: 'oracle'
+  pre_impute_val: false
+refit_model:
+  refit_encoder_class: standard
+  var_latent_STL: True
+  num_latent_samples: 1
+  num_importance_samples: 50
+  num_test_importance_samples: 4096
+  lr_latent: 1e-4
+  amsgrad_latent: True
+  use_lr_scheduler: True
+model_class: IWAE
+model_path: ROOT/logs/toy/iwae_i5/seed_{}/lightning_logs/version_{}/checkpoints/last.ckpt
+trainer:
+  gradient_clip_val: 5
+  gradient_clip_algorithm: norm
+  max_steps: 30
+"""
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    import scipy.io as sio
+    root = tmp_path_factory.mktemp("runner")
+    r = np.random.default_rng(1)
+    (root / "data" / "toy").mkdir(parents=True)
+
+    def draw(n):                        # a 2-d latent pushed through a fixed linear map, plus noise
+        z = r.normal(size=(n, 2))
+        A = np.array([[1.0, -0.5, 0.3, 0.0, 2.0], [0.2, 1.0, -1.0, 0.7, 0.0]])
+        return (z @ A + 0.3 * r.normal(size=(n, 5))).astype(np.float32)
+    sio.savemat(root / "data" / "toy" / "data_mog2_large.mat", {"train": draw(2000), "val": draw(300), "test": draw(200)})
+    return root
+
+
+def launch(workdir, name, text, *extra):
+    from demiss_vae_amd import run
+    path = workdir / f"{name}.yaml"
+    path.write_text(text.replace("ROOT", str(workdir)))
+    lines = []
+    history, results = run.main(["--config", str(path), "--data.data_root", str(workdir / "data"),
+                                 "--trainer.default_root_dir", str(workdir), *extra], log=lines.append)
+    return history, results, lines
+
+
+def test_demissvae_config_trains(workdir):
+    history, _, lines = launch(workdir, "mvb2", CONFIG)
+    assert len(history) == 2 and history[-1]["step"] == 2 * math.ceil(history[-1]["step"] / 2)
+    for row in history:
+        assert {"mvb/train", "cvi/train", "loss/train", "marginal_logprob/val", "complete_marginal_logprob/val"} <= set(row)
+        assert all(math.isfinite(v) for v in row.values())
+    assert history[1]["loss/train"] < history[0]["loss/train"]
+    assert history[1]["marginal_logprob/val"] > history[0]["marginal_logprob/val"]
+    out = workdir / "logs/toy/mvb2/seed_m20220118_d20220118/lightning_logs/version_0"
+    ck = torch.load(out / "checkpoints" / "last.ckpt", weights_only=True)
+    assert ck["epoch"] == 2 and any(k.startswith("generator_network.") for k in ck["state_dict"])
+    assert [json.loads(l)["epoch"] for l in (out / "metrics.jsonl").read_text().splitlines()] == [0, 1]
+
+
+def test_iwae_config_then_refit_and_test_loglik(workdir):
+    history, _, _ = launch(workdir, "iwae", IWAE_CONFIG)
+    assert len(history) == 6 and history[-1]["step"] == 6 * 16
+    assert history[-1]["elbo/val"] > history[0]["elbo/val"] and history[-1]["elbo/train"] > history[0]["elbo/train"]
+
+    refit_history, results, lines = launch(workdir, "refit", REFIT_CONFIG)
+    assert any("Using pre-trained model from" in l and "version_0" in l for l in lines)
+    assert refit_history[-1]["step"] == 30                      # max_steps ends the run inside an epoch
+    ll = results["est_loglik/test"]
+    # complete test data, 4096 importance samples: above the 5-sample bound on half-missing validation data per
+    # dimension is not comparable, so compare with the complete-data 50-sample bound of the refit's training rows
+    assert math.isfinite(ll) and ll > refit_history[-1]["elbo/train"] - 0.05
+    # the generator is frozen during the refit: only the encoder moved
+    before = torch.load(workdir / "logs/toy/iwae_i5/seed_m20220118_d20220118/lightning_logs/version_0/checkpoints/last.ckpt",
+                        weights_only=True)["state_dict"]
+    after = torch.load(workdir / "logs/toy/refit/iwae_i5/seed_m20220118_d20220118/lightning_logs/version_0/checkpoints/last.ckpt",
+                       weights_only=True)["state_dict"]
+    moved = {k.split(".")[0] for k in before if not torch.equal(before[k], after[k])}
+    assert moved == {"var_latent_network"}

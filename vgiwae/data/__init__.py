@@ -4,3 +4,4 @@ from .uniform_missingness_provider import UniformMissingnessDataset, generate_un
 from .quadrant_missingness_provider import QuadrantMissingnessDataset, generate_quadrant_mask  # noqa: F401
 from .fully_missing_filter_dataset import FullyMissingDataFilter  # noqa: F401
 from .dataset_with_indices import DatasetWithIndices  # noqa: F401
+from .missing_data_module import MissingDataModule, DATASET, MISSINGNESS, PRE_IMPUTATION  # noqa: F401,E402

@@ -1,11 +1,16 @@
+from demiss_vae_amd import parallel as P
+
+
 def mvb2_manual_optimisation_step(self, enc_loss, gen_loss):
     """One optimiser step driven by two losses: the generator loss updates the decoder parameters, the encoder
-    loss the encoder parameters; then clip, step and (per-step) schedule
+    loss the encoder parameters; then (under data parallelism) average the gradients over ranks, clip, step and
+    (per-step) schedule
     (reference: vgiwae/shared/mvb2_manual_optimisation.py:1-22)."""
     opt = self.optimizers(use_pl_optimizer=True)
     opt.zero_grad()
     self.manual_backward(gen_loss, retain_graph=True, inputs=list(self.generator_network.parameters()))
     self.manual_backward(enc_loss, inputs=list(self.var_latent_network.parameters()))
+    P.allreduce_grads([p for g in opt.param_groups for p in g["params"]])
     self.configure_gradient_clipping(opt, -1, gradient_clip_val=self.hparams.mvb2_optim_gradclip_val,
                                      gradient_clip_algorithm=self.hparams.mvb2_optim_gradclip_alg)
     opt.step()
