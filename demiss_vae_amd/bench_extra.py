@@ -60,6 +60,29 @@ def missiwae_step(device, name, B, D, Zd, enc_shape, dec_shape, C=5, dropout=0.0
     return out
 
 
+def iwae_step(device, B, I=5):
+    """MissIWAE training step on UCI-gas shapes (configs/uci_gas/compare/mis50/iwae_i5_encm_stl.yaml), Adam included."""
+    from oracle.recipes import NetSpec, make_batch
+    enc_s, dec_s = NetSpec(16, 32, 2, 256), NetSpec(16, 16, 2, 256)
+    enc, dec = _packed(device, enc_s, 1, True), _packed(device, dec_s, 2, True)
+    dims = ModelDims(D=8, Zd=16, encoder_use_mis_mask=True)
+    X, M = make_batch(3, B, 8)
+    X, M = X.to(device), M.to(device)
+    opt = torch.optim.Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True, fused=True)
+
+    def step():
+        bound, _ = estimate_iwelbo(dims, enc, dec, X, M, num_importance_samples=I, STL=True)
+        opt.zero_grad(set_to_none=True)
+        (-bound).backward()
+        opt.step()
+
+    t = _sync_time(step, 30, 10)
+    macs = lambda sp: sum(n * k for n, k in sp.layer_shapes())
+    flops = 3 * 2 * B * (macs(enc_s) + I * macs(dec_s))
+    return {"workload": f"UCI-gas MissIWAE I={I} STL step incl. Adam, B={B}", "ms_per_step": round(t * 1e3, 4),
+            "samples_per_s": round(B * I / t, 1), "step_tflops": round(flops / t / 1e12, 2)}
+
+
 def demiss_toy_step(device, B=4096, K=5):
     """toy_mog2_large DeMissVAE (configs/toy_mog2_large/compare/mis50/mvb2vae_lairdmisr0_k5_stl_mlp.yaml shapes:
     D=5, Zd=2, encoder (5,4,3,200), decoder (2,10,3,200), K=5 imputations, LAIR I=1 r=0 T=1, mvb2 + STL):
@@ -93,14 +116,16 @@ def demiss_toy_step(device, B=4096, K=5):
             "samples_per_s": round(B * K / t, 1)}
 
 
-def loglik_eval_rate(device, B=50, K=50000, batches=4):
-    """Refit test step on UCI-gas shapes: B=50 test points x K=50 000 importance samples per batch.  Under data
-    parallelism every rank takes its own batches of test points (no exchange until the final mean)."""
+def loglik_eval_rate(device, B=50, K=50000, batches=4, name="gas", D=8, Zd=16, enc_shape=(16, 32, 2, 256),
+                     dec_shape=(16, 16, 2, 256), C=1):
+    """Refit test step (UCI-gas shapes by default): B=50 test points x K=50 000 importance samples per batch; C > 1:
+    a stratified-mixture encoder sampled as a plain mixture.  Under data parallelism every rank takes its own
+    batches of test points (no exchange until the final mean)."""
     from oracle.recipes import NetSpec, make_batch
-    enc_s, dec_s = NetSpec(16, 32, 2, 256), NetSpec(16, 16, 2, 256)
+    enc_s, dec_s = NetSpec(*enc_shape), NetSpec(*dec_shape)
     enc, dec = _packed(device, enc_s, 1, False), _packed(device, dec_s, 2, False)
-    dims = ModelDims(D=8, Zd=16, encoder_use_mis_mask=True)
-    X, _ = make_batch(5 + P.rank(), B, 8)
+    dims = ModelDims(D=D, Zd=Zd, encoder_use_mis_mask=True, q_dist="stratified_with_eps" if C > 1 else "normal_with_eps", C=C)
+    X, _ = make_batch(5 + P.rank(), B, D)
     X = X.to(device)
     M = torch.ones_like(X, dtype=torch.bool)
 
@@ -109,7 +134,7 @@ def loglik_eval_rate(device, B=50, K=50000, batches=4):
             imp.estimate_loglik(dims, enc, dec, X, M, num_importance_samples=K, chunk=8192)
 
     t = _sync_time(run, 2, 1)
-    return {"workload": f"refit test_step, gas shapes, B={B} x K={K} per batch", "ms_per_batch": round(t / batches * 1e3, 3),
+    return {"workload": f"refit test_step, {name} shapes, B={B} x K={K} per batch", "ms_per_batch": round(t / batches * 1e3, 3),
             "samples_per_s": round(batches * B * K / t, 1)}
 
 

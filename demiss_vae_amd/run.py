@@ -106,17 +106,19 @@ def load_config(path, overrides=()):
 
 # ------------------------------------------------------------------------------------------ the loop
 class _Means:
+    """epoch means of the logged values; tensors are summed on the device, so logging never waits for the GPU"""
+
     def __init__(self):
         self.sum, self.n = {}, {}
 
-    def add(self, logged):
+    def add(self, logged, weight=1):
         for k, v in logged.items():
-            v = float(v)
-            self.sum[k] = self.sum.get(k, 0.0) + v
-            self.n[k] = self.n.get(k, 0) + 1
+            v = v.detach().float() if isinstance(v, torch.Tensor) else float(v)
+            self.sum[k] = self.sum[k] + v * weight if k in self.sum else v * weight
+            self.n[k] = self.n.get(k, 0) + weight
 
     def result(self, suffix=None):
-        return {k: self.sum[k] / self.n[k] for k in sorted(self.sum) if suffix is None or k.endswith(suffix)}
+        return {k: float(self.sum[k]) / self.n[k] for k in sorted(self.sum) if suffix is None or k.endswith(suffix)}
 
 
 def seed_everything(seed):
@@ -206,16 +208,13 @@ def test(model, datamodule, log=print):
     of everything logged, weighted by batch size."""
     datamodule.setup("test")
     model.eval()
-    tot, n = {}, 0
+    means = _Means()
     with torch.no_grad():
         for i, batch in enumerate(datamodule.test_dataloader()):
             model._logged = {}
             model.test_step(batch, i)
-            b = batch[0].shape[0]
-            for k, v in model._logged.items():
-                tot[k] = tot.get(k, 0.0) + float(v) * b
-            n += b
-    out = {k: v / n for k, v in sorted(tot.items())}
+            means.add(model._logged, weight=batch[0].shape[0])
+    out = means.result()
     if P.rank() == 0:
         log(json.dumps(out))
     return out
