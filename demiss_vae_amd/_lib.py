@@ -65,6 +65,9 @@ SIGNATURES = {
     "dmv_obj_backward_dec": (C.c_int, [C.POINTER(DmvObjCfg), _P, _I64, _P, _P, _P, _P, _F, _F, _P, _I64, _P]),
     "dmv_obj_backward_latent": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvLatentBwd), _P, _P, _P, _I64, _P, _I64,
                                           _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dmv_obj_backward_dec_terms": (C.c_int, [C.POINTER(DmvObjCfg), _P, _I64, _P, _P, _P, _P, _P, _I64, _P]),
+    "dmv_obj_backward_latent_terms": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _P, _P, _P, _I64, _P, _I64,
+                                                _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmv_obj_implicit_ws_floats": (_SZ, [C.POINTER(DmvObjCfg), _I32]),
     "dmv_obj_backward_latent_implicit": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _P, _P, _I64, _P, _I64, _P, _F, _F, _P, _P, _P]),
     "dmv_grid_marginal_ws_floats": (_SZ, [_I64, _I32]),

@@ -367,6 +367,7 @@ struct BwdDecArgs {
   const float* X;
   const uint8_t* M;
   const float* wgt;     // nullable
+  const float* wgt_f;   // nullable: separate per-row weight of the unmasked term (wgt then weighs the masked one only)
   const float* gscale;  // nullable device scalar
   float base_m, base_f;
   float* d_dec;
@@ -387,7 +388,8 @@ __global__ void k_obj_bwd_dec(BwdDecArgs a) {
     const int64_t b = (n / a.G) % a.B;
     const int64_t xrow = a.x_per_component ? (b * a.G + g) : b;
     const float x = a.X[xrow * a.D + d];
-    const float coef = gs * (a.wgt ? a.wgt[n] : 1.f) * ((a.M[xrow * a.D + d] ? a.base_m : 0.f) + a.base_f);
+    const float wm = a.wgt ? a.wgt[n] : 1.f;
+    const float coef = gs * ((a.M[xrow * a.D + d] ? wm * a.base_m : 0.f) + (a.wgt_f ? a.wgt_f[n] : wm) * a.base_f);
     const float* dec = a.dec + n * a.ld_dec;
     float gr;
     if (normal) {
@@ -414,6 +416,7 @@ __global__ void k_obj_bwd_dec_bern4(BwdDecArgs a) {
     const int64_t b = (n / a.G) % a.B;
     const int64_t xrow = a.x_per_component ? (b * a.G + g) : b;
     const float w = gs * (a.wgt ? a.wgt[n] : 1.f);
+    const float wf = a.wgt_f ? gs * a.wgt_f[n] : w;
     const float* dec = a.dec + n * a.ld_dec;
     const float* X = a.X + xrow * a.D;
     const uint8_t* M = a.M + xrow * a.D;
@@ -427,7 +430,7 @@ __global__ void k_obj_bwd_dec_bern4(BwdDecArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = a.gen_dist == DMV_GEN_BERN ? x4[e] : (x4[e] + 1.f) * 0.5f;
-          const float coef = w * ((((m4 >> (8 * e)) & 0xffu) ? a.base_m : 0.f) + a.base_f);
+          const float coef = (((m4 >> (8 * e)) & 0xffu) ? w * a.base_m : 0.f) + wf * a.base_f;
           o[e] = coef * (v - dmv_sigmoid(l4[e]));
         }
       }
@@ -456,6 +459,8 @@ struct BwdLatArgs {
   const float* dZ;            // nullable, decoder input gradient [N][ld_dz]
   int64_t ld_dz;
   const float* wgt;           // nullable
+  const float* wgt_qown;      // nullable: per-row weight of the q_own term (wgt when null)
+  const float* wgt_qmix;      // nullable: per-row weight of the q_mix term (wgt when null)
   const float* zscale;        // nullable
   const float* comp_lp;       // [N][G] when base_qmix != 0
   const float* qmix;          // terms[4]
@@ -497,7 +502,7 @@ __global__ void k_obj_bwd_latent(BwdLatArgs a) {
       for (int s = 0; s < a.S; ++s)
         for (int g = 0; g < a.G; ++g) {
           const int64_t n = ((int64_t)s * a.B + b) * a.G + g;
-          const float cw = a.base_qmix * (a.wgt ? a.wgt[n] : 1.f);
+          const float cw = a.base_qmix * (a.wgt_qmix ? a.wgt_qmix[n] : a.wgt ? a.wgt[n] : 1.f);
           const float r = expf(logpi(gp) + a.comp_lp[n * a.G + gp] - a.qmix[n]);
           acc += cw * (r - pi);
         }
@@ -515,10 +520,11 @@ __global__ void k_obj_bwd_latent(BwdLatArgs a) {
     {
       const int64_t n = ((int64_t)s * a.B + b) * a.G + gp;
       const float w = a.wgt ? a.wgt[n] : 1.f;
+      const float wo = a.wgt_qown ? a.wgt_qown[n] : w;
       const float z = a.Z[n * a.ldz + j];
       float dz = a.dZ ? a.dZ[n * a.ld_dz + j] : 0.f;
       dz += a.base_prior * w * (-z);
-      if (a.base_qown != 0.f) dz += a.base_qown * w * (-(z - mu) / (sg * sg));
+      if (a.base_qown != 0.f) dz += a.base_qown * wo * (-(z - mu) / (sg * sg));
       if (has_mix) {
         float t = 0.f;
         for (int c = 0; c < a.G; ++c) {
@@ -526,7 +532,7 @@ __global__ void k_obj_bwd_latent(BwdLatArgs a) {
           const float mc = q_mu(a.enc, a.q, b, c, j), sc = q_sigma(a.enc, a.q, b, c, j);
           t += r * (-(z - mc) / (sc * sc));
         }
-        dz += a.base_qmix * w * t;
+        dz += a.base_qmix * (a.wgt_qmix ? a.wgt_qmix[n] : w) * t;
       }
       if (a.use_zscale && a.zscale) dz *= a.zscale[n];
       acc_mu += dz;
@@ -534,15 +540,15 @@ __global__ void k_obj_bwd_latent(BwdLatArgs a) {
       // (2) direct dependence of log q_own on its parameters
       if (a.own_live && a.base_qown != 0.f) {
         const float df = z - mu;
-        acc_mu += a.base_qown * w * (df / (sg * sg));
-        acc_sg += a.base_qown * w * (df * df / (sg * sg * sg) - 1.f / sg);
+        acc_mu += a.base_qown * wo * (df / (sg * sg));
+        acc_sg += a.base_qown * wo * (df * df / (sg * sg * sg) - 1.f / sg);
       }
     }
     // (3) direct dependence of log q_mix (evaluated at every sample of the datapoint) on component gp
     if (has_mix && a.mix_live) {
       for (int g = 0; g < a.G; ++g) {
         const int64_t n = ((int64_t)s * a.B + b) * a.G + g;
-        const float w = a.wgt ? a.wgt[n] : 1.f;
+        const float w = a.wgt_qmix ? a.wgt_qmix[n] : a.wgt ? a.wgt[n] : 1.f;
         const float z = a.Z[n * a.ldz + j];
         const float r = expf(logpi(gp) + a.comp_lp[n * a.G + gp] - a.qmix[n]);
         const float df = z - mu;
@@ -944,9 +950,9 @@ extern "C" int dmv_kl_std_normal(const DmvObjCfg* cfg, const float* enc, float* 
   return DMV_OK;
 }
 
-extern "C" int dmv_obj_backward_dec(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec, const float* X,
-                                    const uint8_t* M, const float* wgt, const float* gscale, float base_m, float base_f,
-                                    float* d_dec, int64_t ld_ddec, void* stream) {
+static int backward_dec(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec, const float* X, const uint8_t* M,
+                        const float* wgt, const float* wgt_f, const float* gscale, float base_m, float base_f,
+                        float* d_dec, int64_t ld_ddec, void* stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (!dec || !X || !M || !d_dec) return DMV_E_BADARG;
@@ -955,7 +961,7 @@ extern "C" int dmv_obj_backward_dec(const DmvObjCfg* cfg, const float* dec, int6
   BwdDecArgs a;
   a.N = nrows(cfg); a.B = cfg->B; a.G = cfg->G; a.D = cfg->D;
   a.gen_dist = cfg->gen_dist; a.x_per_component = cfg->x_per_component;
-  a.dec = dec; a.ld_dec = ld_dec; a.X = X; a.M = M; a.wgt = wgt; a.gscale = gscale;
+  a.dec = dec; a.ld_dec = ld_dec; a.X = X; a.M = M; a.wgt = wgt; a.wgt_f = wgt_f; a.gscale = gscale;
   a.base_m = base_m; a.base_f = base_f; a.d_dec = d_dec; a.ld_ddec = ld_ddec;
   const bool vec4 = cfg->gen_dist >= DMV_GEN_BERN && cfg->D >= 64 && (cfg->D & 3) == 0 && (ld_dec & 3) == 0 && (ld_ddec & 3) == 0 &&
                     ((((uintptr_t)dec | (uintptr_t)X | (uintptr_t)d_dec) & 15) == 0) && (((uintptr_t)M & 3) == 0);
@@ -970,11 +976,24 @@ extern "C" int dmv_obj_backward_dec(const DmvObjCfg* cfg, const float* dec, int6
   return DMV_OK;
 }
 
-extern "C" int dmv_obj_backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const float* enc, const float* Z,
-                                       const float* eps, int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
-                                       const float* zscale, const float* comp_lp, const float* qmix,
-                                       const float* dlogit, const float* kl_wgt, const float* gscale, float* d_enc,
-                                       void* stream) {
+extern "C" int dmv_obj_backward_dec(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec, const float* X,
+                                    const uint8_t* M, const float* wgt, const float* gscale, float base_m, float base_f,
+                                    float* d_dec, int64_t ld_ddec, void* stream) {
+  return backward_dec(cfg, dec, ld_dec, X, M, wgt, nullptr, gscale, base_m, base_f, d_dec, ld_ddec, stream);
+}
+
+extern "C" int dmv_obj_backward_dec_terms(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec, const float* X,
+                                          const uint8_t* M, const float* g_masked, const float* g_full, float* d_dec,
+                                          int64_t ld_ddec, void* stream) {
+  if (!g_masked || !g_full) return DMV_E_BADARG;
+  return backward_dec(cfg, dec, ld_dec, X, M, g_masked, g_full, nullptr, 1.f, 1.f, d_dec, ld_ddec, stream);
+}
+
+static int backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const float* enc, const float* Z,
+                           const float* eps, int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
+                           const float* wgt_qown, const float* wgt_qmix, const float* zscale, const float* comp_lp,
+                           const float* qmix, const float* dlogit, const float* kl_wgt, const float* gscale, float* d_enc,
+                           void* stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (!p || !enc || !Z || !eps || !d_enc || ldz < cfg->Zd) return DMV_E_BADARG;
@@ -986,12 +1005,36 @@ extern "C" int dmv_obj_backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd*
   a.base_prior = p->base_prior; a.base_qown = p->base_qown; a.base_qmix = p->base_qmix; a.base_w = p->base_w;
   a.own_live = p->own_live; a.mix_live = p->mix_live; a.use_zscale = p->use_zscale; a.kl_coef = p->kl_coef;
   a.enc = enc; a.Z = Z; a.eps = eps; a.ldz = ldz; a.dZ = dZ; a.ld_dz = ld_dz;
-  a.wgt = wgt; a.zscale = zscale; a.comp_lp = comp_lp; a.qmix = qmix; a.dlogit = dlogit; a.kl_wgt = kl_wgt; a.gscale = gscale;
+  a.wgt = wgt; a.wgt_qown = wgt_qown; a.wgt_qmix = wgt_qmix;
+  a.zscale = zscale; a.comp_lp = comp_lp; a.qmix = qmix; a.dlogit = dlogit; a.kl_wgt = kl_wgt; a.gscale = gscale;
   a.d_enc = d_enc;
   const int64_t work = (int64_t)cfg->B * cfg->G * (cfg->Zd + 1);
   hipLaunchKernelGGL(k_obj_bwd_latent, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
+}
+
+extern "C" int dmv_obj_backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const float* enc, const float* Z,
+                                       const float* eps, int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
+                                       const float* zscale, const float* comp_lp, const float* qmix,
+                                       const float* dlogit, const float* kl_wgt, const float* gscale, float* d_enc,
+                                       void* stream) {
+  return backward_latent(cfg, p, enc, Z, eps, ldz, dZ, ld_dz, wgt, nullptr, nullptr, zscale, comp_lp, qmix, dlogit, kl_wgt,
+                         gscale, d_enc, stream);
+}
+
+extern "C" int dmv_obj_backward_latent_terms(const DmvObjCfg* cfg, int32_t mix_kind, int32_t q_live, const float* enc,
+                                             const float* Z, const float* eps, int64_t ldz, const float* dZ, int64_t ld_dz,
+                                             const float* g_prior, const float* g_qown, const float* g_qmix,
+                                             const float* zscale, const float* comp_lp, const float* qmix, float* d_enc,
+                                             void* stream) {
+  if (!g_prior || !g_qown || !g_qmix || !comp_lp || !qmix) return DMV_E_BADARG;
+  if (mix_kind != DMV_Q_IMPUTATION && mix_kind != DMV_Q_STRATIFIED) return DMV_E_BADARG;
+  DmvLatentBwd p;
+  p.base_prior = 1.f; p.base_qown = 1.f; p.base_qmix = 1.f; p.base_w = 0.f; p.kl_coef = 0.f;
+  p.own_live = q_live; p.mix_live = q_live; p.use_zscale = zscale ? 1 : 0; p.mix_kind = mix_kind;
+  return backward_latent(cfg, &p, enc, Z, eps, ldz, dZ, ld_dz, g_prior, g_qown, g_qmix, zscale, comp_lp, qmix, nullptr,
+                         nullptr, nullptr, d_enc, stream);
 }
 
 extern "C" int dmv_lse_update(int32_t B, int64_t Kc, const float* terms, int32_t q_term, float* run_max, float* run_sum,

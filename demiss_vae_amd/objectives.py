@@ -79,7 +79,7 @@ def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, 
     lib = L.lib()
     st = L.stream_ptr()
     dev = X.device
-    demiss = plan.kind in ("mvb2", "cvi", "mvb")
+    demiss = plan.kind in ("mvb2", "cvi", "mvb", "terms")
     c = _Ctx()
     if demiss:
         B, K, D = X.shape
@@ -140,7 +140,7 @@ def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, 
     else:
         q_kind, mix_C = L.Q_OWN, 1
     terms = torch.empty((5, N), dtype=torch.float32, device=dev)
-    need_comp = training and q_kind != L.Q_OWN and plan.kind in ("miwae", "cvi")
+    need_comp = training and q_kind != L.Q_OWN and plan.kind in ("miwae", "cvi", "terms")
     comp_lp = torch.empty((N, mix_C), dtype=torch.float32, device=dev) if need_comp else None
     L.check(lib.dmv_obj_terms(C.byref(cfg), q_kind, mix_C, L.ptr(dec_out), dec_out.shape[1], L.ptr(Xc), L.ptr(Mu),
                               L.ptr(Z), Zd, L.ptr(enc_out), L.ptr(terms), L.ptr(comp_lp), st))
@@ -354,6 +354,74 @@ class _FusedObjective(torch.autograd.Function):
                     p = _latent_params(prior=1.0, qown=-1.0, own_live=not plan.STL)
                     g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, None)
         return (None,) * 10 + tuple(g_enc_params) + tuple(g_dec_params)
+
+
+class _DemissTerms(torch.autograd.Function):
+    """The five per-sample terms [5, nz, I, B, K] as differentiable outputs; the caller composes its objective from
+    them with ordinary tensor operations (tiny next to the networks) and the backward turns the terms' cotangents
+    into network gradients through the kernels.  split: two copies, the first carrying gradient to the decoder
+    parameters only, the second to the encoder parameters only (through the decoder's input gradient)."""
+
+    @staticmethod
+    def forward(ctx, dims, nz, I, q_live, split, enc, dec, Xt, M, eps, enc_keep, dec_keep, *params):
+        training = any(ctx.needs_input_grad[12:])
+        plan = _Plan("terms", nz, I)
+        c = _forward_core(dims, plan, enc, dec, Xt, M, eps, enc_keep, dec_keep, training)
+        ctx.c, ctx.enc, ctx.dec, ctx.q_live, ctx.split = c, enc, dec, q_live, split
+        ctx.set_materialize_grads(False)
+        shape = (5, nz, I, c.B, c.G)
+        if split:
+            return c.terms.clone().view(shape), c.terms.view(shape)
+        return (c.terms.view(shape),)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        c, enc, dec = ctx.c, ctx.enc, ctx.dec
+        lib, st = L.lib(), L.stream_ptr()
+        g_enc_params = [None] * (2 * enc.dims.num_layers)
+        g_dec_params = [None] * (2 * dec.dims.num_layers)
+
+        def dec_cotangent(g):
+            d_dec = torch.empty_like(c.dec_out)
+            L.check(lib.dmv_obj_backward_dec_terms(C.byref(c.cfg), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
+                                                   L.ptr(g[0]), L.ptr(g[1]), L.ptr(d_dec), d_dec.shape[1], st))
+            return d_dec
+
+        def encoder_grads(g, dZ):
+            d_enc = torch.zeros_like(c.enc_out)
+            L.check(lib.dmv_obj_backward_latent_terms(
+                C.byref(c.cfg), L.Q_IMPUTATION, int(ctx.q_live), L.ptr(c.enc_out), L.ptr(c.Z), L.ptr(c.eps), c.Z.shape[1],
+                L.ptr(dZ), dZ.shape[1], L.ptr(g[2]), L.ptr(g[3]), L.ptr(g[4]), None, L.ptr(c.comp_lp),
+                L.ptr(c.terms[4]), L.ptr(d_enc), st))
+            return mlp_backward(enc, c.enc_saved, d_enc, c.enc_rows, need_dx=False, need_param_grads=True,
+                                drop_keep=c.enc_keep)[1]
+
+        flat = [None if g is None else g.reshape(5, -1).float().contiguous() for g in gouts]
+        if ctx.split:
+            if flat[0] is not None:
+                _, g_dec_params = mlp_backward(dec, c.dec_saved, dec_cotangent(flat[0]), c.N, need_dx=False,
+                                               need_param_grads=True, drop_keep=c.dec_keep)
+            if flat[1] is not None:
+                dZ, _ = mlp_backward(dec, c.dec_saved, dec_cotangent(flat[1]), c.N, need_dx=True, need_param_grads=False,
+                                     drop_keep=c.dec_keep)
+                g_enc_params = encoder_grads(flat[1], dZ)
+        elif flat[0] is not None:
+            dZ, g_dec_params = mlp_backward(dec, c.dec_saved, dec_cotangent(flat[0]), c.N, need_dx=True, need_param_grads=True,
+                                            drop_keep=c.dec_keep)
+            g_enc_params = encoder_grads(flat[0], dZ)
+        return (None,) * 12 + tuple(g_enc_params) + tuple(g_dec_params)
+
+
+def demiss_terms(dims, enc, dec, Xt, M, *, num_latent_samples=1, num_importance_samples=1, q_live=True, split=False, eps=None,
+                 enc_keep=None, dec_keep=None):
+    """Per-sample terms of imputed batches Xt, M [B, K, D] with latent samples of shape [nz, I, B, K] (eps
+    [nz, I, B, K, Zd]): a tensor [5, nz, I, B, K] holding sum_d M log p(x_d|z), sum_d log p(x_d|z), log p(z),
+    log q_bk(z) and log (1/K) sum_k' q_bk'(z) (vgiwae/shared/iwae.py:17-45, 66-90, 102-132).  q_live False treats q's
+    parameters as constants inside the two q terms ("sticking the landing" / doubly reparameterised estimators).
+    Returns (terms,) or, with split, (terms_for_decoder, terms_for_encoder)."""
+    assert not dims.q_is_mixture and not dims.q_is_reparam
+    return _DemissTerms.apply(dims, num_latent_samples, num_importance_samples, q_live, split, enc, dec, Xt, M, eps,
+                              enc_keep, dec_keep, *enc.params(), *dec.params())
 
 
 def _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx=None):

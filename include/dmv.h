@@ -193,6 +193,22 @@ int dmv_obj_backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const f
                             const float* zscale, const float* comp_lp, const float* qmix, const float* dlogit,
                             const float* kl_wgt, const float* gscale, float* d_enc, void* stream);
 
+/* Backward from per-term cotangents, for objectives composed by the caller out of the five terms of dmv_obj_terms
+ * (the importance-weighted DeMissVAE family, vgiwae/models/mvbiwae.py:97-565, combines them in a dozen ways).
+ * Decoder side:  d_dec[n][c] = (g_masked[n] * M_d + g_full[n]) * d log p(x_d|z)/d dec[n][c]
+ *   with g_masked / g_full [N] = d loss / d terms[0] / terms[1].
+ * Latent side: gradient w.r.t. the encoder output of
+ *   sum_n g_prior[n]*terms[2][n] + g_qown[n]*terms[3][n] + g_qmix[n]*terms[4][n]  + (decoder path, given as dZ)
+ *   through z = mu + sigma*eps (all of it times zscale[n] when zscale is given: the weight hook of the doubly
+ *   reparameterised estimator, models/mvbiwae.py:103-114) and, when q_live, through q's own parameters.
+ *   mix_kind DMV_Q_IMPUTATION or DMV_Q_STRATIFIED; comp_lp / qmix as produced by dmv_obj_terms. */
+int dmv_obj_backward_dec_terms(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec, const float* X, const uint8_t* M,
+                               const float* g_masked, const float* g_full, float* d_dec, int64_t ld_ddec, void* stream);
+int dmv_obj_backward_latent_terms(const DmvObjCfg* cfg, int32_t mix_kind, int32_t q_live, const float* enc,
+                                  const float* Z, const float* eps, int64_t ldz, const float* dZ, int64_t ld_dz,
+                                  const float* g_prior, const float* g_qown, const float* g_qmix, const float* zscale,
+                                  const float* comp_lp, const float* qmix, float* d_enc, void* stream);
+
 /* Latent-side backward for a mixture encoder sampled ancestrally with implicit reparameterisation gradients
  * (vgiwae/shared/reparametrized_mixture_same_family.py:27-191 rsample + _distributional_transform; used by the
  * reparametrised_mixture* variational families, vgiwae/models/vae.py:108-260).  Rows n = s*B + b (G must be 1),

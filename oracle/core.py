@@ -325,6 +325,72 @@ def mvb_objective(spec: ModelSpec, enc_params, dec_params, Xt, M, eps, *, STL=Fa
     return (full + prior - lq).mean(0)
 
 
+def mvbiwae_objectives(spec: ModelSpec, enc_params, dec_params, Xt, M, eps, *, objective, enc_isweights="dmmis",
+                       dec_isweights="dmmis", STL=False, DREG=False, resample_idx=None, enc_masks=None, dec_masks=None):
+    """Importance-weighted DeMissVAE objectives, vgiwae/models/mvbiwae.py:97-650.  Xt, M [B,K,D], eps [nz,I,B,K,Zd].
+    Returns per-datapoint (generator objective [B], encoder objective [B]); the single-objective variants
+    (mvb_* / cvi_*) return the same tensor twice.
+
+    Importance weights: "smis" uses log q_bk(z), "dmmis" the uniform mixture over the K imputations' posteriors.
+    "all" pools the I*K samples of a datapoint in one logsumexp, "indep" takes one logsumexp over I per imputation
+    and averages over K.  The weighted variants keep the value logsumexp(a) of the masked ("marginal") weights a but
+    take the gradient of the complete-data weights under softmax(a); with DREG they add the score-function
+    correction -(1 - w)w d a (mvbiwae.py:382-392).  The weight hook on Z the reference prepares is never
+    installed (its log_weights_to_iwelbo is called without var_latent_DREG, models/iwae.py:70-81), so DREG only
+    detaches q here."""
+    Mf = M.to(Xt.dtype)
+    p = _encode(spec, enc_params, Xt, M, enc_masks)
+    mu, sigma, _ = q_heads(spec, p)
+    Z = mu + sigma * eps                                              # [nz, I, B, K, Zd]
+    g = mlp_forward(dec_params, Z, spec.dec, dec_masks)
+    lp = gen_logprob(spec, g, Xt)
+    gen_marg, gen_full = (lp * Mf).sum(-1), lp.sum(-1)
+    prior = log_std_normal(Z).sum(-1)
+    mq, sq = (mu.detach(), sigma.detach()) if (STL or DREG) else (mu, sigma)
+    lq = {"smis": log_normal(Z, mq, sq).sum(-1), "dmmis": imputation_mixture_logprob(Z, mq, sq)}
+    nz, I, B, K = prior.shape
+
+    def pooled(lw):                                                   # [nz, I, B, K] -> [nz, I*K, B]
+        return lw.permute(0, 1, 3, 2).reshape(nz, I * K, B)
+
+    def bound(lw, how):
+        if how == "all":
+            return (torch.logsumexp(pooled(lw), dim=1) - math.log(I * K)).mean(0)
+        return (torch.logsumexp(lw, dim=1) - math.log(I)).mean((0, 2))
+
+    if objective in ("mvb_indep", "mvb_all", "cvi_indep", "cvi_all"):
+        assert enc_isweights == dec_isweights
+        gen = gen_full if objective.startswith("mvb") else gen_marg
+        out = bound(gen + prior - lq[enc_isweights], objective.split("_")[1])
+        return out, out
+    lw_marg = gen_marg + prior - lq[dec_isweights]
+    lw_full = gen_full + prior - lq[enc_isweights]
+    plain = {"mvb2_encindep_decall": ("all", "indep"), "mvb2_encindep_decindep": ("indep", "indep"),
+             "mvb2_encall_decall": ("all", "all")}
+    if objective in plain:
+        dec_how, enc_how = plain[objective]
+        return bound(lw_marg, dec_how), bound(lw_full, enc_how)
+    weighted = {"mvb2_encallweightedsmis_decall": "smis", "mvb2_encallweighteddmmis_decall": "dmmis",
+                "mvb2_encallweighteddmmis_decallresampl": "dmmis", "mvb2_all_encweighteddmmis_decweighteddmmis": "dmmis"}
+    gw = gen_marg + prior - lq[weighted[objective]]                   # weights that re-weight the gradient
+    enc_obj = bound(gw.detach() - lw_full.detach() + lw_full, "all")
+    if DREG:
+        a = pooled(gw)
+        w = torch.softmax(a, dim=1)
+        v = (((1 - w) * w).detach() * a).sum(1).mean(0)
+        enc_obj = enc_obj - v + v.detach()
+    if objective == "mvb2_all_encweighteddmmis_decweighteddmmis":
+        gen_obj = bound(gw.detach() - lw_full.detach() + lw_full, "all")     # the un-corrected value, both networks
+    elif objective.endswith("resampl"):
+        flat = lw_marg.permute(0, 2, 1, 3).reshape(nz, B, I * K)             # [nz, B, (i k)]
+        assert nz == 1, "the reference's gather only broadcasts for one outer sample"
+        picked = torch.gather(flat.expand(resample_idx.shape[0], nz, B, I * K), -1, resample_idx.unsqueeze(-1)).squeeze(-1)
+        gen_obj = picked.mean((0, 1))
+    else:
+        gen_obj = bound(lw_marg, "all")
+    return gen_obj, enc_obj
+
+
 # --------------------------------------------------------------------------------------
 # Imputation samplers
 # --------------------------------------------------------------------------------------

@@ -237,3 +237,79 @@ def test_short_training_run_learns():
             first = loss.item() if first is None else 0.9 * first + 0.1 * loss.item()
         last = loss.item() if last is None else 0.9 * last + 0.1 * loss.item()
     assert last < first - 1.0, (first, last)
+
+
+@pytest.mark.parametrize("name", gu.names("mvbiwae_"))
+def test_mvbiwae_class_matches_reference(name):
+    """every objective variant of the importance-weighted DeMissVAE: values and both networks' gradients"""
+    from vgiwae.models import IS_WEIGHTS, MVB_IWAE_OBJ
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(dict(g, gen_dist="normal", q_dist="normal", mask_concat=False))
+    objective = str(g["objective"])
+    model = _build("MVBIWAE", spec, enc_p, dec_p, num_latent_samples=int(g["nz"]), num_importance_samples=int(g["I"]),
+                   var_latent_STL=bool(g["STL"]), var_latent_DREG=bool(g["DREG"]), mvb_objective=MVB_IWAE_OBJ[objective],
+                   enc_isweights=IS_WEIGHTS[str(g["enc_w"])], dec_isweights=IS_WEIGHTS[str(g["dec_w"])])
+    assert model.automatic_optimization is not objective.startswith("mvb2")
+    Xt, Mk, eps = (torch.from_numpy(g[k]).cuda() for k in ("Xt", "M", "eps"))
+    if objective.startswith("mvb2"):
+        ridx = torch.from_numpy(g["resample_idx"]).cuda() if "resample_idx" in g else None
+        gen_obj, enc_obj = model.estimate_mvb2_objectives(Xt, Mk, eps=eps, resample_idx=ridx)
+        (-gen_obj.mean()).backward(retain_graph=True, inputs=list(model.generator_network.parameters()))
+        (-enc_obj.mean()).backward(inputs=list(model.var_latent_network.parameters()))
+    else:
+        fn = model.estimate_mvb_objective if objective.startswith("mvb") else model.estimate_cvi_objective
+        gen_obj = enc_obj = fn(Xt, Mk, eps=eps)
+        (-gen_obj.mean()).backward()
+    torch.testing.assert_close(gen_obj.detach().cpu(), torch.from_numpy(g["gen_obj"]), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(enc_obj.detach().cpu(), torch.from_numpy(g["enc_obj"]), rtol=1e-5, atol=1e-5)
+    assert gu.check_grads(g, "genc", _grads(model.var_latent_network, spec.enc), 1e-4, 2e-6) > 0
+    assert gu.check_grads(g, "gdec", _grads(model.generator_network, spec.dec), 1e-4, 2e-6) > 0
+
+
+def test_mvbiwae_training_steps_run_and_learn():
+    """training_step / validation_step of the importance-weighted DeMissVAE with device noise and the imputation
+    buffers: a manual-optimisation variant and a single-objective one"""
+    from types import SimpleNamespace
+    from oracle.recipes import NetSpec, make_batch, make_params
+    from oracle.core import ModelSpec
+    from vgiwae.data import DatasetWithIndices
+    from vgiwae.models import IS_WEIGHTS, MVB_IWAE_OBJ
+    from vgiwae.shared.vae_imputation import VAESampler_PseudoGibbs
+    from vgiwae.utils.imputation_distribution import IMPUTATION_INIT
+    spec = ModelSpec(D=5, Zd=2, enc=NetSpec(5, 4, 1, 32), dec=NetSpec(2, 10, 1, 32), gen_dist="normal", q_dist="normal")
+    X, M = make_batch(5, 256, 5)
+
+    class Data(torch.utils.data.Dataset):
+        def __getitem__(self, i):
+            return X.numpy()[i], M.numpy()[i]
+
+        def __len__(self):
+            return len(X)
+    for objective in ("mvb2_encallweighteddmmis_decall", "cvi_all"):
+        torch.manual_seed(0)
+        model = _build("MVBIWAE", spec, make_params(spec.enc, 1), make_params(spec.dec, 2), num_latent_samples=1,
+                       num_importance_samples=3, var_latent_STL=True, mvb_objective=MVB_IWAE_OBJ[objective],
+                       enc_isweights=IS_WEIGHTS.dmmis, dec_isweights=IS_WEIGHTS.dmmis, num_imputations_train=4,
+                       num_imputations_val=4, imputation_init_train=IMPUTATION_INIT.empirical,
+                       imputation_init_val=IMPUTATION_INIT.empirical, init_imputation_distribution=True, mvb_eval_val_loss=True,
+                       mvb_delay_imputation=0, vae_sampler=VAESampler_PseudoGibbs(num_iterations=1))
+        data = DatasetWithIndices(Data())
+        model.trainer = SimpleNamespace(datamodule=SimpleNamespace(train_data=data, val_data=data), max_epochs=1, max_steps=-1)
+        model.setup("fit")
+        opt = model.configure_optimizers()["optimizer"]
+        model._optimizers = opt
+        batch = (X.cuda(), M.cuda(), torch.arange(256).cuda())
+        losses = []
+        for step in range(40):
+            model._logged = {}
+            loss = model.training_step(batch, step)
+            if model.automatic_optimization:
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            losses.append(float(loss.detach()))
+        assert all(np.isfinite(losses)) and np.mean(losses[-5:]) < np.mean(losses[:5])
+        assert ("cvi/train" in model._logged) and "loss/train" in model._logged
+        model._logged = {}
+        model.validation_step(batch, 0)
+        assert np.isfinite(float(model._logged["loss/val"]))

@@ -117,6 +117,29 @@ def test_mvb(name):
     assert gu.check_grads(g, "gdec", _grads(dec_p), RT_G, AT_G) > 0
 
 
+# ------------------------------------------------------------------------------------- importance-weighted DeMissVAE
+@pytest.mark.parametrize("name", gu.names("mvbiwae_"))
+def test_mvbiwae(name):
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(dict(g, gen_dist="normal", q_dist="normal", mask_concat=False))
+    enc_p, dec_p = _as_params(enc_p), _as_params(dec_p)
+    objective = str(g["objective"])
+    ridx = torch.from_numpy(g["resample_idx"]) if "resample_idx" in g else None
+    gen_obj, enc_obj = core.mvbiwae_objectives(spec, enc_p, dec_p, torch.from_numpy(g["Xt"]), torch.from_numpy(g["M"]),
+                                               torch.from_numpy(g["eps"]), objective=objective, enc_isweights=str(g["enc_w"]),
+                                               dec_isweights=str(g["dec_w"]), STL=bool(g["STL"]), DREG=bool(g["DREG"]),
+                                               resample_idx=ridx)
+    torch.testing.assert_close(gen_obj.detach(), torch.from_numpy(g["gen_obj"]), rtol=RT_B, atol=1e-5)
+    torch.testing.assert_close(enc_obj.detach(), torch.from_numpy(g["enc_obj"]), rtol=RT_B, atol=1e-5)
+    if objective.startswith("mvb2"):
+        (-gen_obj.mean()).backward(retain_graph=True, inputs=list(dec_p.values()))
+        (-enc_obj.mean()).backward(inputs=list(enc_p.values()))
+    else:
+        (-gen_obj.mean()).backward()
+    assert gu.check_grads(g, "genc", _grads(enc_p), RT_G, AT_G) > 0
+    assert gu.check_grads(g, "gdec", _grads(dec_p), RT_G, AT_G) > 0
+
+
 # ------------------------------------------------------------------------------------- A12
 @pytest.mark.parametrize("name", gu.names("pgibbs_normal"))
 def test_pseudo_gibbs_normal(name):

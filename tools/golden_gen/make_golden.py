@@ -397,6 +397,64 @@ def cases_mvb(out):
          B=64, nz=1, seed=20220120, objective="mvb2", STL=True, store_inputs=False)
 
 
+def _mvbiwae(out, name, *, objective, enc_w, dec_w, STL=False, DREG=False, nz=2, seed):
+    """Importance-weighted DeMissVAE objectives (vgiwae/models/mvbiwae.py) on [nz, I, B, K] samples."""
+    from vgiwae.models.mvbiwae import MVB_IWAE_OBJ, IS_WEIGHTS
+    D, Zd, K, I, B = 5, 2, 3, 4, 6
+    enc_spec, dec_spec = NetSpec(D, 2 * Zd, 1, 16), NetSpec(Zd, 2 * D, 1, 16)
+    enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+    model = build_model("MVBIWAE", enc_spec, dec_spec, enc_p, dec_p, "normal", "normal", var_latent_STL=STL,
+                        var_latent_DREG=DREG, num_latent_samples=nz, num_importance_samples=I,
+                        mvb_objective=MVB_IWAE_OBJ[objective], enc_isweights=IS_WEIGHTS[enc_w], dec_isweights=IS_WEIGHTS[dec_w])
+    X, M = make_batch(seed + 2, B, D)
+    fill, _ = make_batch(seed + 6, B * K, D)
+    Mk = M[:, None, :].expand(B, K, D).contiguous()
+    Xt = torch.where(Mk, X[:, None, :].expand(B, K, D), fill.reshape(B, K, D)).contiguous()
+    eps = make_noise(seed + 3, nz, I, B, K, Zd)
+    noise = Noise()
+    noise.normal = [eps.clone()]
+    enc, dec = model.var_latent_network, model.generator_network
+    arrays = dict(seed=seed, B=B, K=K, I=I, nz=nz, D=D, Zd=Zd, STL=STL, DREG=DREG, objective=objective, enc_w=enc_w, dec_w=dec_w,
+                  enc_spec=np.array([enc_spec.in_dim, enc_spec.out_dim, enc_spec.nb, enc_spec.hidden]),
+                  dec_spec=np.array([dec_spec.in_dim, dec_spec.out_dim, dec_spec.nb, dec_spec.hidden]), Xt=Xt, M=Mk, eps=eps)
+    with injected(noise):
+        if objective.startswith("mvb2"):
+            gen_obj, enc_obj = model.estimate_mvb2_objectives(Xt, Mk)
+        elif objective.startswith("mvb"):
+            gen_obj = enc_obj = model.estimate_mvb_objective(Xt, Mk)
+        else:
+            gen_obj = enc_obj = model.estimate_cvi_objective(Xt, Mk)
+    arrays.update(gen_obj=gen_obj, enc_obj=enc_obj)
+    if noise.cat_draws:
+        arrays["resample_idx"] = noise.cat_draws[0]
+    if objective.startswith("mvb2"):
+        (-gen_obj.mean()).backward(retain_graph=True, inputs=list(dec.parameters()))
+        (-enc_obj.mean()).backward(inputs=list(enc.parameters()))
+    else:
+        (-gen_obj.mean()).backward()
+    arrays.update(params_to_dict("enc", enc_p))
+    arrays.update(params_to_dict("dec", dec_p))
+    arrays.update(grads_to_dict("genc", enc))
+    arrays.update(grads_to_dict("gdec", dec))
+    save(out, name, **arrays)
+
+
+def cases_mvbiwae(out):
+    cases = [("mvb_indep", "dmmis", "dmmis", "stl", 2), ("mvb_all", "smis", "smis", "plain", 2),
+             ("cvi_indep", "smis", "smis", "dreg", 2), ("cvi_all", "dmmis", "dmmis", "plain", 2),
+             ("mvb2_encindep_decall", "smis", "dmmis", "stl", 2), ("mvb2_encindep_decindep", "dmmis", "dmmis", "plain", 2),
+             ("mvb2_encall_decall", "dmmis", "smis", "dreg", 2),
+             ("mvb2_encallweightedsmis_decall", "dmmis", "dmmis", "stl", 2),
+             ("mvb2_encallweighteddmmis_decall", "smis", "dmmis", "dreg", 2),
+             ("mvb2_encallweighteddmmis_decall", "dmmis", "dmmis", "plain", 2),
+             ("mvb2_all_encweighteddmmis_decweighteddmmis", "dmmis", "dmmis", "dreg", 2),
+             ("mvb2_all_encweighteddmmis_decweighteddmmis", "dmmis", "dmmis", "stl", 1),
+             ("mvb2_encallweighteddmmis_decallresampl", "dmmis", "dmmis", "stl", 1)]
+    for k, (objective, enc_w, dec_w, mode, nz) in enumerate(cases):
+        _mvbiwae(out, f"mvbiwae_{objective}_{enc_w}_{dec_w}_{mode}", objective=objective, enc_w=enc_w, dec_w=dec_w,
+                 STL=mode == "stl", DREG=mode == "dreg", nz=nz, seed=11000 + 10 * k)
+
+
 def _reparam(out, name, *, cls, D, Zd, C, B, I, nz, seed, with_eps=True):
     """VAE / IWAE whose encoder is a mixture sampled ancestrally with implicit reparameterisation gradients
     (the reparametrised_mixture* families), STL as in every shipped config."""
@@ -790,6 +848,7 @@ def main():
         "resnet": lambda: cases_resnet(args.out),
         "reparam": lambda: cases_reparam(args.out),
         "marginal": lambda: cases_marginal(args.out),
+        "mvbiwae": lambda: cases_mvbiwae(args.out),
     }
     for name, fn in groups.items():
         if args.only and name not in args.only.split(","):

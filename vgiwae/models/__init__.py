@@ -8,6 +8,7 @@ encoder checkpoint) and the gradient-variance probe are accepted as keyword argu
 from .vae import VAE
 from .iwae import IWAE
 from .mvbvae import MVBVAE, MVB_OBJECTIVE
+from .mvbiwae import MVBIWAE, MVB_IWAE_OBJ, IS_WEIGHTS
 from .multiple_vae import MultipleVAE
 from .multiple_iwae import MultipleIWAE
 
@@ -65,7 +66,7 @@ def _with_ignored_diagnostics(base, suffix):
     return type(name, (base,), members)
 
 
-for _base in (VAE, IWAE, MVBVAE, MultipleIWAE, MultipleVAE):
+for _base in (VAE, IWAE, MVBVAE, MVBIWAE, MultipleIWAE, MultipleVAE):
     for _suffix in _DIAGNOSTIC_KWARGS:
         _cls = _with_ignored_diagnostics(_base, _suffix)
         globals()[_cls.__name__] = _cls
