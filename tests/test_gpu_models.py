@@ -313,3 +313,63 @@ def test_mvbiwae_training_steps_run_and_learn():
         model._logged = {}
         model.validation_step(batch, 0)
         assert np.isfinite(float(model._logged["loss/val"]))
+
+
+def test_rejection_sampler_draws_from_the_grid_posterior():
+    """VAESampler_Rejection: accepted latents follow p(z | x_obs) as tabulated on the latent grid; imputations keep the
+    observed values and are written back into the buffer.  (Own device draws: checked statistically.)"""
+    import math
+    from oracle.recipes import NetSpec, make_batch, make_params
+    from oracle.core import ModelSpec
+    from demiss_vae_amd.imputation import ImputationBuffer
+    from vgiwae.shared import vae_marginal_logprob as R
+    spec = ModelSpec(D=5, Zd=2, enc=NetSpec(5, 4, 1, 32), dec=NetSpec(2, 10, 2, 32), gen_dist="normal", q_dist="normal")
+    model = _build("VAE", spec, make_params(spec.enc, 1), make_params(spec.dec, 2), num_latent_samples=1).eval()
+    X, M = make_batch(9, 6, 5)
+    x, m = X.cuda(), M.cuda()
+    dims, _, dec = model.engine()
+    lo, hi, steps, K = -4.0, 4.0, 160, 3000
+    env = R.grid_envelope(dims, dec, x, m, lo, hi, steps)
+    # the same joint on the grid, by the oracle-side formulas on the CPU
+    from oracle import core
+    Z, _ = R.latent_grid(2, "cpu", lo, hi, steps)
+    g = core.mlp_forward(make_params(spec.dec, 2), Z, spec.dec)
+    joint = (core.gen_logprob(spec, g.unsqueeze(0), X.unsqueeze(1)) * M.unsqueeze(1)).sum(-1) + core.log_std_normal(Z).sum(-1)
+    torch.testing.assert_close(env.cpu(), joint.max(1)[0], rtol=1e-4, atol=1e-4)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    Zs = R.sample_pz_given_xo_with_rejection_sampling(dims, dec, x, m, K, env + math.log(1.05), 8192, lo, hi, generator=gen)
+    assert Zs.shape == (6, K, 2) and bool(((Zs >= lo) & (Zs <= hi)).all())
+    post = torch.softmax(joint.double(), 1)                                         # grid posterior [B, Nz]
+    mean = post @ Z.double()
+    var = post @ (Z.double() ** 2) - mean ** 2
+    err = (Zs.double().mean(1).cpu() - mean).abs()
+    assert bool((err < 5 * (var / K).sqrt() + 2 * (hi - lo) / steps).all()), (err, var)   # Monte-Carlo error + one grid cell
+    # the sampler call: K copies, observed entries kept, missing ones fresh per copy, buffer updated
+    sampler = R.VAESampler_Rejection(Z_batchsize=4096, envelope_multiplier=1.05, grid_min=lo, grid_max=hi, grid_steps=steps)
+    buf = ImputationBuffer(X, 4, "cuda")
+    Xt, idx = buf.gather(torch.arange(6).cuda())
+    Mk = m.unsqueeze(1).expand(6, 4, 5).contiguous()
+    out = sampler(Xt, Mk, model=model, buffer=buf, idx_imp=idx, generator=gen)
+    assert out.shape == (6, 4, 5) and torch.equal(out[Mk], Xt[Mk])
+    assert not torch.equal(out[:, 0][~m], out[:, 1][~m])
+    assert torch.equal(buf.gather(torch.arange(6).cuda())[0], out)
+
+
+def test_mog_oracle_sampler_on_the_device():
+    """VAESampler_MoG_Oracle inside update_imputations' calling convention (device tensors, buffer write-back)"""
+    from types import SimpleNamespace
+    from demiss_vae_amd.imputation import ImputationBuffer
+    from vgiwae.utils.mog_utils import VAESampler_MoG_Oracle
+    g = gu.load("mog_oracle")
+    f = {"comp_probs": np.exp(g["comp_log_probs"])[None], "means": g["means"], "covs": g["covs"]}
+    model = SimpleNamespace(datamodule=SimpleNamespace(train_data_core=SimpleNamespace(data_file=f)))
+    X, M = torch.from_numpy(g["X"]), torch.from_numpy(g["M"])
+    buf = ImputationBuffer(X, 5, "cuda")
+    index = torch.arange(len(X)).cuda()
+    Xt, idx = buf.gather(index)
+    Mk = M.cuda().unsqueeze(1).expand(-1, 5, -1).contiguous()
+    sampler = VAESampler_MoG_Oracle(start_distribution="indep_marginal_mog", interpolate_target="conditional_independent_mog",
+                                    interpolate_alpha=0.25)
+    out = sampler(Xt, Mk, model=model, buffer=buf, idx_imp=idx, generator=torch.Generator(device="cuda").manual_seed(0))
+    assert out.is_cuda and out.dtype == torch.float32 and torch.isfinite(out).all()
+    assert torch.equal(out[Mk], Xt[Mk]) and torch.equal(buf.gather(index)[0], out)

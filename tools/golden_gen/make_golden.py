@@ -455,6 +455,61 @@ def cases_mvbiwae(out):
                  STL=mode == "stl", DREG=mode == "dreg", nz=nz, seed=11000 + 10 * k)
 
 
+def cases_mog_oracle(out):
+    """Oracle sampler of the toy control study (vgiwae/utils/mog_utils.py): interpolated conditional mixtures for every
+    start / target the configs name, and one sampling call with injected normal noise and recorded component draws."""
+    from vgiwae.utils import mog_utils as ref
+    r = np.random.default_rng(77)
+    C, D, B, K = 6, 5, 9, 4
+    A = r.normal(size=(C, D, D))
+    covs = torch.tensor(A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D))
+    means = torch.tensor(r.normal(size=(C, D)) * 2)
+    probs = r.random(C) + 0.1
+    comp_log_probs = torch.tensor(probs / probs.sum()).log()
+    X, M = make_batch(771, B, D)
+    M[0] = torch.tensor([True, False, False, False, False])
+    M[1] = True                                      # fully observed row
+    # the reference scales views of `covs` in place for some targets (harmless there: it reloads the parameters at every
+    # call), so every call below gets its own copy
+    arrays = dict(X=X, M=M, comp_log_probs=comp_log_probs, means=means, covs=covs.clone(), K=K)
+    lp, mu, cv = ref.compute_conditional_mog_parameters(X, M, comp_log_probs, means, covs.clone())
+    arrays.update(cond_lp=lp, cond_means=mu, cond_covs=cv)
+    targets = ["indep_marginal_gaussian", "indep_marginal_mog", "conditional_independent_mog",
+               "conditional_independent_mog_created_from_true_indep_mog",
+               "conditional_independent_mog_with_var_shrinkage_to_0.01var", "conditional_mog_with_equal_component_probabilities",
+               "conditional_mog_with_mode_collapse_to_maxprob_mode", "conditional_mog_with_mode_collapse_to_secondlargestprob_mode",
+               "conditional_mog_with_mode_collapse_to_thirdlargestprob_mode",
+               "conditional_mog_with_mode_collapse_to_fourthlargestprob_mode",
+               "conditional_mog_with_mode_collapse_to_fifthlargestprob_mode", "marginal_gaussian", "marginal_mog",
+               "conditional_mog_with_mode_collapse_to_firstnonzero_mode"]
+    arrays["targets"] = np.array(targets)
+    for i, t in enumerate(targets):
+        for start, alpha in ((None, 0.25), ("indep_marginal_mog", 0.5)):
+            p = ref.construct_interpolated_conditional_mogs_from_true_mog(
+                X, M, start_distribution=start, interpolate_method="linear", interpolate_target=t, alpha=alpha,
+                comp_log_probs=comp_log_probs.clone(), means=means.clone(), covs=covs.clone())
+            tag = f"t{i}_{'cond' if start is None else 'indep'}"
+            arrays.update({f"{tag}_lp": p["comp_log_probs"], f"{tag}_means": p["means"], f"{tag}_covs": p["covs"]})
+    # sampling from the last interpolation of the first target
+    p = ref.construct_interpolated_conditional_mogs_from_true_mog(
+        X, M, start_distribution=None, interpolate_method="linear", interpolate_target=targets[0], alpha=0.5,
+        comp_log_probs=comp_log_probs.clone(), means=means.clone(), covs=covs.clone())
+    noise = Noise()
+    eps = torch.from_numpy(np.random.default_rng(78).normal(size=(B, K, D)))
+    noise.normal = [eps.clone()]
+    import torch.distributions.multivariate_normal as tdm
+    stock = tdm._standard_normal          # MultivariateNormal holds its own reference to the primitive
+    tdm._standard_normal = lambda shape, dtype, device: noise._pop_normal(shape).to(dtype)
+    try:
+        with injected(noise):
+            Xs = ref.sample_sparse_mog(K, M, p["comp_log_probs"], p["means"], p["covs"])
+    finally:
+        tdm._standard_normal = stock
+    assert not noise.normal
+    arrays.update(sample_eps=eps, sample_comp=noise.cat_draws[0], sample_out=Xs)
+    save(out, "mog_oracle", **arrays)
+
+
 def _reparam(out, name, *, cls, D, Zd, C, B, I, nz, seed, with_eps=True):
     """VAE / IWAE whose encoder is a mixture sampled ancestrally with implicit reparameterisation gradients
     (the reparametrised_mixture* families), STL as in every shipped config."""
@@ -849,6 +904,7 @@ def main():
         "reparam": lambda: cases_reparam(args.out),
         "marginal": lambda: cases_marginal(args.out),
         "mvbiwae": lambda: cases_mvbiwae(args.out),
+        "mog_oracle": lambda: cases_mog_oracle(args.out),
     }
     for name, fn in groups.items():
         if args.only and name not in args.only.split(","):
