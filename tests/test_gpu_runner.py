@@ -90,11 +90,18 @@ def workdir(tmp_path_factory):
     r = np.random.default_rng(1)
     (root / "data" / "toy").mkdir(parents=True)
 
-    def draw(n):                        # a 2-d latent pushed through a fixed linear map, plus noise
-        z = r.normal(size=(n, 2))
-        A = np.array([[1.0, -0.5, 0.3, 0.0, 2.0], [0.2, 1.0, -1.0, 0.7, 0.0]])
-        return (z @ A + 0.3 * r.normal(size=(n, 5))).astype(np.float32)
-    sio.savemat(root / "data" / "toy" / "data_mog2_large.mat", {"train": draw(2000), "val": draw(300), "test": draw(200)})
+    # a three-component mixture of Gaussians with its parameters in the file, like the reference's toy data
+    C, D = 3, 5
+    A = r.normal(size=(C, D, D))
+    covs = A @ A.transpose(0, 2, 1) / D + 0.2 * np.eye(D)
+    means = r.normal(size=(C, D)) * 2
+    probs = np.array([[0.5, 0.3, 0.2]])
+
+    def draw(n):
+        c = r.choice(C, size=n, p=probs[0])
+        return (means[c] + np.einsum("nij,nj->ni", np.linalg.cholesky(covs)[c], r.normal(size=(n, D)))).astype(np.float32)
+    sio.savemat(root / "data" / "toy" / "data_mog2_large.mat", {"train": draw(2000), "val": draw(300), "test": draw(200),
+                                                                "comp_probs": probs, "means": means, "covs": covs})
     return root
 
 
@@ -120,6 +127,26 @@ def test_demissvae_config_trains(workdir):
     ck = torch.load(out / "checkpoints" / "last.ckpt", weights_only=True)
     assert ck["epoch"] == 2 and any(k.startswith("generator_network.") for k in ck["state_dict"])
     assert [json.loads(l)["epoch"] for l in (out / "metrics.jsonl").read_text().splitlines()] == [0, 1]
+
+
+def test_control_study_config_with_oracle_imputations(workdir):
+    """the same model with imputations drawn from a degraded version of the true conditional mixture"""
+    text = CONFIG.replace("logs/toy/mvb2", "logs/toy/oracle").replace(
+        """      class_path: vgiwae.shared.vae_imputation.VAESampler_PseudoGibbs
+      init_args:
+        num_iterations: 3
+        clip_imputations: False
+""", """      class_path: vgiwae.utils.mog_utils.VAESampler_MoG_Oracle
+      init_args:
+        start_distribution: indep_marginal_mog
+        interpolate_method: linear
+        interpolate_target: conditional_independent_mog
+        interpolate_alpha: 0.5
+""")
+    assert "VAESampler_MoG_Oracle" in text
+    history, _, _ = launch(workdir, "oracle", text)
+    assert len(history) == 2 and all(math.isfinite(v) for row in history for v in row.values())
+    assert history[1]["marginal_logprob/val"] > history[0]["marginal_logprob/val"]
 
 
 def test_iwae_config_then_refit_and_test_loglik(workdir):
