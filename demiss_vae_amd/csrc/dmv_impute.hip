@@ -56,6 +56,7 @@ struct TailArgs {
   const uint8_t* M;          // [N][D]
   const float* noise;        // nullable [N][D]: standard normal (Gaussian decoder) or U[0,1) (Bernoulli)
   uint64_t seed, offset;
+  const uint64_t* offset_base;  // nullable device counter (a multiple of 4) added to offset
   const float* clip_min;     // nullable [D]
   const float* clip_max;     // nullable [D]
   int clip_after_blend;      // LAIR clips the blended row (observed entries included)
@@ -98,6 +99,7 @@ __device__ __forceinline__ float tail_element(const TailArgs& a, const float* de
 
 __global__ void k_impute_tail(TailArgs a) {
   const int64_t total = a.N * a.D;
+  const uint64_t off = a.offset + (a.offset_base ? a.offset_base[0] : 0ull);
   const bool normal = a.gen_dist <= DMV_GEN_NORMAL_EPS;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i / a.D;
@@ -105,8 +107,8 @@ __global__ void k_impute_tail(TailArgs a) {
     const int64_t r = a.row_map ? a.row_map[n] : n;
     const float* dec = a.dec + r * a.ld_dec;
     const float noise = a.noise ? a.noise[i]
-                                : normal ? dmv_philox_normal(a.seed, a.offset + (uint64_t)i)
-                                         : dmv_philox_uniform(a.seed, a.offset + (uint64_t)i);
+                                : normal ? dmv_philox_normal(a.seed, off + (uint64_t)i)
+                                         : dmv_philox_uniform(a.seed, off + (uint64_t)i);
     const float out = tail_element(a, dec, d, noise, a.X_old[i], a.M[i] != 0);
     a.X_out[i] = out;
     if (a.buf) a.buf[a.idx_imp[n] * a.D + d] = out;
@@ -117,6 +119,7 @@ __global__ void k_impute_tail(TailArgs a) {
 // 16-byte access per array; blockIdx.y walks the rows.  Same values as the scalar kernel.
 __global__ void k_impute_tail4(TailArgs a) {
   const bool normal = a.gen_dist <= DMV_GEN_NORMAL_EPS;
+  const uint64_t off = a.offset + (a.offset_base ? a.offset_base[0] : 0ull);
   const int D4 = a.D >> 2;
   for (int64_t n = blockIdx.y; n < a.N; n += gridDim.y) {
     const int64_t r = a.row_map ? a.row_map[n] : n;
@@ -131,7 +134,7 @@ __global__ void k_impute_tail4(TailArgs a) {
         const f32x4 t = *(const f32x4*)(a.noise + i);
         nz = dmv_f4{{t[0], t[1], t[2], t[3]}};
       } else {
-        const uint64_t c = (a.offset + (uint64_t)i) >> 2;
+        const uint64_t c = (off + (uint64_t)i) >> 2;
         nz = normal ? dmv_philox_normal4(a.seed, c) : dmv_philox_uniform4(a.seed, c);
       }
       f32x4 o;
@@ -152,6 +155,7 @@ struct DrawArgs {
   const float* logits;  // [B][P]
   const float* u;       // nullable [B][K] in [0,1)
   uint64_t seed, offset;
+  const uint64_t* offset_base;  // nullable device counter added to offset
   int64_t* idx;         // [B][K]
 };
 
@@ -169,7 +173,8 @@ __global__ void k_categorical_draw(DrawArgs a) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
   for (int k = lane; k < a.K; k += 64) {
-    const float u = a.u ? a.u[(int64_t)b * a.K + k] : dmv_philox_uniform(a.seed, a.offset + (uint64_t)b * a.K + k);
+    const float u = a.u ? a.u[(int64_t)b * a.K + k]
+                        : dmv_philox_uniform(a.seed, a.offset + (a.offset_base ? a.offset_base[0] : 0ull) + (uint64_t)b * a.K + k);
     const float target = u * se;
     float c = 0.f;
     int pick = a.P - 1;
@@ -182,12 +187,16 @@ __global__ void k_categorical_draw(DrawArgs a) {
 }
 
 // Bernoulli(1 - p) keep masks for the residual blocks' dropout (vgiwae/shared/neural_nets.py:65,70)
-__global__ void k_dropout_masks(uint8_t* __restrict__ keep, int64_t n, float p, uint64_t seed, uint64_t offset) {
+__global__ void k_dropout_masks(uint8_t* __restrict__ keep, int64_t n, float p, uint64_t seed, uint64_t offset,
+                                const uint64_t* offset_base) {
+  if (offset_base) offset += offset_base[0];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     keep[i] = dmv_philox_uniform(seed, offset + (uint64_t)i) >= p ? 1 : 0;
 }
 // four masks per thread and Philox call (n % 4 == 0, offset % 4 == 0, 4-byte aligned base); same values
-__global__ void k_dropout_masks4(uint32_t* __restrict__ keep4, int64_t n4, float p, uint64_t seed, uint64_t offset) {
+__global__ void k_dropout_masks4(uint32_t* __restrict__ keep4, int64_t n4, float p, uint64_t seed, uint64_t offset,
+                                 const uint64_t* offset_base) {
+  if (offset_base) offset += offset_base[0];
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
     const dmv_f4 u = dmv_philox_uniform4(seed, (offset >> 2) + (uint64_t)q);
     keep4[q] = (u.v[0] >= p ? 1u : 0u) | (u.v[1] >= p ? 0x100u : 0u) | (u.v[2] >= p ? 0x10000u : 0u) | (u.v[3] >= p ? 0x1000000u : 0u);
@@ -231,9 +240,9 @@ extern "C" int dmv_rows_scatter(float* dst, const int64_t* idx, int64_t n, int32
 
 extern "C" int dmv_impute_tail(int64_t N, int32_t D, int32_t gen_dist, const float* dec, int64_t ld_dec,
                                const int64_t* row_map, const float* X_old, const uint8_t* M, const float* noise,
-                               uint64_t seed, uint64_t offset, const float* clip_min, const float* clip_max,
-                               int32_t clip_after_blend, float* X_out, float* buf, const int64_t* idx_imp,
-                               void* stream) {
+                               uint64_t seed, uint64_t offset, const uint64_t* offset_base, const float* clip_min,
+                               const float* clip_max, int32_t clip_after_blend, float* X_out, float* buf,
+                               const int64_t* idx_imp, void* stream) {
   if (N < 0 || D < 1 || !dec || !X_old || !M || !X_out) return DMV_E_BADARG;
   if (gen_dist < DMV_GEN_NORMAL || gen_dist > DMV_GEN_BERN_M1P1) return DMV_E_UNSUPPORTED;
   const int P = gen_dist <= DMV_GEN_NORMAL_EPS ? 2 * D : D;
@@ -241,7 +250,7 @@ extern "C" int dmv_impute_tail(int64_t N, int32_t D, int32_t gen_dist, const flo
   if (N == 0) return DMV_OK;
   TailArgs a;
   a.N = N; a.D = D; a.gen_dist = gen_dist; a.dec = dec; a.ld_dec = ld_dec; a.row_map = row_map;
-  a.X_old = X_old; a.M = M; a.noise = noise; a.seed = seed; a.offset = offset;
+  a.X_old = X_old; a.M = M; a.noise = noise; a.seed = seed; a.offset = offset; a.offset_base = offset_base;
   a.clip_min = clip_min; a.clip_max = clip_max; a.clip_after_blend = clip_after_blend;
   a.X_out = X_out; a.buf = buf; a.idx_imp = idx_imp;
   const uintptr_t al = (uintptr_t)dec | (uintptr_t)X_old | (uintptr_t)X_out | (uintptr_t)noise | (uintptr_t)buf;
@@ -257,23 +266,25 @@ extern "C" int dmv_impute_tail(int64_t N, int32_t D, int32_t gen_dist, const flo
 }
 
 extern "C" int dmv_categorical_draw(int32_t B, int32_t P, int32_t K, const float* logits, const float* u, uint64_t seed,
-                                    uint64_t offset, int64_t* idx, void* stream) {
+                                    uint64_t offset, const uint64_t* offset_base, int64_t* idx, void* stream) {
   if (B < 1 || P < 1 || K < 1 || !logits || !idx) return DMV_E_BADARG;
   DrawArgs a;
-  a.B = B; a.P = P; a.K = K; a.logits = logits; a.u = u; a.seed = seed; a.offset = offset; a.idx = idx;
+  a.B = B; a.P = P; a.K = K; a.logits = logits; a.u = u; a.seed = seed; a.offset = offset; a.offset_base = offset_base; a.idx = idx;
   hipLaunchKernelGGL(k_categorical_draw, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
 
-extern "C" int dmv_dropout_masks(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+extern "C" int dmv_dropout_masks(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset,
+                                 const uint64_t* offset_base, void* stream) {
   if (!keep || n < 0 || !(p >= 0.f && p < 1.f)) return DMV_E_BADARG;
   if (n == 0) return DMV_OK;
   if ((n & 3) == 0 && (offset & 3) == 0 && ((uintptr_t)keep & 3) == 0)
     hipLaunchKernelGGL(k_dropout_masks4, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t*)keep, n / 4, p,
-                       seed, offset);
+                       seed, offset, offset_base);
   else
-    hipLaunchKernelGGL(k_dropout_masks, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, keep, n, p, seed, offset);
+    hipLaunchKernelGGL(k_dropout_masks, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, keep, n, p, seed, offset,
+                       offset_base);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }

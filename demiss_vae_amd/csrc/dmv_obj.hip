@@ -57,10 +57,12 @@ struct SampleArgs {
   int64_t ldz;
   float* Z;
   uint64_t seed, offset;
+  const uint64_t* offset_base;   // nullable device counter added to offset (advanced by the caller between replays)
 };
 
 __global__ void k_latent_sample(SampleArgs a) {
   const int64_t total = a.N * a.ldz;
+  const uint64_t off = a.offset + (a.offset_base ? a.offset_base[0] : 0ull);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i / a.ldz;
     const int j = (int)(i - n * a.ldz);
@@ -68,7 +70,7 @@ __global__ void k_latent_sample(SampleArgs a) {
     int g = (int)(n % a.G);
     const int64_t b = (n / a.G) % a.B;
     if (a.comp_idx) g = (int)a.comp_idx[n];
-    const float e = a.eps ? a.eps[i] : dmv_philox_normal(a.seed, a.offset + (uint64_t)i);
+    const float e = a.eps ? a.eps[i] : dmv_philox_normal(a.seed, off + (uint64_t)i);
     if (a.eps_out) a.eps_out[i] = e;
     a.Z[i] = q_mu(a.enc, a.q, b, g, j) + q_sigma(a.enc, a.q, b, g, j) * e;
   }
@@ -828,8 +830,8 @@ static inline unsigned grid_for(int64_t work, int block, unsigned cap = 8192) {
 }
 
 extern "C" int dmv_latent_sample(const DmvObjCfg* cfg, const float* enc, const float* eps, uint64_t seed,
-                                 uint64_t offset, int64_t ldz, const int64_t* comp_idx, float* Z, float* eps_out,
-                                 void* stream) {
+                                 uint64_t offset, const uint64_t* offset_base, int64_t ldz, const int64_t* comp_idx,
+                                 float* Z, float* eps_out, void* stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (!enc || !Z || ldz < cfg->Zd) return DMV_E_BADARG;
@@ -837,7 +839,7 @@ extern "C" int dmv_latent_sample(const DmvObjCfg* cfg, const float* enc, const f
   SampleArgs a;
   a.N = nrows(cfg); a.B = cfg->B; a.G = cfg->G; a.Zd = cfg->Zd;
   a.q = qaddr(cfg); a.enc = enc; a.eps = eps; a.eps_out = eps_out; a.comp_idx = comp_idx;
-  a.ldz = ldz; a.Z = Z; a.seed = seed; a.offset = offset;
+  a.ldz = ldz; a.Z = Z; a.seed = seed; a.offset = offset; a.offset_base = offset_base;
   hipLaunchKernelGGL(k_latent_sample, dim3(grid_for(a.N * ldz, 256)), dim3(256), 0, (hipStream_t)stream, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;

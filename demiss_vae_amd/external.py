@@ -76,11 +76,11 @@ class _Sample(torch.autograd.Function):
             comp_idx, eps = reparam_components(c.dims, c.cfg, enc, comp_idx, eps)
         if eps is not None:
             used = eps.reshape(N, Zd).contiguous().float()
-            L.check(lib.dmv_latent_sample(C.byref(c.cfg), L.ptr(enc), L.ptr(used), 0, 0, Zd, L.ptr(comp_idx), L.ptr(Z), None, st))
+            L.check(lib.dmv_latent_sample(C.byref(c.cfg), L.ptr(enc), L.ptr(used), 0, 0, None, Zd, L.ptr(comp_idx), L.ptr(Z), None, st))
         else:
             used = torch.empty((N, Zd), dtype=torch.float32, device=enc.device)
             seed, off = rng.next_offset(N * Zd)
-            L.check(lib.dmv_latent_sample(C.byref(c.cfg), L.ptr(enc), None, seed, off, Zd, L.ptr(comp_idx), L.ptr(Z), L.ptr(used), st))
+            L.check(lib.dmv_latent_sample(C.byref(c.cfg), L.ptr(enc), None, seed, off, rng.base_ptr(), Zd, L.ptr(comp_idx), L.ptr(Z), L.ptr(used), st))
         c.enc_out, c.Z, c.eps = enc, Z, used
         ctx.c = c
         return Z

@@ -3,10 +3,13 @@
 At the reference's batch sizes (64 .. 1024 datapoints) a training step is about sixty short kernels and the host
 needs longer to issue them than the GPU to run them.  `GraphedStep` records one step - forward pipelines,
 backward, clipping, optimiser - into a graph and replays it with a single launch.  The library's entry points
-allocate nothing and take the stream as an argument, so they record as they are; what must not be baked into the
-recording is the noise: pass explicit noise tensors (`eps=`, keep-masks) that live outside the graph and refill them
-in `refresh`, which runs before every replay.  Optimisers need `capturable=True`."""
+allocate nothing and take the stream as an argument, so they record as they are.  Noise drawn inside the library stays random across
+replays through a device-resident Philox counter that the recording advances (demiss_vae_amd.rng.CaptureStream);
+explicit noise tensors (`eps=`, keep-masks) must live outside the graph and be refilled in `refresh`, which runs
+before every replay.  Optimisers need `capturable=True`."""
 import torch
+
+from . import rng
 
 
 class GraphedStep:
@@ -26,13 +29,15 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        self.noise = rng.CaptureStream(torch.cuda.current_device())
         if refresh is not None:
             refresh()
         for n in self.nets:
             n.packed()          # allocate the image outside the recording ...
             n.invalidate()      # ... and make sure the packing kernel is part of it
         with torch.cuda.graph(self.graph):
-            self.out = body()
+            with self.noise:
+                self.out = body()
         for n in self.nets:
             n.invalidate()
 

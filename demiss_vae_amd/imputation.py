@@ -122,7 +122,7 @@ def _tail(dims, dec_out, row_map, X_old, M, noise, clip_min, clip_max, clip_afte
     else:
         noise = noise.reshape(N, D).contiguous().float()
     L.check(L.lib().dmv_impute_tail(N, D, L.GEN[dims.gen_dist], L.ptr(dec_out), dec_out.shape[1], L.ptr(row_map),
-                                    L.ptr(X_old), L.ptr(M), L.ptr(noise), seed, off, L.ptr(clip_min), L.ptr(clip_max),
+                                    L.ptr(X_old), L.ptr(M), L.ptr(noise), seed, off, rng.base_ptr(), L.ptr(clip_min), L.ptr(clip_max),
                                     1 if clip_after_blend else 0, L.ptr(X_out),
                                     L.ptr(buf.data_imp) if buf is not None else None, L.ptr(idx_imp), L.stream_ptr()))
     return X_out
@@ -134,7 +134,7 @@ def _keep(net, rows, training, device):
     n = net.dims.nb * rows * net.dims.hidden
     keep = torch.empty(n, dtype=torch.uint8, device=device)
     seed, off = rng.next_offset(n)
-    L.check(L.lib().dmv_dropout_masks(L.ptr(keep), n, net.dims.dropout, seed, off, L.stream_ptr()))
+    L.check(L.lib().dmv_dropout_masks(L.ptr(keep), n, net.dims.dropout, seed, off, rng.base_ptr(), L.stream_ptr()))
     return keep
 
 
@@ -160,10 +160,10 @@ def pseudo_gibbs(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_i
         Z = torch.empty((N, dims.Zd), dtype=torch.float32, device=dev)
         if eps_z is not None:
             e = eps_z[t].reshape(N, dims.Zd).contiguous().float()
-            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(e), 0, 0, dims.Zd, None, L.ptr(Z), None, st))
+            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(e), 0, 0, None, dims.Zd, None, L.ptr(Z), None, st))
         else:
             seed, off = rng.next_offset(N * dims.Zd)
-            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, dims.Zd, None, L.ptr(Z), None, st))
+            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, rng.base_ptr(), dims.Zd, None, L.ptr(Z), None, st))
         if isinstance(dec, PackedNet):
             dec_out, _ = mlp_forward(dec, Z, dims.Zd, N, save=False, drop_keep=_keep(dec, N, training, dev))
         else:
@@ -214,10 +214,10 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
         Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
         if eps_z is not None:
             e = eps_z[t].reshape(N, Zd).contiguous().float()
-            L.check(lib.dmv_latent_sample(C.byref(scfg), L.ptr(enc_out), L.ptr(e), 0, 0, Zd, None, L.ptr(Z), None, st))
+            L.check(lib.dmv_latent_sample(C.byref(scfg), L.ptr(enc_out), L.ptr(e), 0, 0, None, Zd, None, L.ptr(Z), None, st))
         else:
             seed, off = rng.next_offset(N * Zd)
-            L.check(lib.dmv_latent_sample(C.byref(scfg), L.ptr(enc_out), None, seed, off, Zd, None, L.ptr(Z), None, st))
+            L.check(lib.dmv_latent_sample(C.byref(scfg), L.ptr(enc_out), None, seed, off, rng.base_ptr(), Zd, None, L.ptr(Z), None, st))
         dec_out, _ = mlp_forward(dec, Z, Zd, N, save=False, drop_keep=_keep(dec, N, training, dev))
         # DMIS log-weights: uniform mixture over the K+r components of the datapoint (shared/iwae.py:57-100)
         cfg = L.DmvObjCfg()
@@ -234,7 +234,7 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
         else:
             draw = torch.empty((B, Kp), dtype=torch.int64, device=dev)
             seed, off = rng.next_offset(B * Kp)
-            L.check(lib.dmv_categorical_draw(B, I * Kp, Kp, L.ptr(logits), None, seed, off, L.ptr(draw), st))
+            L.check(lib.dmv_categorical_draw(B, I * Kp, Kp, L.ptr(logits), None, seed, off, rng.base_ptr(), L.ptr(draw), st))
         draw = draw[:, :K]                                                       # keep the first K (:521-524)
         i_sel, k_sel = draw // Kp, draw % Kp
         row_map = ((i_sel * B + torch.arange(B, device=dev)[:, None]) * Kp + k_sel).reshape(-1).contiguous()
@@ -255,7 +255,7 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
         else:
             draw = torch.empty((B, K), dtype=torch.int64, device=dev)
             seed, off = rng.next_offset(B * K)
-            L.check(lib.dmv_categorical_draw(B, T * I * Kp, K, L.ptr(lws), None, seed, off, L.ptr(draw), st))
+            L.check(lib.dmv_categorical_draw(B, T * I * Kp, K, L.ptr(lws), None, seed, off, rng.base_ptr(), L.ptr(draw), st))
         Zf = torch.gather(Zs, 1, draw[..., None].expand(B, K, Zd)).reshape(B * K, Zd).contiguous()
         dec_out, _ = mlp_forward(dec, Zf, Zd, B * K, save=False, drop_keep=_keep(dec, B * K, training, dev))
         Xc = _tail(dims, dec_out, None, Xc, Mu, noise_x[T] if noise_x is not None else None, None, None, False,
@@ -304,17 +304,17 @@ def estimate_loglik(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, nu
             else:
                 d = torch.empty((B, Kc), dtype=torch.int64, device=dev)
                 seed, off = rng.next_offset(B * Kc)
-                L.check(lib.dmv_categorical_draw(B, dims.C, Kc, L.ptr(logits), None, seed, off, L.ptr(d), st))
+                L.check(lib.dmv_categorical_draw(B, dims.C, Kc, L.ptr(logits), None, seed, off, rng.base_ptr(), L.ptr(d), st))
                 comp = d.t().contiguous().reshape(-1)
         else:
             cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, 0, Zd, 0
         Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
         if eps is not None:
             e = eps[k0:k0 + Kc].reshape(N, Zd).contiguous().float()
-            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(e), 0, 0, Zd, L.ptr(comp), L.ptr(Z), None, st))
+            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(e), 0, 0, None, Zd, L.ptr(comp), L.ptr(Z), None, st))
         else:
             seed, off = rng.next_offset(N * Zd)
-            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, Zd, L.ptr(comp), L.ptr(Z), None, st))
+            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, rng.base_ptr(), Zd, L.ptr(comp), L.ptr(Z), None, st))
         dec_out, _ = mlp_forward(dec, Z, Zd, N, save=False)
         terms = torch.empty((5, N), dtype=torch.float32, device=dev)
         q_kind = L.Q_STRATIFIED if mixture else L.Q_OWN

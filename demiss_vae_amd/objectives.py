@@ -121,12 +121,12 @@ def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, 
     Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
     if eps is not None:
         eps_used = eps.reshape(N, Zd).contiguous().float()
-        L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(eps_used), 0, 0, Zd, L.ptr(comp_idx),
+        L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(eps_used), 0, 0, None, Zd, L.ptr(comp_idx),
                                       L.ptr(Z), None, st))
     else:
         eps_used = torch.empty((N, Zd), dtype=torch.float32, device=dev) if training else None
         seed, off = rng.next_offset(N * Zd)
-        L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, Zd, L.ptr(comp_idx),
+        L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, rng.base_ptr(), Zd, L.ptr(comp_idx),
                                       L.ptr(Z), L.ptr(eps_used), st))
 
     # ---- decoder
@@ -163,7 +163,7 @@ def reparam_components(dims: ModelDims, cfg, enc_out, comp_idx, eps):
         logits = enc_out[:, 2 * Cn * Zd:2 * Cn * Zd + Cn].contiguous()
         draws = torch.empty((B, S), dtype=torch.int64, device=dev)
         seed, off = rng.next_offset(B * S)
-        L.check(L.lib().dmv_categorical_draw(B, Cn, S, L.ptr(logits), None, seed, off, L.ptr(draws), L.stream_ptr()))
+        L.check(L.lib().dmv_categorical_draw(B, Cn, S, L.ptr(logits), None, seed, off, rng.base_ptr(), L.ptr(draws), L.stream_ptr()))
         comp_idx = draws.t().contiguous().reshape(-1)
     else:
         comp_idx = comp_idx.reshape(-1).to(torch.int64).contiguous()

@@ -135,9 +135,14 @@ typedef struct DmvObjCfg {
  * ldz >= Zd; columns in [Zd, ldz) are zeroed.  eps == NULL: standard normals from Philox4x32-10
  * (stream `seed`, element counter `offset` + n*ldz + j); eps_out (nullable) receives the noise used.
  * comp_idx (nullable, int64 [N], cfg->G must be 1): draw row n from component comp_idx[n] of the
- * stratified encoder output (sampling the mixture without stratification, models/vae.py:298-301). */
+ * stratified encoder output (sampling the mixture without stratification, models/vae.py:298-301).
+ * offset_base (every Philox-consuming entry point has it; nullable): a device-resident counter, a multiple of 4,
+ * whose value at execution time is added to `offset`.  A step recorded in a HIP graph bakes `offset` in; advancing
+ * the counter on the device between replays (the host side records that increment in the graph too) gives every
+ * replay fresh draws. */
 int dmv_latent_sample(const DmvObjCfg* cfg, const float* enc, const float* eps, uint64_t seed, uint64_t offset,
-                      int64_t ldz, const int64_t* comp_idx, float* Z, float* eps_out, void* stream);
+                      const uint64_t* offset_base, int64_t ldz, const int64_t* comp_idx, float* Z, float* eps_out,
+                      void* stream);
 
 /* Per-sample terms (vgiwae/shared/iwae.py:17-45, 66-90, 102-132; models/mvbvae.py:83-137):
  *   terms[0][n] = sum_d M_d log p(x_d|z)      terms[1][n] = sum_d log p(x_d|z)
@@ -253,17 +258,19 @@ int dmv_rows_scatter(float* dst, const int64_t* idx, int64_t n, int32_t D, const
  * noise == NULL: Philox stream (seed, offset + n*D + d). */
 int dmv_impute_tail(int64_t N, int32_t D, int32_t gen_dist, const float* dec, int64_t ld_dec,
                     const int64_t* row_map, const float* X_old, const uint8_t* M, const float* noise,
-                    uint64_t seed, uint64_t offset, const float* clip_min, const float* clip_max,
-                    int32_t clip_after_blend, float* X_out, float* buf, const int64_t* idx_imp, void* stream);
+                    uint64_t seed, uint64_t offset, const uint64_t* offset_base, const float* clip_min,
+                    const float* clip_max, int32_t clip_after_blend, float* X_out, float* buf, const int64_t* idx_imp,
+                    void* stream);
 
 /* K categorical draws per datapoint from softmax(logits[b][0..P)) by inverse CDF
  * (replaces Categorical(logits).sample((K,)), vgiwae/shared/vae_imputation.py:185-186, :679-680).
  * u (nullable) [B][K] uniforms in [0,1); NULL: Philox stream (seed, offset + b*K + k).  idx int64 [B][K]. */
 int dmv_categorical_draw(int32_t B, int32_t P, int32_t K, const float* logits, const float* u, uint64_t seed,
-                         uint64_t offset, int64_t* idx, void* stream);
+                         uint64_t offset, const uint64_t* offset_base, int64_t* idx, void* stream);
 
 /* keep[i] = 1 with probability 1-p (dropout masks of the residual blocks, neural_nets.py:65,70) */
-int dmv_dropout_masks(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+int dmv_dropout_masks(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_base,
+                      void* stream);
 
 #ifdef __cplusplus
 }

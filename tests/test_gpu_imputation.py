@@ -70,7 +70,7 @@ def test_lair_device_draws_match_inverse_cdf():
     u = torch.from_numpy(np.random.Generator(np.random.PCG64(6)).random((B, K)).astype(np.float32))
     idx = torch.empty((B, K), dtype=torch.int64, device="cuda")
     lg, ug = logits.cuda(), u.cuda()
-    L.check(L.lib().dmv_categorical_draw(B, P, K, L.ptr(lg), L.ptr(ug), 0, 0, L.ptr(idx), L.stream_ptr()))
+    L.check(L.lib().dmv_categorical_draw(B, P, K, L.ptr(lg), L.ptr(ug), 0, 0, None, L.ptr(idx), L.stream_ptr()))
     ref = core.inverse_cdf_categorical(logits, u)
     # fp32 vs fp64 cumulative sums can disagree only when u sits on a bin edge
     assert (idx.cpu() != ref).float().mean().item() < 5e-3
@@ -80,7 +80,7 @@ def test_lair_device_draws_match_inverse_cdf():
     counts = torch.zeros(P2)
     for rep in range(200):
         d = torch.empty((B2, K2), dtype=torch.int64, device="cuda")
-        L.check(L.lib().dmv_categorical_draw(B2, P2, K2, L.ptr(lg2), None, 42, rep * B2 * K2, L.ptr(d), L.stream_ptr()))
+        L.check(L.lib().dmv_categorical_draw(B2, P2, K2, L.ptr(lg2), None, 42, rep * B2 * K2, None, L.ptr(d), L.stream_ptr()))
         counts += torch.bincount(d.cpu().reshape(-1), minlength=P2).float()
     freq = counts / counts.sum()
     torch.testing.assert_close(freq, torch.softmax(lg2[0].cpu(), 0), atol=0.01, rtol=0)

@@ -373,3 +373,50 @@ def test_mog_oracle_sampler_on_the_device():
     out = sampler(Xt, Mk, model=model, buffer=buf, idx_imp=idx, generator=torch.Generator(device="cuda").manual_seed(0))
     assert out.is_cuda and out.dtype == torch.float32 and torch.isfinite(out).all()
     assert torch.equal(out[Mk], Xt[Mk]) and torch.equal(buf.gather(index)[0], out)
+
+
+def test_graph_replays_draw_fresh_library_noise():
+    """A recorded step whose noise comes from the library's Philox stream: every replay advances the device-resident
+    counter, so replays see new draws (all standard normal, no repeats), from a stream of their own."""
+    import ctypes as C
+    import demiss_vae_amd as dmv
+    import gpu_util as G
+    from demiss_vae_amd import _lib as L, rng
+    g = gu.load("iwae_stl_normal_with_eps_mc")
+    spec, enc_p, dec_p = gu.model_case(g)
+    dims, enc, dec = G.model_dims(spec), G.packed_net(spec.enc, enc_p, requires_grad=False), \
+        G.packed_net(spec.dec, dec_p, requires_grad=False)
+    X, M = (t.cuda() for t in gu.batch_of(g))
+    rng.set_seed(7)
+    cfg = L.DmvObjCfg()
+    N, Zd = 4096, 8
+    cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = N, 1, 1, 1, 1, Zd
+    cfg.enc_sb, cfg.enc_sg, cfg.raw_off = 2 * Zd, 0, Zd
+    enc_out = torch.zeros(N, 2 * Zd, device="cuda")
+    Z, used = torch.empty(N, Zd, device="cuda"), torch.empty(N, Zd, device="cuda")
+
+    def body():
+        with torch.no_grad():
+            seed, off = rng.next_offset(N * Zd)
+            L.check(L.lib().dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, rng.base_ptr(), Zd, None, L.ptr(Z),
+                                              L.ptr(used), L.stream_ptr()))
+            return dmv.estimate_iwelbo(dims, enc, dec, X, M, num_importance_samples=5)[1]
+    before = rng.get_state()
+    step = dmv.GraphedStep(body, warmup=1)
+    host_after_capture = rng.get_state()
+    draws, bounds = [], []
+    for _ in range(5):
+        bounds.append(step().clone())
+        draws.append(used.clone())
+    assert rng.get_state() == host_after_capture                       # replays leave the eager stream alone ...
+    assert host_after_capture[1] > before[1]                           # ... which only the eager warm-up advanced
+    per_step = N * Zd + ((5 * X.shape[0] * spec.Zd + 3) & ~3)
+    assert int(step.noise.counter) == 5 * per_step
+    flat = torch.stack(draws).reshape(5, -1)
+    assert len({tuple(d[:8].tolist()) for d in flat}) == 5             # different on every replay
+    assert torch.unique(flat).numel() > 0.999 * flat.numel()           # and no range reused
+    e = flat.double()
+    assert abs(e.mean().item()) < 0.01 and abs(e.std().item() - 1) < 0.01
+    assert len({round(float(b.mean()), 5) for b in bounds}) == 5       # the bound is re-estimated with fresh noise
+    eager = torch.stack([body().mean() for _ in range(20)]).mean()
+    assert abs(float(torch.stack(bounds).mean()) - float(eager)) < 0.5

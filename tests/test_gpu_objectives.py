@@ -117,7 +117,7 @@ def test_philox_noise_statistics():
     enc = torch.zeros(N, 2 * Zd, device="cuda")
     Z = torch.empty(N, Zd, device="cuda")
     eps = torch.empty(N, Zd, device="cuda")
-    L.check(L.lib().dmv_latent_sample(C.byref(cfg), L.ptr(enc), None, 99, 0, Zd, None, L.ptr(Z), L.ptr(eps), L.stream_ptr()))
+    L.check(L.lib().dmv_latent_sample(C.byref(cfg), L.ptr(enc), None, 99, 0, None, Zd, None, L.ptr(Z), L.ptr(eps), L.stream_ptr()))
     e = eps.double().cpu()
     assert abs(e.mean().item()) < 5e-3 and abs(e.std().item() - 1) < 5e-3
     assert abs((e ** 4).mean().item() - 3) < 0.1            # kurtosis of a standard normal

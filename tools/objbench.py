@@ -50,7 +50,7 @@ def bwd_fn():
 
 
 def tail_fn():
-    L.check(lib.dmv_impute_tail(N, D, L.GEN["bern_m1_p1"], L.ptr(dec), D, None, L.ptr(X), L.ptr(M), None, 1, 0, None, None, 0,
+    L.check(lib.dmv_impute_tail(N, D, L.GEN["bern_m1_p1"], L.ptr(dec), D, None, L.ptr(X), L.ptr(M), None, 1, 0, None, None, None, 0,
                                 L.ptr(Xo), L.ptr(buf), L.ptr(idx), st))
 
 
