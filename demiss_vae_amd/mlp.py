@@ -1,8 +1,9 @@
 """Host side of the fused residual-MLP kernels (dmv_mlp_* in include/dmv.h).
 
 `PackedNet` owns the fragment-ordered copy of a network's weights and re-packs it when the
-parameters change (tracked through the tensors' version counters, which every in-place optimiser
-update bumps).  `mlp_forward` / `mlp_backward` are thin wrappers over the C ABI working on padded
+parameters may have changed: after any optimiser step anywhere in the process (a global post-step hook;
+torch's fused optimisers update parameters without touching their version counters) and whenever a
+parameter's version counter or address moved (load_state_dict, manual in-place edits).  `mlp_forward` / `mlp_backward` are thin wrappers over the C ABI working on padded
 row-major buffers; `ResidualMLPFunction` exposes one network call to autograd.
 """
 import ctypes as C
@@ -10,8 +11,20 @@ from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
 import torch
+from torch.optim.optimizer import register_optimizer_step_post_hook
 
 from . import _lib as L
+
+
+_optimizer_steps = 0
+
+
+def _count_optimizer_step(*_args, **_kwargs):
+    global _optimizer_steps
+    _optimizer_steps += 1
+
+
+register_optimizer_step_post_hook(_count_optimizer_step)
 
 
 def pad32(n: int) -> int:
@@ -67,7 +80,7 @@ class PackedNet:
         self._stamp = None
 
     def _current_stamp(self):
-        return tuple((t.data_ptr(), t._version) for t in self.params())
+        return (_optimizer_steps,) + tuple((t.data_ptr(), t._version) for t in self.params())
 
     def packed(self) -> torch.Tensor:
         """Fragment image of the current weights (re-packed only when a parameter changed)."""

@@ -75,6 +75,6 @@ class CaptureStream:
     def __exit__(self, *exc):
         global _capture
         _capture = None
-        if self.used:
+        if self.used and exc[0] is None:
             self.counter.add_(self.used)     # recorded with the step: advances on every replay
         return False

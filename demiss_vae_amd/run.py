@@ -8,7 +8,8 @@ the enum members the constructors annotate (what jsonargparse does for the refer
 MissingDataModule, `trainer:` supplies max_epochs / max_steps / gradient clipping.  The loop is the part of
 Lightning's fit loop these models use: setup hooks, automatic or manual optimisation, per-step schedulers,
 gradient clipping through the model's hook, a validation pass per epoch, epoch means of everything passed to
-`self.log`, a final checkpoint (state_dict + hyper-parameters).  One process per GPU; under torchrun the gradients
+`self.log`, a final checkpoint (state_dict + hyper-parameters).  On one GPU with residual-MLP networks a whole
+optimisation step is recorded in a HIP graph and replayed (`--trainer.hip_graph false` turns that off).  One process per GPU; under torchrun the gradients
 are all-reduced (demiss_vae_amd.parallel) and each rank trains on its own fixed part of the training split."""
 import argparse
 import enum
@@ -136,6 +137,122 @@ def init_distributed():
         dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
 
 
+class _DeferredScheduler:
+    """stands in for the scheduler while a step is recorded: the recording must not bake a learning rate in, so the
+    real scheduler is stepped after every replay instead"""
+
+    def step(self, *a, **k):
+        pass
+
+
+class _StepRunner:
+    """One optimisation step on a batch: eagerly, or - once a batch shape has been seen twice - as the replay of a HIP
+    graph of the whole step (model step, backward, clipping, optimiser).  The learning rates live in device tensors
+    the scheduler writes between replays; the library's noise stays fresh through its device counter
+    (demiss_vae_amd.rng.CaptureStream).  A recording is keyed by everything the step's host-side control flow
+    depends on: batch rows and the epoch-dependent switches of the model."""
+
+    def __init__(self, model, opt, sched, params, clip_val, clip_alg, use_graph, log=print):
+        self.model, self.opt, self.sched, self.params, self.log = model, opt, sched, params, log
+        self.clip_val, self.clip_alg = clip_val, clip_alg
+        self.use_graph = use_graph
+        self.seen, self.graphs, self.static = {}, {}, {}
+        self.replays = 0
+        self.side = torch.cuda.Stream() if use_graph else None
+        if use_graph:
+            for g in opt.param_groups:
+                g["capturable"] = True
+                g["lr"] = torch.tensor(float(g["lr"]), device=params[0].device)
+            if sched is not None:          # the scheduler remembers the initial rates as floats: give it tensors' values
+                sched.base_lrs = [float(b) for b in sched.base_lrs]
+
+    def _key(self, batch):
+        m, h = self.model, self.model.hparams
+        key = [tuple(batch[0].shape)]
+        if getattr(m, "train_imp_distribution", None) is not None:      # imputations start after a delay
+            key.append(m.current_epoch >= h.mvb_delay_imputation)
+        if h.get("marginal_eval_train"):
+            key.append(m.current_epoch % h.marginal_eval_freq == 0 or m.current_epoch == (m.trainer.max_epochs or 0) - 1)
+        return tuple(key)
+
+    def _body(self, batch):
+        m, opt = self.model, self.opt
+        if m.automatic_optimization:
+            loss = m.training_step(batch, 0)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            P.allreduce_grads(self.params)
+            m.configure_gradient_clipping(opt, 0, gradient_clip_val=self.clip_val, gradient_clip_algorithm=self.clip_alg)
+            opt.step()
+        else:
+            m.training_step(batch, 0)          # the model steps its optimiser itself (two-loss DeMissVAE step)
+
+    def _after(self):
+        sched = self.sched
+        if sched is None or not (self.model.automatic_optimization or self.model.hparams.get("use_lr_scheduler")):
+            return
+        if self.use_graph and hasattr(sched, "_get_closed_form_lr"):
+            # the same schedule evaluated in closed form on the host: one small write per group instead of the
+            # scheduler's chained tensor arithmetic on the device-resident rates
+            sched.last_epoch += 1
+            values = sched._get_closed_form_lr()
+            for g, lr in zip(self.opt.param_groups, values):
+                g["lr"].fill_(float(lr))
+            sched._last_lr = [float(v) for v in values]
+        else:
+            sched.step()
+
+    def _eager(self, batch, stream=None):
+        m = self.model
+        if stream is not None:
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                self._body(batch)
+            torch.cuda.current_stream().wait_stream(stream)
+        else:
+            self._body(batch)
+        if m.automatic_optimization or self.use_graph:
+            self._after()
+
+    def __call__(self, batch):
+        if not self.use_graph:
+            return self._eager(batch)
+        from .graph import GraphedStep
+        if not self.model.automatic_optimization:
+            self.model._schedulers = _DeferredScheduler()
+        key = self._key(batch)
+        n = self.seen.get(key, 0)
+        self.seen[key] = n + 1
+        if n < 2:                                   # lazily created state (optimiser, workspaces) must exist first
+            return self._eager(batch, self.side)
+        if key not in self.graphs:
+            static = tuple(t.clone() for t in batch)
+            m = self.model
+            nets = tuple(m.engine()[1:]) if getattr(getattr(m, "model", m), "fused", False) else ()
+            logged = {}
+
+            def body():
+                m._logged = logged
+                logged.clear()
+                self._body(static)
+            try:
+                self.graphs[key] = GraphedStep(body, nets=nets, warmup=0)
+            except Exception as e:                  # a step that synchronises with the host cannot be recorded
+                self.log(f"[run] step not recordable ({type(e).__name__}: {e}); continuing without graphs")
+                self.use_graph = False
+                self.model._schedulers = self.sched
+                torch.cuda.synchronize()
+                return self._eager(batch)
+            self.static[key] = (static, logged)
+        static, logged = self.static[key]
+        for dst, src in zip(static, batch):
+            dst.copy_(src)
+        self.graphs[key]()
+        self.replays += 1
+        self.model._logged = dict(logged)
+        self._after()
+
+
 def fit(model, datamodule, trainer_cfg, log=print):
     from . import rng
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
@@ -157,6 +274,9 @@ def fit(model, datamodule, trainer_cfg, log=print):
     sched = conf.get("lr_scheduler", {}).get("scheduler") if isinstance(conf, dict) else None
     model._optimizers, model._schedulers = opt, sched
     params = [p for g in opt.param_groups for p in g["params"]]
+    inner = getattr(model, "model", model)
+    use_graph = bool(trainer_cfg.get("hip_graph", True)) and P.world() == 1 and getattr(inner, "fused", False)
+    run_step = _StepRunner(model, opt, sched, params, clip_val, clip_alg, use_graph, log=log)
     model.on_train_start()
     step, epoch, history, t0 = 0, 0, [], time.time()
     done = False
@@ -167,23 +287,14 @@ def fit(model, datamodule, trainer_cfg, log=print):
         means = _Means()
         for i, batch in enumerate(train_loader):
             model._logged = {}
-            if model.automatic_optimization:
-                loss = model.training_step(batch, i)
-                opt.zero_grad(set_to_none=True)
-                loss.backward()
-                P.allreduce_grads(params)
-                model.configure_gradient_clipping(opt, 0, gradient_clip_val=clip_val, gradient_clip_algorithm=clip_alg)
-                opt.step()
-                if sched is not None:
-                    sched.step()
-            else:
-                model.training_step(batch, i)      # the model steps its optimiser itself (two-loss DeMissVAE step)
+            run_step(batch)
             means.add(model._logged)
             step += 1
             model.global_step = step
             if max_steps != -1 and step >= max_steps:
                 done = True
                 break
+        model._schedulers = sched
         model.on_train_epoch_end()
         model.eval()
         model._logged = {}
@@ -200,6 +311,9 @@ def fit(model, datamodule, trainer_cfg, log=print):
             log(json.dumps(row))
         epoch += 1
     model.on_train_end()
+    trainer.hip_graph_replays = run_step.replays
+    if P.rank() == 0:
+        log(json.dumps({"steps": step, "hip_graph_replays": run_step.replays}))
     return history
 
 

@@ -97,3 +97,25 @@ def test_small_batch_and_large_batch_kernels_agree_bitwise():
         assert torch.equal(y1, y3) and torch.equal(dx1, dx3)
         for a, b in zip(gw1, gw3):                 # weight gradients: different row slicing, same values to rounding
             torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * float(a.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+def test_packed_weights_follow_optimizer_steps(fused):
+    """torch's fused optimisers update parameters without bumping their version counters: the fragment image must
+    still be rebuilt after a step (the forward after the step = a forward through a freshly packed copy)."""
+    import demiss_vae_amd as dmv
+    from oracle.recipes import NetSpec, make_params
+    import gpu_util as G
+    spec = NetSpec(16, 16, 2, 64)
+    net = G.packed_net(spec, make_params(spec, 5))
+    x = torch.randn(96, 16, device="cuda")
+    y0, _ = dmv.mlp_forward(net, x, 16, 96)
+    opt = torch.optim.Adam(net.params(), lr=1e-2, fused=fused)
+    for p in net.params():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    y1, _ = dmv.mlp_forward(net, x, 16, 96)
+    fresh = dmv.PackedNet(net.dims, [w.detach().clone() for w in net.weights], [b.detach().clone() for b in net.biases])
+    y2, _ = dmv.mlp_forward(fresh, x, 16, 96)
+    assert not torch.equal(y0, y1) and torch.equal(y1, y2)

@@ -105,13 +105,19 @@ def workdir(tmp_path_factory):
     return root
 
 
-def launch(workdir, name, text, *extra):
+def launch(workdir, name, text, *extra, recordable=True):
     from demiss_vae_amd import run
     path = workdir / f"{name}.yaml"
     path.write_text(text.replace("ROOT", str(workdir)))
     lines = []
     history, results = run.main(["--config", str(path), "--data.data_root", str(workdir / "data"),
                                  "--trainer.default_root_dir", str(workdir), *extra], log=lines.append)
+    summary = [json.loads(l) for l in lines if str(l).startswith('{"steps"')][0]
+    if recordable:      # every batch shape runs eagerly twice, then as a replay of its recording
+        assert not any("not recordable" in str(l) for l in lines)
+        assert summary["hip_graph_replays"] >= summary["steps"] - 6, summary
+    else:               # a step that synchronises with the host falls back to eager execution, loudly
+        assert any("not recordable" in str(l) for l in lines) and summary["hip_graph_replays"] < summary["steps"]
     return history, results, lines
 
 
@@ -144,7 +150,8 @@ def test_control_study_config_with_oracle_imputations(workdir):
         interpolate_alpha: 0.5
 """)
     assert "VAESampler_MoG_Oracle" in text
-    history, _, _ = launch(workdir, "oracle", text)
+    # the oracle sampler's batched factorisations synchronise with the host, so its steps are not recorded
+    history, _, _ = launch(workdir, "oracle", text, recordable=False)
     assert len(history) == 2 and all(math.isfinite(v) for row in history for v in row.values())
     assert history[1]["marginal_logprob/val"] > history[0]["marginal_logprob/val"]
 

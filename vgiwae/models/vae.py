@@ -160,9 +160,11 @@ class VAE(ImputerModuleBase, PLEstimateTotalTrainSteps):
     def configure_optimizers(self):
         """Adam with one parameter group per network and an optional per-step cosine schedule (vae.py:349-374)."""
         h = self.hparams
+        # one fused kernel per parameter group when the parameters live on the GPU (same update rule)
+        fused = all(p.is_cuda for p in self.parameters())
         opt = torch.optim.Adam([
             {"params": self.generator_network.parameters(), "amsgrad": h.amsgrad_generator, "lr": h.lr_generator},
-            {"params": self.var_latent_network.parameters(), "amsgrad": h.amsgrad_latent, "lr": h.lr_latent}])
+            {"params": self.var_latent_network.parameters(), "amsgrad": h.amsgrad_latent, "lr": h.lr_latent}], fused=fused)
         out = {"optimizer": opt}
         if h.use_lr_scheduler:
             steps = h.max_scheduler_steps if h.max_scheduler_steps != -1 else self.estimated_num_training_steps
