@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--with-conv", action="store_true",
                     help="also time the image DeMissVAE step with convolutional trunks (MIOpen warm-up takes a while)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--torch-optim", action="store_true",
+                    help="clip_grad_norm_ + torch.optim.Adam(fused) instead of the library's clip + Adam step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--kernels-only", action="store_true",
                     help="only launch the decoder MLP kernels of the roofline record (for rocprofv3 runs)")
@@ -207,8 +209,12 @@ def main():
     if args.kernels_only:
         print(json.dumps({"roofline": kernel_roofline(dec, dec_s, B * K, device)}))
         return
-    opt = torch.optim.Adam([{"params": dec.params(), "amsgrad": True, "lr": 1e-3},
-                            {"params": enc.params(), "amsgrad": True, "lr": 1e-3}], fused=True)
+    groups = [{"params": dec.params(), "amsgrad": True, "lr": 1e-3}, {"params": enc.params(), "amsgrad": True, "lr": 1e-3}]
+    if args.torch_optim:        # stock torch: clip_grad_norm_ + fused Adam (about a dozen launches)
+        opt = torch.optim.Adam(groups, fused=True)
+    else:                       # the library's clip + AMSGrad step (three launches; what the model classes use)
+        from demiss_vae_amd.optim import Adam
+        opt = Adam(groups)
 
     def barrier():
         if dist:
@@ -223,7 +229,10 @@ def main():
         fwd_bwd()
         if dist:
             allreduce_grads(params)
-        torch.nn.utils.clip_grad_norm_(params, 5.0, foreach=True)
+        if args.torch_optim:
+            torch.nn.utils.clip_grad_norm_(params, 5.0, foreach=True)
+        else:
+            opt.clip_on_next_step(5.0)
         opt.step()
 
     dbg("model built")
@@ -272,30 +281,20 @@ def main():
             d2 = make_gas(device, 512)
             dims2, enc2, dec2, X2, M2 = d2[0], d2[1], d2[2], d2[5], d2[6]
             p2 = enc2.params() + dec2.params()
-            opt2 = torch.optim.Adam(p2, lr=1e-3, amsgrad=True, fused=True)
+            from demiss_vae_amd.optim import Adam as LibAdam
+            opt2 = LibAdam(p2, lr=1e-3, amsgrad=True)
 
             def step512():
                 opt2.zero_grad(set_to_none=True)
                 b, _ = dmv.estimate_iwelbo(dims2, enc2, dec2, X2, M2, num_latent_samples=1, num_importance_samples=K, STL=True)
                 (-b).backward()
-                torch.nn.utils.clip_grad_norm_(p2, 5.0, foreach=True)
+                opt2.clip_on_next_step(5.0)
                 opt2.step()
 
             t512 = timed(step512, 50, 10, barrier)
             extra["yaml_batch_512"] = {"ms_per_step": round(t512 * 1e3, 4), "samples_per_s": round(512 * K / t512, 1)}
-            # the same step recorded once in a HIP graph (noise refilled outside the recording)
-            opt3 = torch.optim.Adam(p2, lr=1e-3, amsgrad=True, fused=True, capturable=True)
-            eps512 = torch.empty(1, K, 512, dims2.Zd, device=device)
-
-            def body512():
-                opt3.zero_grad(set_to_none=True)
-                b, _ = dmv.estimate_iwelbo(dims2, enc2, dec2, X2, M2, num_latent_samples=1, num_importance_samples=K, STL=True,
-                                           eps=eps512)
-                (-b).backward()
-                torch.nn.utils.clip_grad_norm_(p2, 5.0, foreach=True)
-                opt3.step()
-
-            g512 = dmv.GraphedStep(body512, refresh=lambda: eps512.normal_(), nets=(enc2, dec2))
+            # the same step recorded once in a HIP graph (library noise: fresh on every replay)
+            g512 = dmv.GraphedStep(step512, nets=(enc2, dec2))
             tg = timed(g512, 200, 20, barrier)
             extra["yaml_batch_512_hip_graph"] = {"ms_per_step": round(tg * 1e3, 4), "samples_per_s": round(512 * K / tg, 1)}
             from demiss_vae_amd.bench_extra import demiss_toy_step, missiwae_step

@@ -38,6 +38,10 @@ class DmvLatentBwd(C.Structure):
                 ("mix_kind", C.c_int32)]
 
 
+class DmvAdamGroup(C.Structure):
+    _fields_ = [("lr", C.c_void_p), ("step", C.c_void_p), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
+
+
 _P = C.c_void_p
 _I64 = C.c_int64
 _I32 = C.c_int32
@@ -72,6 +76,8 @@ SIGNATURES = {
     "dmv_obj_backward_latent_implicit": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _P, _P, _I64, _P, _I64, _P, _F, _F, _P, _P, _P]),
     "dmv_grid_marginal_ws_floats": (_SZ, [_I64, _I32]),
     "dmv_grid_marginal": (C.c_int, [_I32, _I32, _I64, _P, _I64, _P, _I32, _P, _P, _P, _P, _P, _P]),
+    "dmv_opt_ws_floats": (_SZ, [_I32, _P]),
+    "dmv_opt_adam_step": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _SZ, _P, _P]),
     "dmv_lse_update": (C.c_int, [_I32, _I64, _P, _I32, _P, _P, _P]),
     "dmv_rows_gather": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "dmv_rows_scatter": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),

@@ -8,6 +8,7 @@ from . import estimate_iwelbo, estimate_multiple_iwelbo, mvb2_objectives, ModelD
 from .mlp import make_keep_masks
 from . import imputation as imp
 from . import parallel as P
+from .optim import Adam
 
 
 def _sync_time(fn, steps, warmup):
@@ -39,7 +40,7 @@ def missiwae_step(device, name, B, D, Zd, enc_shape, dec_shape, C=5, dropout=0.0
     dims = ModelDims(D=D, Zd=Zd, q_dist="stratified_with_eps", C=C, encoder_use_mis_mask=True)
     X, M = make_batch(3, B, D)
     X, M = X.to(device), M.to(device)
-    opt = torch.optim.Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True, fused=True)
+    opt = Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True)
 
     def step():
         ek = make_keep_masks(enc.dims, B, device)
@@ -68,7 +69,7 @@ def iwae_step(device, B, I=5):
     dims = ModelDims(D=8, Zd=16, encoder_use_mis_mask=True)
     X, M = make_batch(3, B, 8)
     X, M = X.to(device), M.to(device)
-    opt = torch.optim.Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True, fused=True)
+    opt = Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True)
 
     def step():
         bound, _ = estimate_iwelbo(dims, enc, dec, X, M, num_importance_samples=I, STL=True)
@@ -96,7 +97,7 @@ def demiss_toy_step(device, B=4096, K=5):
     buf = imp.ImputationBuffer(X, K, device)
     Mdev = M.to(device)
     params = enc.params() + dec.params()
-    opt = torch.optim.Adam(params, lr=1e-3, amsgrad=True, fused=True)
+    opt = Adam(params, lr=1e-3, amsgrad=True)
     gen = torch.Generator(device=device)
     gen.manual_seed(0)
 

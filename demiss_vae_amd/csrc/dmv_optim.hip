@@ -1,0 +1,197 @@
+// Optimiser step of the training loop: global gradient-norm clipping + Adam / AMSGrad over all parameter tensors of
+// both networks in three launches (vgiwae/models/vae.py:349-390: torch.optim.Adam with two parameter groups, then
+// clip_grad_norm_ over all parameters; torch needs about a dozen launches for the same work, and its multi-tensor
+// Adam runs a 547 k-parameter model on ten workgroups).
+//
+//   k_opt_sumsq   partial sums of g^2 over fixed 4096-element chunks (one workgroup per chunk: the summation order
+//                 does not depend on the launch geometry)
+//   k_opt_prep    one workgroup: total norm -> clip coefficient min(1, max_norm / (norm + 1e-6)) (torch's
+//                 clip_grad_norm_), step counters += 1, bias corrections per group
+//   k_opt_apply   one workgroup per chunk:  g' = coef g;  m = m + (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;
+//                 [vmax = max(vmax, v)];  p -= (lr / (1 - b1^t)) m / (sqrt(v or vmax) / sqrt(1 - b2^t) + eps)
+// Tensor tables travel by value in the kernel arguments (like torch's multi-tensor kernels), so a recorded step
+// replays against the same gradient addresses without host copies.  Learning rates and step counters are read from
+// device memory: schedulers and replays change them without re-recording.
+#include "dmv_common.h"
+
+namespace {
+
+constexpr int kChunk = 4096;
+constexpr int kMaxT = DMV_OPT_MAX_TENSORS;
+constexpr int kMaxG = DMV_OPT_MAX_GROUPS;
+
+struct OptTable {
+  int n;
+  int first_chunk[kMaxT + 1];   // prefix sums of ceil(numel / kChunk)
+  float* p[kMaxT];
+  const float* g[kMaxT];
+  float* m[kMaxT];
+  float* v[kMaxT];
+  float* vmax[kMaxT];           // null: plain Adam
+  int numel[kMaxT];
+  signed char group[kMaxT];
+};
+
+struct OptGroups {
+  int n;
+  const float* lr[kMaxG];       // device scalars
+  float* step[kMaxG];           // device scalars (float counters, like torch's capturable optimisers)
+  float beta1[kMaxG], beta2[kMaxG], eps[kMaxG];
+  float omb1[kMaxG], omb2[kMaxG];  // 1 - beta, rounded from double
+  double beta1d[kMaxG], beta2d[kMaxG];
+};
+
+// state block at the head of the workspace
+struct OptState {
+  float coef;
+  float bc1[kMaxG];
+  float bc2_sqrt[kMaxG];
+};
+
+__device__ inline int find_tensor(const OptTable& t, int chunk) {
+  int lo = 0, hi = t.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.first_chunk[mid] <= chunk) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__device__ inline float block_sum(float x, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) red[wave] = x;
+  __syncthreads();
+  float s = 0.f;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;   // valid in thread 0
+}
+
+__global__ void k_opt_sumsq(OptTable t, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int chunk = blockIdx.x;
+  const int ti = find_tensor(t, chunk);
+  const int base = (chunk - t.first_chunk[ti]) * kChunk;
+  const int end = min(base + kChunk, t.numel[ti]);
+  const float* g = t.g[ti];
+  float acc = 0.f;
+  for (int i = base + threadIdx.x; i < end; i += blockDim.x) { const float x = g[i]; acc += x * x; }
+  const float s = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[chunk] = s;
+}
+
+__global__ void k_opt_prep(OptGroups gr, int n_chunks, float max_norm, const float* __restrict__ partial, OptState* st,
+                           float* norm_out) {
+  __shared__ float red[4];
+  float coef = 1.f;
+  if (max_norm > 0.f) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n_chunks; i += blockDim.x) acc += partial[i];
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+      const float norm = sqrtf(tot);
+      if (norm_out) norm_out[0] = norm;
+      coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+    }
+  }
+  if (threadIdx.x == 0) {
+    st->coef = coef;
+    for (int g = 0; g < gr.n; ++g) {
+      const float s = gr.step[g][0] + 1.f;
+      gr.step[g][0] = s;
+      st->bc1[g] = (float)(1.0 - pow(gr.beta1d[g], (double)s));          // double, like torch's host-side scalars
+      st->bc2_sqrt[g] = (float)sqrt(1.0 - pow(gr.beta2d[g], (double)s));
+    }
+  }
+}
+
+__global__ void k_opt_apply(OptTable t, OptGroups gr, const OptState* __restrict__ st) {
+  const int chunk = blockIdx.x;
+  const int ti = find_tensor(t, chunk);
+  const int base = (chunk - t.first_chunk[ti]) * kChunk;
+  const int end = min(base + kChunk, t.numel[ti]);
+  const int gi = t.group[ti];
+  const float coef = st->coef, b2 = gr.beta2[gi], eps = gr.eps[gi], omb1 = gr.omb1[gi], omb2 = gr.omb2[gi];
+  const float step_size = gr.lr[gi][0] / st->bc1[gi], bc2s = st->bc2_sqrt[gi];
+  float* p = t.p[ti];
+  const float* g = t.g[ti];
+  float* m = t.m[ti];
+  float* v = t.v[ti];
+  float* vm = t.vmax[ti];
+  for (int i = base + threadIdx.x; i < end; i += blockDim.x) {
+    const float gs = g[i] * coef;
+    float mi = m[i], vi = v[i];
+    mi = mi + omb1 * (gs - mi);
+    vi = b2 * vi + omb2 * gs * gs;
+    m[i] = mi;
+    v[i] = vi;
+    float d = vi;
+    if (vm) { d = fmaxf(vm[i], vi); vm[i] = d; }
+    p[i] = p[i] - step_size * (mi / (sqrtf(d) / bc2s + eps));
+  }
+}
+
+}  // namespace
+
+extern "C" size_t dmv_opt_ws_floats(int32_t n, const int64_t* numel) {
+  if (n < 1 || n > kMaxT || !numel) return 0;
+  size_t chunks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (numel[i] < 0 || numel[i] > 0x7fffffff) return 0;
+    chunks += (size_t)((numel[i] + kChunk - 1) / kChunk);
+  }
+  return (sizeof(OptState) + 3) / 4 + chunks + 1;
+}
+
+extern "C" int dmv_opt_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
+                                 float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
+                                 const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm,
+                                 float* ws, size_t ws_floats, float* norm_out, void* stream) {
+  if (n < 1 || n > kMaxT || n_groups < 1 || n_groups > kMaxG) return DMV_E_UNSUPPORTED;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !group_of || !groups || !ws) return DMV_E_BADARG;
+  if (ws_floats < dmv_opt_ws_floats(n, numel) || dmv_opt_ws_floats(n, numel) == 0) return DMV_E_WORKSPACE;
+  OptTable t;
+  t.n = n;
+  int chunks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || group_of[i] < 0 || group_of[i] >= n_groups) return DMV_E_BADARG;
+    t.first_chunk[i] = chunks;
+    chunks += (int)((numel[i] + kChunk - 1) / kChunk);
+    t.p[i] = params[i]; t.g[i] = grads[i]; t.m[i] = exp_avg[i]; t.v[i] = exp_avg_sq[i];
+    t.vmax[i] = max_exp_avg_sq ? max_exp_avg_sq[i] : nullptr;
+    t.numel[i] = (int)numel[i];
+    t.group[i] = (signed char)group_of[i];
+  }
+  t.first_chunk[n] = chunks;
+  for (int i = n; i < kMaxT; ++i) { t.first_chunk[i + 1] = chunks; t.numel[i] = 0; t.group[i] = 0; t.p[i] = nullptr; t.g[i] = nullptr; t.m[i] = nullptr; t.v[i] = nullptr; t.vmax[i] = nullptr; }
+  OptGroups gr;
+  gr.n = n_groups;
+  for (int g = 0; g < kMaxG; ++g) {
+    const bool live = g < n_groups;
+    if (live && (!groups[g].lr || !groups[g].step)) return DMV_E_BADARG;
+    gr.lr[g] = live ? groups[g].lr : nullptr;
+    gr.step[g] = live ? groups[g].step : nullptr;
+    gr.beta1[g] = live ? (float)groups[g].beta1 : 0.f;
+    gr.beta2[g] = live ? (float)groups[g].beta2 : 0.f;
+    gr.eps[g] = live ? (float)groups[g].eps : 0.f;
+    gr.beta1d[g] = live ? groups[g].beta1 : 0.0;
+    gr.beta2d[g] = live ? groups[g].beta2 : 0.0;
+    gr.omb1[g] = live ? (float)(1.0 - groups[g].beta1) : 0.f;
+    gr.omb2[g] = live ? (float)(1.0 - groups[g].beta2) : 0.f;
+  }
+  if (chunks == 0) return DMV_OK;
+  OptState* st = (OptState*)ws;
+  float* partial = ws + (sizeof(OptState) + 3) / 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (max_norm > 0.f) {
+    hipLaunchKernelGGL(k_opt_sumsq, dim3((unsigned)chunks), dim3(256), 0, s, t, partial);
+    DMV_HIP_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_opt_prep, dim3(1), dim3(256), 0, s, gr, chunks, max_norm, partial, st, norm_out);
+  DMV_HIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_opt_apply, dim3((unsigned)chunks), dim3(256), 0, s, t, gr, st);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}

@@ -104,8 +104,12 @@ except Exception:  # ModuleNotFoundError here; any import-time failure means "no
         def clip_gradients(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):
             if not gradient_clip_val:
                 return
+            by_norm = (gradient_clip_algorithm or "norm") == "norm"
+            if by_norm and hasattr(optimizer, "clip_on_next_step"):
+                optimizer.clip_on_next_step(gradient_clip_val)      # folded into the optimiser's own kernels
+                return
             params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
-            if (gradient_clip_algorithm or "norm") == "norm":
+            if by_norm:
                 torch.nn.utils.clip_grad_norm_(params, gradient_clip_val)
             else:
                 torch.nn.utils.clip_grad_value_(params, gradient_clip_val)

@@ -159,7 +159,8 @@ class _StepRunner:
         self.seen, self.graphs, self.static = {}, {}, {}
         self.replays = 0
         self.side = torch.cuda.Stream() if use_graph else None
-        if use_graph:
+        self.own = hasattr(opt, "sync_lr")          # demiss_vae_amd.optim.Adam keeps its rates on the device itself
+        if use_graph and not self.own:
             for g in opt.param_groups:
                 g["capturable"] = True
                 g["lr"] = torch.tensor(float(g["lr"]), device=params[0].device)
@@ -191,7 +192,10 @@ class _StepRunner:
         sched = self.sched
         if sched is None or not (self.model.automatic_optimization or self.model.hparams.get("use_lr_scheduler")):
             return
-        if self.use_graph and hasattr(sched, "_get_closed_form_lr"):
+        if self.own:
+            sched.step()
+            self.opt.sync_lr()
+        elif self.use_graph and hasattr(sched, "_get_closed_form_lr"):
             # the same schedule evaluated in closed form on the host: one small write per group instead of the
             # scheduler's chained tensor arithmetic on the device-resident rates
             sched.last_epoch += 1

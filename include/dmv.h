@@ -272,6 +272,30 @@ int dmv_categorical_draw(int32_t B, int32_t P, int32_t K, const float* logits, c
 int dmv_dropout_masks(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_base,
                       void* stream);
 
+/* Optimiser step (vgiwae/models/vae.py:349-390: Adam / AMSGrad with one parameter group per network, preceded by
+ * clip_grad_norm_ over all parameters; shared/mvb2_manual_optimisation.py:9-11).  One call =
+ *   norm = || all grads ||_2;  coef = max_norm > 0 ? min(1, max_norm / (norm + 1e-6)) : 1;  g' = coef * g   (grads are
+ *   left untouched in memory);  step[group] += 1;  Adam update of every tensor with its group's hyper-parameters:
+ *   m += (1-b1)(g'-m);  v = b2 v + (1-b2) g'^2;  [vmax = max(vmax, v)];
+ *   p -= lr / (1-b1^t) * m / (sqrt(vmax or v) / sqrt(1-b2^t) + eps).
+ * params / grads / exp_avg / exp_avg_sq / max_exp_avg_sq: host arrays of n device pointers (max_exp_avg_sq == NULL or
+ * an entry NULL: no AMSGrad for that tensor); numel[i] elements each; group_of[i] in [0, n_groups).
+ * groups[g].lr and .step are device scalars (float): schedulers write lr, the call increments step.
+ * ws: dmv_opt_ws_floats(n, numel) floats.  norm_out (nullable device scalar) receives the gradient norm.
+ * The pointers are passed to the kernels by value: a step recorded in a HIP graph replays without host copies. */
+#define DMV_OPT_MAX_TENSORS 72
+#define DMV_OPT_MAX_GROUPS 4
+typedef struct DmvAdamGroup {
+  const float* lr;
+  float* step;
+  double beta1, beta2, eps; /* doubles: 1 - beta is formed in double precision before rounding, as torch does */
+} DmvAdamGroup;
+size_t dmv_opt_ws_floats(int32_t n, const int64_t* numel);
+int dmv_opt_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
+                      float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
+                      const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm, float* ws,
+                      size_t ws_floats, float* norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,3 +119,40 @@ def test_packed_weights_follow_optimizer_steps(fused):
     fresh = dmv.PackedNet(net.dims, [w.detach().clone() for w in net.weights], [b.detach().clone() for b in net.biases])
     y2, _ = dmv.mlp_forward(fresh, x, 16, 96)
     assert not torch.equal(y0, y1) and torch.equal(y1, y2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", [0.0, 0.05])
+def test_library_adam_matches_torch_adam(clip):
+    """dmv_opt_adam_step vs torch.nn.utils.clip_grad_norm_ + torch.optim.Adam (two groups, AMSGrad on one of them,
+    odd tensor sizes, a changing learning rate) over several steps; also the state_dict layout."""
+    from demiss_vae_amd.optim import Adam
+    torch.manual_seed(0)
+    shapes = [(256, 16), (256,), (5000,), (3, 7), (1,), (4097,)]
+    mine = [torch.randn(s, device="cuda").requires_grad_() for s in shapes]
+    ref = [p.detach().clone().requires_grad_() for p in mine]
+
+    def groups(ps):
+        return [{"params": ps[:3], "lr": 1e-2, "amsgrad": True}, {"params": ps[3:], "lr": 3e-3, "amsgrad": False}]
+    a, b = Adam(groups(mine)), torch.optim.Adam(groups(ref))
+    for step in range(6):
+        gs = [torch.randn(s, device="cuda") * (10.0 if step == 2 else 0.1) for s in shapes]
+        for p, q, g in zip(mine, ref, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        if clip:
+            a.clip_on_next_step(clip)
+            norm = torch.nn.utils.clip_grad_norm_(ref, clip)
+        if step == 3:
+            for o in (a, b):
+                o.param_groups[0]["lr"] = 5e-3
+        a.step(), b.step()
+        if clip:
+            torch.testing.assert_close(a.grad_norm, norm, rtol=1e-5, atol=0)
+        for p, q in zip(mine, ref):
+            torch.testing.assert_close(p, q, rtol=1e-5, atol=5e-7)
+    sa, sb = a.state_dict()["state"], b.state_dict()["state"]
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        assert sa[k].keys() == sb[k].keys() and float(sa[k]["step"]) == float(sb[k]["step"]) == 6
+        torch.testing.assert_close(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+    assert torch.equal(mine[0].grad, gs[0])                                # gradients are not rescaled in memory

@@ -160,11 +160,9 @@ class VAE(ImputerModuleBase, PLEstimateTotalTrainSteps):
     def configure_optimizers(self):
         """Adam with one parameter group per network and an optional per-step cosine schedule (vae.py:349-374)."""
         h = self.hparams
-        # one fused kernel per parameter group when the parameters live on the GPU (same update rule)
-        fused = all(p.is_cuda for p in self.parameters())
-        opt = torch.optim.Adam([
-            {"params": self.generator_network.parameters(), "amsgrad": h.amsgrad_generator, "lr": h.lr_generator},
-            {"params": self.var_latent_network.parameters(), "amsgrad": h.amsgrad_latent, "lr": h.lr_latent}], fused=fused)
+        groups = [{"params": list(self.generator_network.parameters()), "amsgrad": h.amsgrad_generator, "lr": h.lr_generator},
+                  {"params": list(self.var_latent_network.parameters()), "amsgrad": h.amsgrad_latent, "lr": h.lr_latent}]
+        opt = _adam(groups)
         out = {"optimizer": opt}
         if h.use_lr_scheduler:
             steps = h.max_scheduler_steps if h.max_scheduler_steps != -1 else self.estimated_num_training_steps
@@ -174,6 +172,16 @@ class VAE(ImputerModuleBase, PLEstimateTotalTrainSteps):
 
     def configure_gradient_clipping(self, optimizer, optimizer_idx, gradient_clip_val=None, gradient_clip_algorithm=None):
         self.clip_gradients(optimizer, gradient_clip_val=gradient_clip_val, gradient_clip_algorithm=gradient_clip_algorithm)
+
+
+def _adam(groups):
+    """The library's Adam (same update rule; clipping and both groups in three launches) for fp32 parameters on the
+    GPU, torch's otherwise."""
+    params = [p for g in groups for p in g["params"]]
+    if params and all(p.is_cuda and p.dtype == torch.float32 for p in params) and len(params) <= 72:
+        from demiss_vae_amd.optim import Adam
+        return Adam(groups)
+    return torch.optim.Adam(groups)
 
 
 def _inner(model):

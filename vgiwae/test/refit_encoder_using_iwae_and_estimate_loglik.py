@@ -91,9 +91,9 @@ class RefitEncoderUsingIWAE(LightningModule, PLEstimateTotalTrainSteps):
 
     def configure_optimizers(self):
         h = self.hparams
-        enc_params = list(self.model.var_latent_network.parameters())
-        opt = torch.optim.Adam([{"params": enc_params, "amsgrad": h.amsgrad_latent, "lr": h.lr_latent}],
-                               fused=all(p.is_cuda for p in enc_params))
+        from vgiwae.models.vae import _adam
+        opt = _adam([{"params": list(self.model.var_latent_network.parameters()), "amsgrad": h.amsgrad_latent,
+                      "lr": h.lr_latent}])
         out = {"optimizer": opt}
         if h.use_lr_scheduler:
             steps = h.max_scheduler_steps if h.max_scheduler_steps != -1 else self.estimated_num_training_steps
