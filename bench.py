@@ -93,6 +93,25 @@ def event_time(fn, reps):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+def profiled_traffic(rows, kernel):
+    """HBM bytes per launch of the named kernel at this size, from the committed rocprofv3 PMC passes of
+    `bench.py --kernels-only` (FETCH_SIZE / WRITE_SIZE in runs of their own, gfx950 unit correction applied by
+    tools/summarize_prof.py); counters cannot be collected from inside this process, so null without the summary."""
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_decoder_kernels.md")
+    try:
+        if rows != 163840:
+            return {"traffic": None}
+        text = open(path).read()
+        head = {"k_mlp_fwd": "### void k_mlp_fwd", "k_mlp_bwd": "### void k_mlp_bwd"}.get(kernel, "### k_mlp_wgrad")
+        sec = text[text.index(head):]
+        m = re.search(r"HBM read bytes[^=]*=[^=]*= ([\d.,]+) MB; written = ([\d.,]+) MB", sec)
+        return {"traffic": sum(float(m.group(i).replace(",", "")) for i in (1, 2)) * 1e6, "traffic_unit": "bytes per launch",
+                "traffic_source": "profiles/r1_decoder_kernels.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 163840 rows)"}
+    except Exception:
+        return {"traffic": None}
+
+
 def kernel_roofline(dec, dec_s, rows, device):
     """Times the three decoder MLP kernels on their own (forward, input-gradient chain, weight-gradient
     GEMM + split fold) and returns the roofline record of the slowest, plus all three."""
@@ -135,7 +154,7 @@ def kernel_roofline(dec, dec_s, rows, device):
     name = max(parts, key=lambda k: parts[k]["ms"])
     ach = parts[name]["tflops"]
     roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), **profiled_traffic(rows, name),
             "flops_per_launch": flops, "ms_per_launch": round(parts[name]["ms"], 4),
             "all_kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in parts.items()}}
     return roof
