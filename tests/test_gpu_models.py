@@ -420,3 +420,38 @@ def test_graph_replays_draw_fresh_library_noise():
     assert len({round(float(b.mean()), 5) for b in bounds}) == 5       # the bound is re-estimated with fresh noise
     eager = torch.stack([body().mean() for _ in range(20)]).mean()
     assert abs(float(torch.stack(bounds).mean()) - float(eager)) < 0.5
+
+
+def test_fully_connected_networks_run_through_the_caller_network_engine():
+    """FullyConnectedNetwork trunks (torch modules) with the kernels at their outputs: IWAE bound and gradients vs the
+    same computation in float64 tensor operations on the CPU."""
+    import copy
+    from oracle import core
+    from oracle.recipes import NetSpec, make_batch
+    from vgiwae.models import IWAE
+    from vgiwae.models.iwae import estimate_iwelbo
+    from vgiwae.shared.neural_nets import FullyConnectedNetwork
+    from vgiwae.shared.vae_enums import DISTRIBUTION
+    torch.manual_seed(3)
+    D, Zd, B, I = 6, 3, 9, 4
+    dec, enc = FullyConnectedNetwork([Zd, 24, 2 * D]), FullyConnectedNetwork([2 * D, 24, 24, 2 * Zd], activation=torch.tanh)
+    ref_dec, ref_enc = copy.deepcopy(dec).double(), copy.deepcopy(enc).double()
+    model = IWAE(generator_network=dec, generator_distribution=DISTRIBUTION.normal_with_eps, var_latent_network=enc,
+                 var_latent_distribution=DISTRIBUTION.normal_with_eps, num_latent_samples=1, num_importance_samples=I,
+                 lr_generator=1e-3, lr_latent=1e-3, encoder_use_mis_mask=True, var_latent_STL=True).cuda().train()
+    assert not model.fused and model.latent_dims == Zd
+    X, M = make_batch(21, B, D)
+    eps = torch.randn(1, I, B, Zd)
+    bound = estimate_iwelbo(model, (X.cuda(), M.cuda()), var_latent_STL=True, num_importance_samples=I, eps=eps.cuda())
+    (-bound).backward()
+    spec = core.ModelSpec(D=D, Zd=Zd, enc=NetSpec(2 * D, 2 * Zd, 0, 1), dec=NetSpec(Zd, 2 * D, 0, 1), encoder_use_mis_mask=True)
+    Xd, Md = X.double(), M
+    mu, sigma, _ = core.q_heads(spec, ref_enc(core.encoder_input(spec, Xd * Md, Md.double())))
+    Z = mu + sigma * eps.double()
+    log_w = core.smis_log_weights(spec, ref_dec(Z), Xd, Md, Z, mu.detach(), sigma.detach())
+    want = (torch.logsumexp(log_w, 1) - np.log(I)).mean(0).mean()
+    (-want).backward()
+    np.testing.assert_allclose(bound.item(), want.item(), rtol=2e-5)
+    for mine, ref in ((dec, ref_dec), (enc, ref_enc)):
+        for (k, p), q in zip(mine.named_parameters(), ref.parameters()):
+            torch.testing.assert_close(p.grad.cpu().double(), q.grad, rtol=2e-3, atol=2e-5, msg=k)

@@ -90,9 +90,25 @@ class ResidualFCNetwork(nn.Module):
 
 
 class FullyConnectedNetwork(nn.Module):
-    """Named for import compatibility (vgiwae/shared/neural_nets.py:15-46).  No shipped config uses it and it
-    has no kernel here."""
+    """Plain stack of linear layers with an activation between them (vgiwae/shared/neural_nets.py:15-46); same
+    constructor and state_dict keys (`linear_layers.N.*`).  No shipped config uses it; it stays a torch module
+    (rocBLAS GEMMs) and the kernels take over at its outputs, like the convolutional trunks."""
 
     def __init__(self, layer_dims: List[int], *, activation: Callable = F.relu):
         super().__init__()
-        raise NotImplementedError("FullyConnectedNetwork is outside the accelerated path; use ResidualFCNetwork")
+        self.layer_dims, self.activation = layer_dims, activation
+        self.linear_layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(layer_dims[:-1], layer_dims[1:]))
+
+    @property
+    def latent_dim(self):          # what the model classes ask a decoder for
+        return self.layer_dims[0]
+
+    @property
+    def output_dim(self):
+        return self.layer_dims[-1]
+
+    def forward(self, inputs: torch.Tensor):
+        out = inputs
+        for layer in self.linear_layers[:-1]:
+            out = self.activation(layer(out))
+        return self.linear_layers[-1](out)
