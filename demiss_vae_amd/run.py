@@ -257,7 +257,42 @@ class _StepRunner:
         self._after()
 
 
-def fit(model, datamodule, trainer_cfg, log=print):
+class Checkpointer:
+    """What the reference's checkpoint callback does (train.py:66-79, vgiwae/overrides/model_checkpoint.py:11-66):
+    the best model by validation loss (one file, replaced when beaten; the refit configs' `load_best_model` looks for
+    exactly one file besides last.ckpt), the last model, and snapshots at chosen epochs / steps."""
+
+    def __init__(self, dirpath, model, model_config, *, keep_best=False, monitor="loss/val", epochs=(), steps=()):
+        self.dirpath, self.model, self.model_config = dirpath, model, model_config
+        self.keep_best, self.monitor = keep_best, monitor
+        self.epochs, self.steps = set(epochs or ()), set(steps or ())
+        self.best, self.best_path = float("inf"), None
+
+    def _save(self, name, **extra):
+        path = os.path.join(self.dirpath, name)
+        save_checkpoint(self.model, path, self.model_config, extra)
+        return path
+
+    def on_step(self, step):
+        if step in self.steps:
+            self._save(f"custom_ckpt_by_step_{step}.ckpt", global_step=step)
+
+    def on_validation_end(self, epoch, step, row):
+        value = row.get(self.monitor)
+        if self.keep_best and value is not None and value < self.best:
+            if self.best_path is not None and os.path.exists(self.best_path):
+                os.remove(self.best_path)
+            self.best = value
+            self.best_path = self._save(f"epoch={epoch}-step={step}.ckpt", epoch=epoch + 1, global_step=step,
+                                        monitor=self.monitor, value=value)
+        if epoch in self.epochs:
+            self._save(f"custom_ckpt_by_epoch_{epoch}.ckpt", epoch=epoch + 1, global_step=step)
+
+    def on_train_end(self, epochs, step):
+        self._save("last.ckpt", epoch=epochs, global_step=step)
+
+
+def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None):
     from . import rng
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     max_epochs = trainer_cfg.get("max_epochs")
@@ -295,6 +330,8 @@ def fit(model, datamodule, trainer_cfg, log=print):
             means.add(model._logged)
             step += 1
             model.global_step = step
+            if checkpointer is not None:
+                checkpointer.on_step(step)
             if max_steps != -1 and step >= max_steps:
                 done = True
                 break
@@ -313,8 +350,12 @@ def fit(model, datamodule, trainer_cfg, log=print):
         history.append(row)
         if P.rank() == 0:
             log(json.dumps(row))
+        if checkpointer is not None:
+            checkpointer.on_validation_end(epoch, step, row)
         epoch += 1
     model.on_train_end()
+    if checkpointer is not None:
+        checkpointer.on_train_end(epoch, step)
     trainer.hip_graph_replays = run_step.replays
     if P.rank() == 0:
         log(json.dumps({"steps": step, "hip_graph_replays": run_step.replays}))
@@ -369,17 +410,22 @@ def load_model(path, model_class=None):
     class the checkpoint was trained as, the way the reference's refit script picks the class to load with
     (refit_encoder_using_iwae_and_estimate_loglik.py:100-125)."""
     ckpt = torch.load(path, map_location="cpu", weights_only=True)
-    node = dict(ckpt["model_config"])
+    model = instantiate(retarget(ckpt["model_config"], model_class))
+    model.load_state_dict(ckpt["state_dict"])
+    return model
+
+
+def retarget(node, model_class=None):
+    """the YAML node of a model, rewritten for another class of vgiwae.models: keyword arguments of a diagnostic
+    wrapper the model was trained under mean nothing to a class without that wrapper"""
+    node = dict(node)
     if model_class is not None:
-        # keyword arguments of a diagnostic wrapper the checkpoint was trained under mean nothing to another class
         from vgiwae.models import _DIAGNOSTIC_KWARGS
         keep = next((set(kw) for suffix, kw in _DIAGNOSTIC_KWARGS.items() if model_class.endswith(suffix)), set())
         drop = set().union(*_DIAGNOSTIC_KWARGS.values()) - keep
         node["class_path"] = "vgiwae.models." + model_class
         node["init_args"] = {k: v for k, v in (node.get("init_args") or {}).items() if k not in drop}
-    model = instantiate(node)
-    model.load_state_dict(ckpt["state_dict"])
-    return model
+    return node
 
 
 def resolve_model_path(template, exp_dir, load_best=False):
@@ -434,22 +480,23 @@ def main(argv=None, log=print):
         path = resolve_model_path(cfg["model_path"], exp_dir, cfg.get("load_best_model", False))
         log("Using pre-trained model from: " + path)
         model.set_model(load_model(path, cfg.get("model_class")))
-        model_config = {**torch.load(path, map_location="cpu", weights_only=True)["model_config"]}
-        if cfg.get("model_class"):
-            model_config["class_path"] = "vgiwae.models." + cfg["model_class"]
+        model_config = retarget(torch.load(path, map_location="cpu", weights_only=True)["model_config"], cfg.get("model_class"))
     else:
         model = instantiate(cfg["model"])
         model_config = cfg["model"]
     seed_everything(cfg["seed_everything"])      # same generator state at the start of fitting whatever was built
-    history = fit(model, datamodule, trainer_cfg, log=log)
+    out = next_version_dir(exp_dir)
+    ckpt = None
+    if P.rank() == 0:
+        ckpt = Checkpointer(os.path.join(out, "checkpoints"), model, model_config,
+                            keep_best=bool(cfg.get("add_checkpoint_callback", False)),
+                            epochs=cfg.get("save_custom_epochs"), steps=cfg.get("save_custom_steps"))
+    history = fit(model, datamodule, trainer_cfg, log=log, checkpointer=ckpt)
     results = {}
     if refit and cfg.get("run_test", True):
         log("Estimating test-log-likelihood.")
         results = test(model, datamodule, log=log)
     if P.rank() == 0:
-        out = next_version_dir(exp_dir)
-        save_checkpoint(model, os.path.join(out, "checkpoints", "last.ckpt"), model_config,
-                        {"epoch": len(history), "global_step": history[-1]["step"] if history else 0})
         with open(os.path.join(out, "metrics.jsonl"), "w") as f:
             for row in history:
                 f.write(json.dumps(row) + "\n")

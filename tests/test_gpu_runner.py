@@ -17,6 +17,9 @@ pytestmark = pytest.mark.gpu
 IWAE_CONFIG = """
 seed_everything: 20220118
 experiment_subdir_base: logs/toy/iwae_i5
+add_checkpoint_callback: True
+save_custom_epochs: [1]
+save_custom_steps: [5]
 data:
   setup_seed: 20220118
   dataset: toy_mog2_large
@@ -75,6 +78,7 @@ refit_model:
   amsgrad_latent: True
   use_lr_scheduler: True
 model_class: IWAE
+load_best_model: True
 model_path: ROOT/logs/toy/iwae_i5/seed_{}/lightning_logs/version_{}/checkpoints/last.ckpt
 trainer:
   gradient_clip_val: 5
@@ -161,15 +165,21 @@ def test_iwae_config_then_refit_and_test_loglik(workdir):
     assert len(history) == 6 and history[-1]["step"] == 6 * 16
     assert history[-1]["elbo/val"] > history[0]["elbo/val"] and history[-1]["elbo/train"] > history[0]["elbo/train"]
 
+    ckpts = sorted(os.listdir(workdir / "logs/toy/iwae_i5/seed_m20220118_d20220118/lightning_logs/version_0/checkpoints"))
+    best = [c for c in ckpts if c.startswith("epoch=")]
+    assert len(best) == 1 and set(ckpts) == {best[0], "last.ckpt", "custom_ckpt_by_epoch_1.ckpt", "custom_ckpt_by_step_5.ckpt"}
+    for c in ("custom_ckpt_by_epoch_1.ckpt", "custom_ckpt_by_step_5.ckpt"):       # the refit looks for one file besides last
+        os.remove(workdir / "logs/toy/iwae_i5/seed_m20220118_d20220118/lightning_logs/version_0/checkpoints" / c)
+
     refit_history, results, lines = launch(workdir, "refit", REFIT_CONFIG)
-    assert any("Using pre-trained model from" in l and "version_0" in l for l in lines)
+    assert any("Using pre-trained model from" in l and "version_0" in l and best[0] in l for l in lines)
     assert refit_history[-1]["step"] == 30                      # max_steps ends the run inside an epoch
     ll = results["est_loglik/test"]
     # complete test data, 4096 importance samples: above the 5-sample bound on half-missing validation data per
     # dimension is not comparable, so compare with the complete-data 50-sample bound of the refit's training rows
     assert math.isfinite(ll) and ll > refit_history[-1]["elbo/train"] - 0.05
     # the generator is frozen during the refit: only the encoder moved
-    before = torch.load(workdir / "logs/toy/iwae_i5/seed_m20220118_d20220118/lightning_logs/version_0/checkpoints/last.ckpt",
+    before = torch.load(workdir / "logs/toy/iwae_i5/seed_m20220118_d20220118/lightning_logs/version_0/checkpoints" / best[0],
                         weights_only=True)["state_dict"]
     after = torch.load(workdir / "logs/toy/refit/iwae_i5/seed_m20220118_d20220118/lightning_logs/version_0/checkpoints/last.ckpt",
                        weights_only=True)["state_dict"]
