@@ -455,3 +455,35 @@ def test_fully_connected_networks_run_through_the_caller_network_engine():
     for mine, ref in ((dec, ref_dec), (enc, ref_enc)):
         for (k, p), q in zip(mine.named_parameters(), ref.parameters()):
             torch.testing.assert_close(p.grad.cpu().double(), q.grad, rtol=2e-3, atol=2e-5, msg=k)
+
+
+def test_training_trajectory_matches_reference():
+    """25 optimisation steps through the model class, the library's clip + Adam / AMSGrad step and a cosine schedule,
+    on the reference's own trajectory: bound and gradient norm at every step, parameters at the end."""
+    from oracle.recipes import make_batch, make_noise
+    from vgiwae.models.iwae import estimate_iwelbo
+    from demiss_vae_amd.optim import Adam
+    g = gu.load("trajectory_iwae")
+    spec, enc_p, dec_p = gu.model_case(dict(g, gen_dist="normal_with_eps", q_dist="normal_with_eps", mask_concat=True))
+    seed, steps, B, I = int(g["seed"]), int(g["steps"]), int(g["B"]), int(g["I"])
+    model = _build("IWAE", spec, enc_p, dec_p, num_latent_samples=1, num_importance_samples=I, var_latent_STL=True,
+                   amsgrad_generator=True, amsgrad_latent=False, use_lr_scheduler=True, max_scheduler_steps=steps)
+    model.hparams.lr_generator, model.hparams.lr_latent = float(g["lr_generator"]), float(g["lr_latent"])
+    conf = model.configure_optimizers()
+    opt, sched = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+    assert isinstance(opt, Adam)
+    for t in range(steps):
+        X, M = make_batch(seed + 100 + t, B, spec.D)
+        eps = make_noise(seed + 1000 + t, 1, I, B, spec.Zd)
+        bound = estimate_iwelbo(model, (X.cuda(), M.cuda()), var_latent_STL=True, num_importance_samples=I, eps=eps.cuda())
+        opt.zero_grad()
+        (-bound).backward()
+        model.configure_gradient_clipping(opt, 0, gradient_clip_val=float(g["clip"]), gradient_clip_algorithm="norm")
+        opt.step()
+        sched.step()
+        np.testing.assert_allclose(bound.item(), g["bounds"][t], rtol=2e-4)
+        np.testing.assert_allclose(opt.grad_norm.item(), g["grad_norms"][t], rtol=2e-3)
+        np.testing.assert_allclose([grp["lr"] for grp in opt.param_groups], g["lrs"][t], rtol=1e-6)
+    for name, net in (("enc", model.var_latent_network), ("dec", model.generator_network)):
+        for k, v in net.state_dict().items():
+            torch.testing.assert_close(v.cpu(), torch.from_numpy(g[f"{name}_final.{k}"]), rtol=1e-3, atol=1e-4)

@@ -292,3 +292,33 @@ def test_grid_marginal_logprob(name):
     obs, full = core.grid_marginal_logprob(spec, dec_p, X, M, lo, hi, int(g["grid_steps"]))
     np.testing.assert_allclose(obs.numpy(), g["marginal_obs"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(full.numpy(), g["marginal_full"], rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------- a training run, step by step
+def test_training_trajectory():
+    """25 optimisation steps of the reference (bound, backward, clip, Adam / AMSGrad with a cosine schedule): the
+    oracle's bound with stock torch optimiser calls follows the same trajectory."""
+    from oracle.recipes import make_batch, make_noise
+    g = gu.load("trajectory_iwae")
+    spec, enc_p, dec_p = gu.model_case(dict(g, gen_dist="normal_with_eps", q_dist="normal_with_eps", mask_concat=True))
+    enc_p, dec_p = _as_params(enc_p), _as_params(dec_p)
+    seed, steps, B, I = int(g["seed"]), int(g["steps"]), int(g["B"]), int(g["I"])
+    opt = torch.optim.Adam([{"params": list(dec_p.values()), "amsgrad": True, "lr": float(g["lr_generator"])},
+                            {"params": list(enc_p.values()), "amsgrad": False, "lr": float(g["lr_latent"])}])
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, steps, eta_min=0)
+    params = list(dec_p.values()) + list(enc_p.values())
+    for t in range(steps):
+        X, M = make_batch(seed + 100 + t, B, spec.D)
+        eps = make_noise(seed + 1000 + t, 1, I, B, spec.Zd)
+        bound, _ = core.estimate_iwelbo(spec, enc_p, dec_p, X, M, eps, STL=True)
+        opt.zero_grad()
+        (-bound).backward()
+        norm = torch.nn.utils.clip_grad_norm_(params, float(g["clip"]))
+        opt.step()
+        sched.step()
+        np.testing.assert_allclose(bound.item(), g["bounds"][t], rtol=2e-4)
+        np.testing.assert_allclose(norm.item(), g["grad_norms"][t], rtol=2e-3)
+    for k, v in enc_p.items():
+        torch.testing.assert_close(v.detach(), torch.from_numpy(g["enc_final." + k]), rtol=1e-3, atol=1e-4)
+    for k, v in dec_p.items():
+        torch.testing.assert_close(v.detach(), torch.from_numpy(g["dec_final." + k]), rtol=1e-3, atol=1e-4)

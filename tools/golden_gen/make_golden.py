@@ -510,6 +510,45 @@ def cases_mog_oracle(out):
     save(out, "mog_oracle", **arrays)
 
 
+def cases_trajectory(out):
+    """A short training run of the reference, step by step: IWAE bound -> backward -> clip_grad_norm_ over all
+    parameters -> the optimiser of its own configure_optimizers (Adam, AMSGrad on the generator group, cosine
+    schedule) -> scheduler step, with the latent noise of every step taken from the seed recipe."""
+    from vgiwae.models.iwae import estimate_iwelbo
+    D, Zd, B, I, steps, clip = 8, 16, 32, 5, 25, 0.5
+    seed = 12000
+    enc_spec, dec_spec = NetSpec(2 * D, 2 * Zd, 2, 32), NetSpec(Zd, 2 * D, 2, 32)
+    enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+    model = build_model("IWAE", enc_spec, dec_spec, enc_p, dec_p, "normal_with_eps", "normal_with_eps",
+                        encoder_use_mis_mask=True, var_latent_STL=True, num_importance_samples=I,
+                        amsgrad_generator=True, amsgrad_latent=False, use_lr_scheduler=True, max_scheduler_steps=steps)
+    model.hparams.lr_generator, model.hparams.lr_latent = 3e-3, 1e-3
+    conf = model.configure_optimizers()
+    opt, sched = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+    params = [p for g in opt.param_groups for p in g["params"]]
+    bounds, norms, lrs = [], [], []
+    for t in range(steps):
+        X, M = make_batch(seed + 100 + t, B, D)
+        noise = Noise()
+        noise.normal = [make_noise(seed + 1000 + t, 1, I, B, Zd)]
+        with injected(noise):
+            bound = estimate_iwelbo(model, (X, M), var_latent_STL=True, num_latent_samples=1, num_importance_samples=I)
+        opt.zero_grad()
+        (-bound).backward()
+        norms.append(torch.nn.utils.clip_grad_norm_(params, clip))
+        opt.step()
+        sched.step()
+        bounds.append(bound.detach())
+        lrs.append([g["lr"] for g in opt.param_groups])
+    arrays = dict(seed=seed, D=D, Zd=Zd, B=B, I=I, steps=steps, clip=clip, lr_generator=3e-3, lr_latent=1e-3,
+                  enc_spec=np.array([enc_spec.in_dim, enc_spec.out_dim, enc_spec.nb, enc_spec.hidden]),
+                  dec_spec=np.array([dec_spec.in_dim, dec_spec.out_dim, dec_spec.nb, dec_spec.hidden]),
+                  bounds=torch.stack(bounds), grad_norms=torch.stack(norms), lrs=np.array(lrs))
+    arrays.update({f"enc_final.{k}": v.detach() for k, v in model.var_latent_network.state_dict().items()})
+    arrays.update({f"dec_final.{k}": v.detach() for k, v in model.generator_network.state_dict().items()})
+    save(out, "trajectory_iwae", **arrays)
+
+
 def _reparam(out, name, *, cls, D, Zd, C, B, I, nz, seed, with_eps=True):
     """VAE / IWAE whose encoder is a mixture sampled ancestrally with implicit reparameterisation gradients
     (the reparametrised_mixture* families), STL as in every shipped config."""
@@ -905,6 +944,7 @@ def main():
         "marginal": lambda: cases_marginal(args.out),
         "mvbiwae": lambda: cases_mvbiwae(args.out),
         "mog_oracle": lambda: cases_mog_oracle(args.out),
+        "trajectory": lambda: cases_trajectory(args.out),
     }
     for name, fn in groups.items():
         if args.only and name not in args.only.split(","):
