@@ -219,7 +219,7 @@ def main():
 
     import demiss_vae_amd as dmv
     from demiss_vae_amd import rng
-    from demiss_vae_amd.parallel import allreduce_grads
+    from demiss_vae_amd.parallel import all_reduce, allreduce_grads
     rng.set_seed(20220118 + rank)
 
     B, K = args.batch, 5
@@ -259,7 +259,7 @@ def main():
     dbg(f"timed {dt}")
     if dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
+        all_reduce(t, td.ReduceOp.MAX)
         dt = t.item()
 
     # K = 50 000 log-likelihood estimation: test points sharded over ranks, rates summed
@@ -272,7 +272,7 @@ def main():
         dbg("loglik done")
         if dist:
             t = torch.tensor([ll["samples_per_s"]], device=device, dtype=torch.float64)
-            td.all_reduce(t, op=td.ReduceOp.SUM)
+            all_reduce(t, td.ReduceOp.SUM)
             ll["samples_per_s"] = round(t.item(), 1)
             ll["workload"] += f", {world} ranks each on its own test points"
 

@@ -26,6 +26,19 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def all_reduce(t: torch.Tensor, op=None, group=None):
+    """dist.all_reduce; under the gloo backend (CPU tests, rehearsals with several ranks on one GPU) device tensors
+    are staged through host memory"""
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 def allreduce_grads(params: Sequence[torch.Tensor], group=None):
     """Average .grad over ranks with one flat all-reduce (equal shard sizes assumed)."""
     if world() == 1:
@@ -34,7 +47,7 @@ def allreduce_grads(params: Sequence[torch.Tensor], group=None):
     if not with_grad:
         return
     flat = _flatten_dense_tensors([p.grad for p in with_grad])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    all_reduce(flat, dist.ReduceOp.SUM, group)
     flat.div_(dist.get_world_size(group))
     for p, g in zip(with_grad, _unflatten_dense_tensors(flat, [p.grad for p in with_grad])):
         p.grad.copy_(g)
@@ -46,10 +59,10 @@ def lse_allreduce(run_max: torch.Tensor, run_sum: torch.Tensor, group=None):
     if world() == 1:
         return run_max, run_sum
     m = run_max.clone()
-    dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    all_reduce(m, dist.ReduceOp.MAX, group)
     s = run_sum * torch.exp(run_max - m)
     s = torch.where(torch.isfinite(run_max), s, torch.zeros_like(s))
-    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    all_reduce(s, dist.ReduceOp.SUM, group)
     return m, s
 
 
