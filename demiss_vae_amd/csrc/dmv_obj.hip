@@ -829,6 +829,35 @@ static inline unsigned grid_for(int64_t work, int block, unsigned cap = 8192) {
   return (unsigned)(g > cap ? cap : g);
 }
 
+// four consecutive latent dimensions per thread (Zd, ldz, offset multiples of 4, 16-byte aligned rows): one Philox call
+// and one 16-byte access per array; same values as the scalar kernel
+__global__ void k_latent_sample4(SampleArgs a) {
+  const int64_t total4 = (a.N * a.ldz) >> 2;
+  const uint64_t off = a.offset + (a.offset_base ? a.offset_base[0] : 0ull);
+  const int ld4 = (int)(a.ldz >> 2);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = q / ld4;
+    const int j = (int)(q - n * ld4) << 2;
+    const int64_t i = q << 2;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f}, e = {0.f, 0.f, 0.f, 0.f};
+    if (j < a.Zd) {
+      int g = (int)(n % a.G);
+      const int64_t b = (n / a.G) % a.B;
+      if (a.comp_idx) g = (int)a.comp_idx[n];
+      if (a.eps) {
+        e = *(const f32x4*)(a.eps + i);
+      } else {
+        const dmv_f4 r = dmv_philox_normal4(a.seed, (off + (uint64_t)i) >> 2);
+        e = f32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) z[k] = q_mu(a.enc, a.q, b, g, j + k) + q_sigma(a.enc, a.q, b, g, j + k) * e[k];
+    }
+    *(f32x4*)(a.Z + i) = z;
+    if (a.eps_out) *(f32x4*)(a.eps_out + i) = e;
+  }
+}
+
 extern "C" int dmv_latent_sample(const DmvObjCfg* cfg, const float* enc, const float* eps, uint64_t seed,
                                  uint64_t offset, const uint64_t* offset_base, int64_t ldz, const int64_t* comp_idx,
                                  float* Z, float* eps_out, void* stream) {
@@ -840,7 +869,11 @@ extern "C" int dmv_latent_sample(const DmvObjCfg* cfg, const float* enc, const f
   a.N = nrows(cfg); a.B = cfg->B; a.G = cfg->G; a.Zd = cfg->Zd;
   a.q = qaddr(cfg); a.enc = enc; a.eps = eps; a.eps_out = eps_out; a.comp_idx = comp_idx;
   a.ldz = ldz; a.Z = Z; a.seed = seed; a.offset = offset; a.offset_base = offset_base;
-  hipLaunchKernelGGL(k_latent_sample, dim3(grid_for(a.N * ldz, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  const uintptr_t al = (uintptr_t)Z | (uintptr_t)eps | (uintptr_t)eps_out;
+  if ((cfg->Zd & 3) == 0 && (ldz & 3) == 0 && (offset & 3) == 0 && (al & 15) == 0)
+    hipLaunchKernelGGL(k_latent_sample4, dim3(grid_for(a.N * ldz / 4, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(k_latent_sample, dim3(grid_for(a.N * ldz, 256)), dim3(256), 0, (hipStream_t)stream, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }

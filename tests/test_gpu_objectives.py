@@ -171,3 +171,33 @@ def test_reparametrised_mixture(name, engine):
     if engine == "fused":
         b2, _ = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=4, num_importance_samples=8, STL=True)
         assert torch.isfinite(b2) and abs(b2.item() - float(g["bound"])) < 0.5 * abs(float(g["bound"])) + 5
+
+
+def test_latent_sample_vector_and_scalar_kernels_agree():
+    """the 16-byte path of dmv_latent_sample (aligned buffers) draws the same values as the scalar path (forced here by a
+    misaligned noise output buffer), with and without explicit noise and for mixture components picked per row"""
+    import ctypes as C
+    from demiss_vae_amd import _lib as L
+    B, G, S, Zd = 37, 5, 3, 8
+    N = S * B * G
+    cfg = L.DmvObjCfg()
+    cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, G, 1, S, 1, Zd
+    ldE = 2 * G * Zd + G
+    cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, Zd, G * Zd, 2 * G * Zd
+    enc = torch.randn(B, ldE, device="cuda")
+    outs = []
+    for shift in (0, 1):
+        Z = torch.empty(N, Zd, device="cuda")
+        buf = torch.empty(N * Zd + 4, device="cuda")
+        used = buf[shift:shift + N * Zd]
+        L.check(L.lib().dmv_latent_sample(C.byref(cfg), L.ptr(enc), None, 5, 64, None, Zd, None, L.ptr(Z), L.ptr(used), L.stream_ptr()))
+        outs.append((Z.clone(), used.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    eps = outs[0][1].reshape(N, Zd).contiguous()
+    Z2 = torch.empty(N, Zd, device="cuda")
+    L.check(L.lib().dmv_latent_sample(C.byref(cfg), L.ptr(enc), L.ptr(eps), 0, 0, None, Zd, None, L.ptr(Z2), None, L.stream_ptr()))
+    assert torch.equal(Z2, outs[0][0])
+    mu = enc[:, :G * Zd].reshape(B, G, Zd)
+    sg = torch.nn.functional.softplus(enc[:, G * Zd:2 * G * Zd]).reshape(B, G, Zd)
+    want = mu.unsqueeze(0) + sg.unsqueeze(0) * eps.reshape(S, B, G, Zd)
+    torch.testing.assert_close(Z2.reshape(S, B, G, Zd), want, rtol=1e-5, atol=1e-6)
