@@ -807,6 +807,83 @@ __global__ void k_grid_marginal(GridArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Divergences between the model's posterior over the latent grid and a variational mixture
+// (vgiwae/shared/vae_marginal_logprob.py:91-192).  For row r with data x_r (mask optional):
+//   log p_z = log p(z) + sum_d [M_d] log p(x_d | z) - log_marg[r]        (posterior density on the grid)
+//   log q_z = logsumexp_k sum_j log N(z_j; mu_rkj, sigma_rkj) - log Kq   (uniform mixture of Kq Gaussians)
+//   KL(p||q) = sum_z p (log p - log q) dz,  KL(q||p) = sum_z q (log q - log p) dz,
+//   JSD = (sum_z q (log q - log m) dz + sum_z p (log p - log m) dz) / 2,  log m = log((p + q) / 2).
+// One block per row over the grid prepared by k_grid_prep; fp32 like the reference's tensors.
+// ------------------------------------------------------------------------------------------
+struct GridDivArgs {
+  int64_t Nz;
+  int D, Zd, R, Kq, gen_dist;
+  const float* ws;        // [Nz][D][3]
+  const float* log_prior; // [Nz]
+  const float* Zg;        // [Nz][Zd]
+  float dz;
+  const float* X;         // [R][D]
+  const uint8_t* M;       // nullable [R][D]
+  const float* log_marg;  // [R]
+  const float* q_mu;      // [R][Kq][Zd]
+  const float* q_sigma;
+  float* out;             // [3][R]
+};
+
+__global__ void k_grid_divs(GridDivArgs a) {
+  const int r = blockIdx.x;
+  const float* X = a.X + (int64_t)r * a.D;
+  const uint8_t* M = a.M ? a.M + (int64_t)r * a.D : nullptr;
+  const float* mu = a.q_mu + (int64_t)r * a.Kq * a.Zd;
+  const float* sg = a.q_sigma + (int64_t)r * a.Kq * a.Zd;
+  const bool normal = a.gen_dist <= DMV_GEN_NORMAL_EPS;
+  const float lmarg = a.log_marg[r], logK = logf((float)a.Kq);
+  float fow = 0.f, rev = 0.f, jq = 0.f, jp = 0.f;
+  for (int64_t z = threadIdx.x; z < a.Nz; z += blockDim.x) {
+    const float* w = a.ws + z * a.D * 3;
+    float lp = a.log_prior[z];
+    for (int d = 0; d < a.D; ++d) {
+      float t;
+      if (normal) { const float df = X[d] - w[3 * d]; t = w[3 * d + 2] - df * df * w[3 * d + 1]; }
+      else { const float v = a.gen_dist == DMV_GEN_BERN ? X[d] : (X[d] + 1.f) * 0.5f; t = w[3 * d + 2] + v * w[3 * d]; }
+      lp += (!M || M[d]) ? t : 0.f;
+    }
+    lp -= lmarg;
+    const float* zz = a.Zg + z * a.Zd;
+    float qm = -INFINITY, qs = 0.f;
+    for (int k = 0; k < a.Kq; ++k) {
+      float l = 0.f;
+      for (int j = 0; j < a.Zd; ++j) l += log_normal(zz[j], mu[k * a.Zd + j], sg[k * a.Zd + j]);
+      const float nm = fmaxf(qm, l);
+      if (nm > -INFINITY) { qs = qs * expf(qm - nm) + expf(l - nm); qm = nm; }
+    }
+    const float lq = qm + logf(qs) - logK;
+    const float hi = fmaxf(lp, lq), lo = fminf(lp, lq);
+    const float lm = hi + log1pf(expf(lo - hi)) - 0.69314718056f;
+    const float p = expf(lp), q = expf(lq);
+    fow += p * (lp - lq) * a.dz;
+    rev += q * (lq - lp) * a.dz;
+    jq += q * (lq - lm) * a.dz;
+    jp += p * (lp - lm) * a.dz;
+  }
+  __shared__ float sh[4][4];
+  float v4[4] = {fow, rev, jq, jp};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float s = group_sum<64>(v4[i]);
+    if ((threadIdx.x & 63) == 0) sh[i][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t[4];
+    for (int i = 0; i < 4; ++i) t[i] = sh[i][0] + sh[i][1] + sh[i][2] + sh[i][3];
+    a.out[r] = t[0];
+    a.out[a.R + r] = t[1];
+    a.out[2 * a.R + r] = 0.5f * (t[2] + t[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 static int check_cfg(const DmvObjCfg* c) {
@@ -1102,6 +1179,22 @@ extern "C" int dmv_grid_marginal(int32_t gen_dist, int32_t D, int64_t Nz, const 
   hipLaunchKernelGGL(k_grid_prep, dim3(grid_for(Nz * D, 256)), dim3(256), 0, st, a);
   DMV_HIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_grid_marginal, dim3((unsigned)B), dim3(256), 0, st, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+extern "C" int dmv_grid_divergences(int32_t gen_dist, int32_t D, int32_t Zd, int64_t Nz, const float* ws,
+                                    const float* log_prior, const float* Zgrid, float dz, int32_t R, const float* X,
+                                    const uint8_t* M, const float* log_marg, int32_t Kq, const float* q_mu,
+                                    const float* q_sigma, float* out, void* stream) {
+  if (gen_dist < DMV_GEN_NORMAL || gen_dist > DMV_GEN_BERN_M1P1) return DMV_E_UNSUPPORTED;
+  if (D < 1 || Zd < 1 || Nz < 1 || R < 0 || Kq < 1 || !(dz > 0.f)) return DMV_E_BADARG;
+  if (!ws || !log_prior || !Zgrid || !X || !log_marg || !q_mu || !q_sigma || !out) return DMV_E_BADARG;
+  if (R == 0) return DMV_OK;
+  GridDivArgs a;
+  a.Nz = Nz; a.D = D; a.Zd = Zd; a.R = R; a.Kq = Kq; a.gen_dist = gen_dist; a.ws = ws; a.log_prior = log_prior;
+  a.Zg = Zgrid; a.dz = dz; a.X = X; a.M = M; a.log_marg = log_marg; a.q_mu = q_mu; a.q_sigma = q_sigma; a.out = out;
+  hipLaunchKernelGGL(k_grid_divs, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }

@@ -156,7 +156,7 @@ class _StepRunner:
         self.model, self.opt, self.sched, self.params, self.log = model, opt, sched, params, log
         self.clip_val, self.clip_alg = clip_val, clip_alg
         self.use_graph = use_graph
-        self.seen, self.graphs, self.static = {}, {}, {}
+        self.seen, self.graphs, self.static, self.eager_keys = {}, {}, {}, set()
         self.replays = 0
         self.side = torch.cuda.Stream() if use_graph else None
         self.own = hasattr(opt, "sync_lr")          # demiss_vae_amd.optim.Adam keeps its rates on the device itself
@@ -227,8 +227,8 @@ class _StepRunner:
         key = self._key(batch)
         n = self.seen.get(key, 0)
         self.seen[key] = n + 1
-        if n < 2:                                   # lazily created state (optimiser, workspaces) must exist first
-            return self._eager(batch, self.side)
+        if n < 2 or key in self.eager_keys:         # lazily created state (optimiser, workspaces) must exist first
+            return self._eager(batch, self.side if n < 2 else None)
         if key not in self.graphs:
             static = tuple(t.clone() for t in batch)
             m = self.model
@@ -242,9 +242,8 @@ class _StepRunner:
             try:
                 self.graphs[key] = GraphedStep(body, nets=nets, warmup=0)
             except Exception as e:                  # a step that synchronises with the host cannot be recorded
-                self.log(f"[run] step not recordable ({type(e).__name__}: {e}); continuing without graphs")
-                self.use_graph = False
-                self.model._schedulers = self.sched
+                self.log(f"[run] step not recordable ({type(e).__name__}: {e}); steps of this kind run eagerly")
+                self.eager_keys.add(key)
                 torch.cuda.synchronize()
                 return self._eager(batch)
             self.static[key] = (static, logged)

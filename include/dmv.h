@@ -272,6 +272,18 @@ int dmv_categorical_draw(int32_t B, int32_t P, int32_t K, const float* logits, c
 int dmv_dropout_masks(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_base,
                       void* stream);
 
+/* Divergences between the model's posterior on the latent grid and a variational distribution, per row
+ * (vgiwae/shared/vae_marginal_logprob.py:91-192, the posterior-divergence metrics of the toy study):
+ *   p(z) = exp(log_prior[z] + sum_d [M_d] log p(x_d|z) - log_marg[r]),   q(z) = (1/Kq) sum_k N(z; mu_rk, diag sigma_rk^2)
+ *   out[0][r] = KL(p||q), out[1][r] = KL(q||p), out[2][r] = JSD(p, q), sums over the grid times the cell volume dz.
+ * ws: the per-grid-point table left by dmv_grid_marginal for the same decoder outputs; Zgrid [Nz][Zd];
+ * X [R][D]; M nullable (all entries observed); log_marg [R] the matching output of dmv_grid_marginal;
+ * q_mu, q_sigma [R][Kq][Zd]. */
+int dmv_grid_divergences(int32_t gen_dist, int32_t D, int32_t Zd, int64_t Nz, const float* ws, const float* log_prior,
+                         const float* Zgrid, float dz, int32_t R, const float* X, const uint8_t* M,
+                         const float* log_marg, int32_t Kq, const float* q_mu, const float* q_sigma, float* out,
+                         void* stream);
+
 /* Optimiser step (vgiwae/models/vae.py:349-390: Adam / AMSGrad with one parameter group per network, preceded by
  * clip_grad_norm_ over all parameters; shared/mvb2_manual_optimisation.py:9-11).  One call =
  *   norm = || all grads ||_2;  coef = max_norm > 0 ? min(1, max_norm / (norm + 1e-6)) : 1;  g' = coef * g   (grads are

@@ -612,3 +612,37 @@ def grid_marginal_logprob(spec: ModelSpec, dec_params, X, M, grid_min=None, grid
     joint_full = prior + comp.sum(-1)
     ldz = math.log(dz)
     return torch.logsumexp(joint_obs + ldz, dim=0), torch.logsumexp(joint_full + ldz, dim=0)
+
+
+def posterior_divs(spec: ModelSpec, enc_params, dec_params, X, M, X_imp, M_imp, grid_min=None, grid_max=None, grid_steps=None):
+    """vgiwae/shared/vae_marginal_logprob.py:91-192: forward / reverse KL and JSD on the latent grid between the model's
+    posterior and the variational distribution, for complete data [B], incomplete data with the mixture of the K
+    imputations' variational distributions [B], and every imputed copy [B, K].  X is the complete datapoint."""
+    Z, dz = latent_grid(spec.Zd, grid_min, grid_max, grid_steps)
+    g = mlp_forward(dec_params, Z, spec.dec)                                     # [Nz, P]
+    prior = log_std_normal(Z).sum(-1)                                            # [Nz]
+
+    def posterior(Xr, Mr):
+        lp = gen_logprob(spec, g.unsqueeze(1), Xr.unsqueeze(0))                  # [Nz, R, D]
+        if Mr is not None:
+            lp = lp * Mr.to(lp.dtype).unsqueeze(0)
+        joint = prior.unsqueeze(1) + lp.sum(-1)
+        return joint - torch.logsumexp(joint + math.log(dz), dim=0)
+
+    def q_logprob(Xr, Mr):
+        mu, sigma, _ = q_heads(spec, _encode(spec, enc_params, Xr, Mr))
+        return log_normal(Z.unsqueeze(1), mu.unsqueeze(0), sigma.unsqueeze(0)).sum(-1)   # [Nz, R]
+
+    def divs(lp, lq):
+        kl_fow = (torch.exp(lp) * (lp - lq) * dz).sum(0)
+        kl_rev = (torch.exp(lq) * (lq - lp) * dz).sum(0)
+        lm = torch.logsumexp(torch.stack([lq, lp]), dim=0) - math.log(2)
+        jsd = 0.5 * ((torch.exp(lq) * (lq - lm) * dz).sum(0) + (torch.exp(lp) * (lp - lm) * dz).sum(0))
+        return kl_fow, kl_rev, jsd
+    B, K, D = X_imp.shape
+    complete = divs(posterior(X, None), q_logprob(X, M))
+    lq_imps = q_logprob(X_imp.reshape(B * K, D), M_imp.reshape(B * K, D))        # [Nz, B*K]
+    lq_mix = torch.logsumexp(lq_imps.reshape(-1, B, K), dim=2) - math.log(K)
+    incomplete = divs(posterior(X, M), lq_mix)
+    imputed = tuple(t.reshape(B, K) for t in divs(posterior(X_imp.reshape(B * K, D), None), lq_imps))
+    return (*complete, *incomplete, *imputed)

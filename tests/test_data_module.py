@@ -154,6 +154,7 @@ model:
     imputation_init_val: empirical
     init_imputation_distribution: True
     latent_grid_steps: 50
+    compute_complete_var_distribution_kl: True
     vae_sampler:
       class_path: vgiwae.shared.vae_imputation.VAESampler_PseudoGibbs
       init_args:

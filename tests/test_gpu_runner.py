@@ -129,7 +129,9 @@ def test_demissvae_config_trains(workdir):
     history, _, lines = launch(workdir, "mvb2", CONFIG)
     assert len(history) == 2 and history[-1]["step"] == 2 * math.ceil(history[-1]["step"] / 2)
     for row in history:
-        assert {"mvb/train", "cvi/train", "loss/train", "marginal_logprob/val", "complete_marginal_logprob/val"} <= set(row)
+        assert {"mvb/train", "cvi/train", "loss/train", "marginal_logprob/val", "complete_marginal_logprob/val",
+                "complete_posterior_kl_fow/val", "incomplete_posterior_jsd/val", "complete_imps_posterior_kl_rev/val"} <= set(row)
+        assert min(v for k, v in row.items() if "posterior" in k) > -1e-3
         assert all(math.isfinite(v) for v in row.values())
     assert history[1]["loss/train"] < history[0]["loss/train"]
     assert history[1]["marginal_logprob/val"] > history[0]["marginal_logprob/val"]

@@ -322,3 +322,18 @@ def test_training_trajectory():
         torch.testing.assert_close(v.detach(), torch.from_numpy(g["enc_final." + k]), rtol=1e-3, atol=1e-4)
     for k, v in dec_p.items():
         torch.testing.assert_close(v.detach(), torch.from_numpy(g["dec_final." + k]), rtol=1e-3, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------- posterior divergences on the grid
+DIV_NAMES = ("comp_fow", "comp_rev", "comp_jsd", "inc_fow", "inc_rev", "inc_jsd", "imp_fow", "imp_rev", "imp_jsd")
+
+
+@pytest.mark.parametrize("name", gu.names("posterior_divs_"))
+def test_posterior_divergences(name):
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(g)
+    out = core.posterior_divs(spec, enc_p, dec_p, torch.from_numpy(g["X"]), torch.from_numpy(g["M"]), torch.from_numpy(g["Xt"]),
+                              torch.from_numpy(g["Mk"]), float(g["grid_min"]), float(g["grid_max"]), int(g["grid_steps"]))
+    for k, v in zip(DIV_NAMES, out):
+        torch.testing.assert_close(v, torch.from_numpy(g[k]), rtol=1e-4, atol=1e-5, msg=k)
+    assert all((v > -1e-4).all() for v in out)                      # divergences

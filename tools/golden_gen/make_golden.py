@@ -616,6 +616,35 @@ def cases_marginal(out):
         save(out, name, **arrays)
 
 
+def cases_posterior_divs(out):
+    """Posterior-divergence diagnostics of the toy study (vae_marginal_logprob.get_posterior_divs)."""
+    from vgiwae.shared.vae_marginal_logprob import get_posterior_divs
+    names = ("comp_fow", "comp_rev", "comp_jsd", "inc_fow", "inc_rev", "inc_jsd", "imp_fow", "imp_rev", "imp_jsd")
+    for name, D, Zd, steps, lo, hi, mask_concat in (("posterior_divs_2d", 5, 2, 60, -6.0, 6.0, False),
+                                                   ("posterior_divs_2d_encm", 5, 2, 50, -5.0, 5.0, True),
+                                                   ("posterior_divs_1d", 4, 1, 400, -8.0, 8.0, False)):
+        seed = 13000 + steps
+        B, K = 7, 3
+        enc_spec, dec_spec = NetSpec(2 * D if mask_concat else D, 2 * Zd, 2, 32), NetSpec(Zd, 2 * D, 2, 32)
+        enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+        model = build_model("VAE", enc_spec, dec_spec, enc_p, dec_p, "normal", "normal", kl_analytic=True,
+                            encoder_use_mis_mask=mask_concat)
+        model.eval()
+        X, M = make_batch(seed + 2, B, D)
+        fill, _ = make_batch(seed + 6, B * K, D)
+        Mk = M[:, None, :].expand(B, K, D).contiguous()
+        Xt = torch.where(Mk, X[:, None, :].expand(B, K, D), fill.reshape(B, K, D)).contiguous()
+        with torch.inference_mode():
+            res = get_posterior_divs(model, (X, M), (Xt, Mk), grid_min=lo, grid_max=hi, grid_steps=steps)
+        arrays = dict(seed=seed, D=D, Zd=Zd, B=B, K=K, gen_dist="normal", q_dist="normal", mask_concat=mask_concat,
+                      grid_steps=steps, grid_min=lo, grid_max=hi, X=X, M=M, Xt=Xt, Mk=Mk,
+                      enc_spec=np.array([enc_spec.in_dim, 2 * Zd, 2, 32]), dec_spec=np.array([Zd, 2 * D, 2, 32]))
+        arrays.update(dict(zip(names, res)))
+        arrays.update(params_to_dict("enc", enc_p))
+        arrays.update(params_to_dict("dec", dec_p))
+        save(out, name, **arrays)
+
+
 def cases_resnet(out):
     """DeMissVAE (mvb2, STL, pseudo-Gibbs x1) with small convolutional trunks on 28x28 Bernoulli{-1,+1} images: the
     structure of configs/mnist_bin/compare/q50/mvb2vae_noencm_pg_k5_stl.yaml at reduced widths, dropout off."""
@@ -945,6 +974,7 @@ def main():
         "mvbiwae": lambda: cases_mvbiwae(args.out),
         "mog_oracle": lambda: cases_mog_oracle(args.out),
         "trajectory": lambda: cases_trajectory(args.out),
+        "posterior_divs": lambda: cases_posterior_divs(args.out),
     }
     for name, fn in groups.items():
         if args.only and name not in args.only.split(","):

@@ -2,9 +2,10 @@
 
 The `*_FID`, `*MargLogprob` and `*GradVar` names are the reference's diagnostic wrappers
 (models/vae_fid.py:174-180, vae_marglogprob.py:140-146, vae_gradvar.py:51-57).  The `*MargLogprob` classes
-compute the grid marginal log-probability of the batch on the device (demiss_vae_amd/marginal.py) and log it
-under the reference's metric names; the posterior-divergence extras of that wrapper, FID (needs a pre-trained
-encoder checkpoint) and the gradient-variance probe are accepted as keyword arguments, recorded, and skipped."""
+compute the grid marginal log-probability of the batch and, when asked for, the nine posterior-divergence
+diagnostics on the device (demiss_vae_amd/marginal.py) and log them under the reference's metric names; FID (needs a
+pre-trained encoder checkpoint) and the gradient-variance probe are accepted as keyword arguments, recorded, and
+skipped."""
 from .vae import VAE
 from .iwae import IWAE
 from .mvbvae import MVBVAE, MVB_OBJECTIVE
@@ -37,6 +38,17 @@ def _marginal_logprob(self, batch, stage):
                                           grid_steps=h.latent_grid_steps)
     self.log(f"marginal_logprob/{stage}", obs.mean(), on_step=False, on_epoch=True, prog_bar=True, logger=True)
     self.log(f"complete_marginal_logprob/{stage}", full.mean(), on_step=False, on_epoch=True, prog_bar=True, logger=True)
+    if h.compute_complete_var_distribution_kl:
+        # vae_marglogprob.py:54-78, 98-122: divergences between the model's posteriors and the variational ones
+        from demiss_vae_amd.marginal import posterior_divergences
+        imputed = getattr(self, f"{stage}_imp_distribution").get_imputed_datapoints(batch)
+        with torch.no_grad():
+            divs = posterior_divergences(self.model_dims(), self.predict_var_latent_params, self.generator_network.packed_net(),
+                                         batch[0], batch[1], imputed[0], imputed[1], grid_min=h.latent_grid_min,
+                                         grid_max=h.latent_grid_max, grid_steps=h.latent_grid_steps)
+        names = [f"{a}_posterior_{b}" for a in ("complete", "incomplete", "complete_imps") for b in ("kl_fow", "kl_rev", "jsd")]
+        for name, value in zip(names, divs):
+            self.log(f"{name}/{stage}", value.mean(), on_step=False, on_epoch=True, prog_bar=True, logger=True)
 
 
 def _with_ignored_diagnostics(base, suffix):
