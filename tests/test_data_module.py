@@ -124,6 +124,39 @@ def test_device_loader_shards_are_disjoint_equal_and_fixed(data_root):
     assert ids[1] == set(torch.cat([b[2] for b in shards[1]]).tolist())                   # same rows next epoch
 
 
+def test_image_datasets_and_block_missingness(tmp_path):
+    """Omniglot / MNIST files in the reference's npz layout (synthetic images): resize, binarisation, quadrant and
+    top-half masks through the data module"""
+    r = np.random.default_rng(0)
+    (tmp_path / "omniglot").mkdir()
+    (tmp_path / "MNIST").mkdir()
+    for split, n in (("train", 40), ("val", 10), ("test", 12)):
+        img = np.clip(r.random((n, 105, 105)).astype(np.float32) * 1.4 - 0.2, 0, 1)
+        img[:, :, :50] = 1.0                                                      # white left half
+        np.savez(tmp_path / "omniglot" / f"{split}.npz", data=img, targets=np.arange(n))
+        np.savez(tmp_path / "MNIST" / f"{split}.npz", data=r.integers(0, 256, (n, 28, 28), dtype=np.uint8), targets=np.arange(n) % 10)
+    kw = dict(batch_size=8, total_miss_train=0.5, total_miss_val=0.5, pre_imputation=PRE_IMPUTATION.oracle, pre_impute_val=False,
+              data_root=str(tmp_path), setup_seed=20220118, img_dims=[28, 28])
+    dm = MissingDataModule(dataset=DATASET.omniglot_28x28_bin, missingness=MISSINGNESS.quadrants, **kw)
+    dm.device = torch.device("cpu")
+    dm.setup("fit")
+    X, M, T, I = dm.train_data[:]
+    assert X.shape == (40, 784) and set(np.unique(X)) == {-1.0, 1.0} and dm.train_data_core.img_shape == (28, 28)
+    assert (X.reshape(40, 28, 28)[:, :, :12] == 1).all()                          # the white half survives resize + binarisation
+    quads = M.reshape(40, 2, 14, 2, 14).transpose(0, 1, 3, 2, 4).reshape(40, 4, 196)
+    assert ((quads.all(-1) | (~quads).all(-1)).all()) and ((~quads).all(-1).sum(1) == 2).all()   # two whole quadrants missing
+    again = MissingDataModule(dataset=DATASET.omniglot_28x28_bin, missingness=MISSINGNESS.quadrants, **kw)
+    again.setup("fit")
+    assert np.array_equal(again.train_data[:][0], X) and np.array_equal(again.train_data[:][1], M)
+    batch = next(iter(dm.train_dataloader()))
+    assert [t.shape for t in batch] == [(8, 784), (8, 784), (8,), (8,)]
+    small = MissingDataModule(dataset=DATASET.mnist_14x14, missingness=MISSINGNESS.top_half, **kw)
+    small.setup("fit")
+    Xs, Ms = small.train_data[:][:2]
+    assert Xs.shape == (40, 196) and 0 <= Xs.min() and Xs.max() < 1
+    assert not Ms[:, :98].any() and Ms[:, 98:].all()
+
+
 CONFIG = """
 seed_everything: 20220118
 experiment_subdir_base: logs/toy/mvb2

@@ -10,10 +10,11 @@ import torch
 
 from demiss_vae_amd.loader import DeviceLoader
 from demiss_vae_amd.pl_compat import LightningDataModule
-from .datasets import MNIST, ToyDataset, UCITable
+from .datasets import MNIST, Omniglot, ToyDataset, UCITable
 from .dataset_with_indices import DatasetWithIndices
 from .fully_missing_filter_dataset import FullyMissingDataFilter
 from .quadrant_missingness_provider import QuadrantMissingnessDataset
+from .tophalf_missingness_provider import TopHalfMissingnessDataset
 from .uniform_missingness_provider import UniformMissingnessDataset
 
 
@@ -45,7 +46,14 @@ class DATASET(Enum):
             return MNIST(*args, **kwargs)
         if n == "mnist_bin":
             return MNIST(*args, binarise=True, **kwargs)
-        raise NotImplementedError(f"dataset {n}: resizing needs torchvision, which this build does not use")
+        if n.startswith("mnist_"):                                   # mnist_14x14, mnist_7x7, mnist_5x5
+            h, w = (int(v) for v in n[6:].split("x"))
+            return MNIST(*args, resize=(h, w), **kwargs)
+        if n == "omniglot_bin":
+            return Omniglot(*args, binarise_fixed=True, **kwargs)
+        if n == "omniglot_28x28_bin":
+            return Omniglot(*args, resize=(28, 28), binarise_fixed=True, **kwargs)
+        raise NotImplementedError(f"dataset {n}")
 
 
 class MISSINGNESS(Enum):
@@ -64,6 +72,8 @@ class PRE_IMPUTATION(Enum):
 def _add_missingness(dataset, kind: MISSINGNESS, total_miss, img_dims, rng):
     if kind is MISSINGNESS.uniform:
         return UniformMissingnessDataset(dataset, target_idx=0, total_miss=total_miss, rng=rng)
+    if kind is MISSINGNESS.top_half:
+        return TopHalfMissingnessDataset(dataset, target_idx=0, total_miss=total_miss, rng=rng)
     if kind is MISSINGNESS.quadrants:
         return QuadrantMissingnessDataset(dataset, target_idx=0, img_dims=img_dims, total_miss=total_miss, rng=rng)
     raise NotImplementedError(f"missingness {kind.value}")
