@@ -85,6 +85,9 @@ except Exception:  # ModuleNotFoundError here; any import-time failure means "no
         def on_train_epoch_start(self):
             pass
 
+        def on_train_batch_end(self, outputs, batch, batch_idx):
+            pass
+
         def on_train_epoch_end(self):
             pass
 

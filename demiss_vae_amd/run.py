@@ -300,7 +300,7 @@ def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None):
     clip_val, clip_alg = trainer_cfg.get("gradient_clip_val"), trainer_cfg.get("gradient_clip_algorithm")
     datamodule.setup("fit")
     train_loader = datamodule.train_dataloader()
-    trainer = types.SimpleNamespace(max_epochs=max_epochs, max_steps=max_steps, datamodule=datamodule,
+    trainer = types.SimpleNamespace(max_epochs=max_epochs, max_steps=max_steps, datamodule=datamodule, global_step=0,
                                     num_training_batches=len(train_loader), accumulate_grad_batches=1)
     model.trainer = trainer
     model.set_datamodule(datamodule)
@@ -326,9 +326,10 @@ def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None):
         for i, batch in enumerate(train_loader):
             model._logged = {}
             run_step(batch)
-            means.add(model._logged)
             step += 1
-            model.global_step = step
+            model.global_step = trainer.global_step = step
+            model.on_train_batch_end(None, batch, i)
+            means.add(model._logged)
             if checkpointer is not None:
                 checkpointer.on_step(step)
             if max_steps != -1 and step >= max_steps:
@@ -345,7 +346,7 @@ def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None):
                 model.validation_step(batch, i)
                 vmeans.add(model._logged)
         model.on_validation_epoch_end()
-        row = {"epoch": epoch, "step": step, "time_s": round(time.time() - t0, 2), **means.result("/train"), **vmeans.result("/val")}
+        row = {"epoch": epoch, "step": step, "time_s": round(time.time() - t0, 2), **means.result(), **vmeans.result()}
         history.append(row)
         if P.rank() == 0:
             log(json.dumps(row))

@@ -187,3 +187,30 @@ def test_iwae_config_then_refit_and_test_loglik(workdir):
                        weights_only=True)["state_dict"]
     moved = {k.split(".")[0] for k in before if not torch.equal(before[k], after[k])}
     assert moved == {"var_latent_network"}
+
+
+def test_fid_metric_against_a_trained_encoder(workdir):
+    """the *_FID classes: train a complete-data VAE, then a model whose FID is measured in its encoder's feature space"""
+    vae = IWAE_CONFIG.replace("logs/toy/iwae_i5", "logs/toy/vae_complete").replace("vgiwae.models.IWAE", "vgiwae.models.VAE") \
+        .replace("    num_importance_samples: 5\n", "    kl_analytic: False\n").replace("    encoder_use_mis_mask: True\n", "") \
+        .replace("{input_dim: 10, output_dim: 4,", "{input_dim: 5, output_dim: 4,") \
+        .replace("total_miss_train: 0.5", "total_miss_train: 0.0").replace("max_epochs: 6", "max_epochs: 2")
+    launch(workdir, "vae_complete", vae)
+    ckpt = workdir / "logs/toy/vae_complete/seed_m20220118_d20220118/lightning_logs/version_0/checkpoints/last.ckpt"
+    assert ckpt.exists()
+    fid = IWAE_CONFIG.replace("logs/toy/iwae_i5", "logs/toy/iwae_fid").replace("vgiwae.models.IWAE", "vgiwae.models.IWAE_FID") \
+        .replace("    num_importance_samples: 5\n", f"""    num_importance_samples: 5
+    fid_eval_step_freq: 8
+    inception_model_type: VAE_encoder
+    inception_model_path: {ckpt}
+    reference_samples: [ dataset_train, dataset_val, dataset_test ]
+    num_samples_per_batch: 500
+""").replace("max_epochs: 6", "max_epochs: 3")
+    history, _, _ = launch(workdir, "iwae_fid", fid)
+    for row in history:
+        assert {"fid_score/train", "fid_score/val", "fid_score/test"} <= set(row)
+        assert all(math.isfinite(row[k]) and row[k] > -1e-3 for k in row if k.startswith("fid_score"))
+    assert history[-1]["fid_score/train"] < history[0]["fid_score/train"]          # samples approach the data
+    sd = torch.load(workdir / "logs/toy/iwae_fid/seed_m20220118_d20220118/lightning_logs/version_0/checkpoints/last.ckpt",
+                    weights_only=True)["state_dict"]
+    assert not any("inception" in k for k in sd)

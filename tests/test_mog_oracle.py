@@ -78,3 +78,16 @@ def test_sampler_call_keeps_observed_values(g):
     assert not torch.equal(out[:, 0][~g["M"]], out[:, 1][~g["M"]])           # the K imputations are separate draws
     with pytest.raises(AssertionError):
         mu.VAESampler_MoG_Oracle(clip_imputations=True)
+
+
+def test_gaussian_fid_score():
+    """Frechet distance between Gaussians: closed form for commuting covariances, zero for equal ones"""
+    from vgiwae.shared.fid import gaussian_fid_score
+    m1, m2 = torch.tensor([0.0, 1.0, -1.0]), torch.tensor([0.5, 1.0, 1.0])
+    d1, d2 = torch.tensor([1.0, 4.0, 0.25]), torch.tensor([2.25, 1.0, 0.25])
+    got = gaussian_fid_score(m1, torch.diag(d1), m2, torch.diag(d2))
+    want = ((m1 - m2) ** 2).sum() + ((d1.sqrt() - d2.sqrt()) ** 2).sum()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    A = torch.randn(4, 4, generator=torch.Generator().manual_seed(0))
+    C = A @ A.T + torch.eye(4)
+    assert abs(float(gaussian_fid_score(m1[:1].repeat(4), C, m1[:1].repeat(4), C))) < 1e-4

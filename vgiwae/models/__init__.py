@@ -3,9 +3,10 @@
 The `*_FID`, `*MargLogprob` and `*GradVar` names are the reference's diagnostic wrappers
 (models/vae_fid.py:174-180, vae_marglogprob.py:140-146, vae_gradvar.py:51-57).  The `*MargLogprob` classes
 compute the grid marginal log-probability of the batch and, when asked for, the nine posterior-divergence
-diagnostics on the device (demiss_vae_amd/marginal.py) and log them under the reference's metric names; FID (needs a
-pre-trained encoder checkpoint) and the gradient-variance probe are accepted as keyword arguments, recorded, and
-skipped."""
+diagnostics on the device (demiss_vae_amd/marginal.py) and log them under the reference's metric names.  The `*_FID`
+classes evaluate the Frechet distance between model samples and the data splits in the feature space of a trained
+complete-data VAE's encoder every `fid_eval_step_freq` steps (vgiwae/shared/fid.py); without that checkpoint on disk
+the metric is skipped with a notice.  The gradient-variance probe's keyword arguments are accepted and ignored."""
 from .vae import VAE
 from .iwae import IWAE
 from .mvbvae import MVBVAE, MVB_OBJECTIVE
@@ -51,6 +52,66 @@ def _marginal_logprob(self, batch, stage):
             self.log(f"{name}/{stage}", value.mean(), on_step=False, on_epoch=True, prog_bar=True, logger=True)
 
 
+def _fid_members(base):
+    """hooks of the FID wrapper (models/vae_fid.py:42-158)"""
+    import os
+    import torch
+    from vgiwae.shared.fid import compute_inception_gaussian, gaussian_fid_score
+
+    def _inception(self):
+        """encoder of the trained VAE named by the hyper-parameters, or None; kept out of the module tree so that it
+        never reaches state_dict() or the optimiser (vae_fid.py:93-100)"""
+        if "_fid_inception" not in self.__dict__:
+            h, net = self.hparams, None
+            if h.inception_model_type is not None:
+                if h.inception_model_type != "VAE_encoder":
+                    raise NotImplementedError(f"Unknown inception model type: {h.inception_model_type}")
+                if h.inception_model_path and os.path.exists(h.inception_model_path):
+                    from demiss_vae_amd.run import load_model
+                    net = load_model(h.inception_model_path, "VAE").var_latent_network.to(self.device).eval()
+                    for p in net.parameters():
+                        p.requires_grad_(False)
+                else:
+                    print(f"FID skipped: no inception model at {h.inception_model_path}")
+            self.__dict__["_fid_inception"] = net
+        return self.__dict__["_fid_inception"]
+
+    def on_train_start(self):
+        base.on_train_start(self)
+        self.fid_ref_dataset_sizes, self.fid_ref_gaussians = [], []
+        net = _inception(self)
+        if net is None:
+            return
+        dm = self.trainer.datamodule
+        batch = min(self.hparams.num_samples_per_batch or 5000, 5000)
+        for ref in self.hparams.reference_samples or []:
+            if ref not in ("dataset_test", "dataset_val", "dataset_train"):
+                raise NotImplementedError(f"Unknown ref={ref}")
+            split = ref[len("dataset_"):]
+            if not hasattr(dm, f"{split}_data_core"):
+                dm.setup(stage="test" if split == "test" else "fit")
+            data = getattr(dm, f"{split}_data_core")[:]
+            data = torch.as_tensor(data[0] if isinstance(data, tuple) else data).to(self.device)
+            self.fid_ref_dataset_sizes.append(data.shape[0])
+            self.fid_ref_gaussians.append(compute_inception_gaussian(data, inception_model=net, batch_size=batch))
+
+    def eval_fid_score(self, ref_id):
+        n = min(self.fid_ref_dataset_sizes[ref_id], 20000)
+        per = self.hparams.num_samples_per_batch or n
+        with torch.no_grad():
+            samples = torch.cat([self.sample_vae(min(per, n - b)) for b in range(0, n, per)], dim=0)
+            mean, cov = compute_inception_gaussian(samples, inception_model=_inception(self), batch_size=min(per, 5000))
+        return gaussian_fid_score(*self.fid_ref_gaussians[ref_id], mean, cov)
+
+    def on_train_batch_end(self, outputs, batch, batch_idx):
+        step = self.trainer.global_step
+        if not self.fid_ref_gaussians or not (step % self.hparams.fid_eval_step_freq == 0 or step == self.trainer.max_steps):
+            return
+        for ref_id, ref in enumerate(self.hparams.reference_samples):
+            self.log(f"fid_score/{ref[len('dataset_'):]}", eval_fid_score(self, ref_id), on_step=True, on_epoch=False)
+    return dict(on_train_start=on_train_start, eval_fid_score=eval_fid_score, on_train_batch_end=on_train_batch_end)
+
+
 def _with_ignored_diagnostics(base, suffix):
     defaults = _DIAGNOSTIC_KWARGS[suffix]
 
@@ -75,6 +136,8 @@ def _with_ignored_diagnostics(base, suffix):
             _marginal_logprob(self, batch, "val")
             return out
         members.update(training_step=training_step, validation_step=validation_step)
+    if suffix == "_FID":
+        members.update(_fid_members(base))
     return type(name, (base,), members)
 
 
