@@ -88,6 +88,9 @@ except Exception:  # ModuleNotFoundError here; any import-time failure means "no
         def on_train_batch_end(self, outputs, batch, batch_idx):
             pass
 
+        def on_before_optimizer_step(self, optimizer, optimizer_idx):
+            pass
+
         def on_train_epoch_end(self):
             pass
 

@@ -183,6 +183,7 @@ class _StepRunner:
             opt.zero_grad(set_to_none=True)
             loss.backward()
             P.allreduce_grads(self.params)
+            m.on_before_optimizer_step(opt, 0)
             m.configure_gradient_clipping(opt, 0, gradient_clip_val=self.clip_val, gradient_clip_algorithm=self.clip_alg)
             opt.step()
         else:
@@ -336,7 +337,9 @@ def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None):
                 done = True
                 break
         model._schedulers = sched
+        model._logged = {}
         model.on_train_epoch_end()
+        means.add(model._logged)            # what the hook logs once per epoch
         model.eval()
         model._logged = {}
         vmeans = _Means()

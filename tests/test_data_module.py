@@ -250,3 +250,32 @@ def test_checkpoint_round_trip_and_path_resolution(tmp_path):
         assert k == k2 and torch.equal(a, b)
     ck = torch.load(found, weights_only=True)
     assert ck["hyper_parameters"]["mvb_objective"] == "mvb2" and ck["epoch"] == 2
+
+
+def test_gradient_variance_probe_matches_the_stacked_gradient_formula(tmp_path):
+    """*GradVar classes: running sums reproduce std / mean over the stacked per-step gradients
+    (vgiwae/shared/vae_grad_var.py:20-45), dead coordinates left out of the signal-to-noise sum"""
+    path = tmp_path / "cfg.yaml"
+    path.write_text(CONFIG.replace("MVBVAEMargLogprob", "MVBVAEGradVar").replace("    latent_grid_steps: 50\n", "")
+                    .replace("    compute_complete_var_distribution_kl: True\n", ""))
+    m = run.instantiate(run.load_config(str(path))["model"])
+    gen = torch.Generator().manual_seed(0)
+    for epoch in range(2):
+        m.on_train_epoch_start()
+        stacks = {"generator": [], "encoder": []}
+        for step in range(7):
+            for name, net in (("generator", m.generator_network), ("encoder", m.var_latent_network)):
+                for i, p in enumerate(net.parameters()):
+                    p.grad = torch.randn(p.shape, generator=gen) * (0.0 if i == 1 else 1.0 + step)     # one dead tensor
+                stacks[name].append(torch.cat([p.grad.flatten() for p in net.parameters()]))
+            m.on_before_optimizer_step(None, 0)
+        m._logged = {}
+        m.train_imp_distribution = m.val_imp_distribution = None       # the DeMissVAE epoch-end hook is not under test
+        m.resample_imputations = lambda stage: None
+        m.on_train_epoch_end()
+        for name in ("generator", "encoder"):
+            g = torch.stack(stacks[name]).double()
+            std = g.std(0, unbiased=True)
+            snr = (g.mean(0) / std).abs()
+            np.testing.assert_allclose(float(m._logged[f"{name}_grad_var/train"]), float((std ** 2).sum()), rtol=1e-5)
+            np.testing.assert_allclose(float(m._logged[f"{name}_grad_snr/train"]), float(snr[torch.isfinite(snr)].sum()), rtol=1e-5)

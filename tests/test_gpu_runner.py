@@ -214,3 +214,13 @@ def test_fid_metric_against_a_trained_encoder(workdir):
     sd = torch.load(workdir / "logs/toy/iwae_fid/seed_m20220118_d20220118/lightning_logs/version_0/checkpoints/last.ckpt",
                     weights_only=True)["state_dict"]
     assert not any("inception" in k for k in sd)
+
+
+def test_gradvar_class_logs_through_recorded_steps(workdir):
+    """IWAEGradVar through the runner: the probe's accumulation is part of the recorded step"""
+    text = IWAE_CONFIG.replace("logs/toy/iwae_i5", "logs/toy/iwae_gradvar").replace("vgiwae.models.IWAE", "vgiwae.models.IWAEGradVar") \
+        .replace("max_epochs: 6", "max_epochs: 2")
+    history, _, _ = launch(workdir, "iwae_gradvar", text)
+    for row in history:
+        for k in ("generator_grad_var/train", "encoder_grad_var/train", "generator_grad_snr/train", "encoder_grad_snr/train"):
+            assert math.isfinite(row[k]) and row[k] > 0, (k, row)

@@ -6,7 +6,8 @@ compute the grid marginal log-probability of the batch and, when asked for, the 
 diagnostics on the device (demiss_vae_amd/marginal.py) and log them under the reference's metric names.  The `*_FID`
 classes evaluate the Frechet distance between model samples and the data splits in the feature space of a trained
 complete-data VAE's encoder every `fid_eval_step_freq` steps (vgiwae/shared/fid.py); without that checkpoint on disk
-the metric is skipped with a notice.  The gradient-variance probe's keyword arguments are accepted and ignored."""
+the metric is skipped with a notice.  The `*GradVar` classes log the per-epoch gradient variance and signal-to-noise
+ratio of both networks (vgiwae/shared/vae_grad_var.py)."""
 from .vae import VAE
 from .iwae import IWAE
 from .mvbvae import MVBVAE, MVB_OBJECTIVE
@@ -138,6 +139,22 @@ def _with_ignored_diagnostics(base, suffix):
         members.update(training_step=training_step, validation_step=validation_step)
     if suffix == "_FID":
         members.update(_fid_members(base))
+    if suffix == "GradVar":
+        from vgiwae.shared import vae_grad_var as gv
+
+        def on_train_epoch_start(self):
+            base.on_train_epoch_start(self)
+            gv.gradvar_on_train_epoch_start(self)
+
+        def on_train_epoch_end(self):
+            base.on_train_epoch_end(self)
+            gv.gradvar_training_epoch_end(self)
+
+        def on_before_optimizer_step(self, optimizer, optimizer_idx):
+            base.on_before_optimizer_step(self, optimizer, optimizer_idx)
+            gv.gradvar_on_before_optimizer_step(self, optimizer, optimizer_idx)
+        members.update(on_train_epoch_start=on_train_epoch_start, on_train_epoch_end=on_train_epoch_end,
+                       on_before_optimizer_step=on_before_optimizer_step)
     return type(name, (base,), members)
 
 

@@ -13,6 +13,7 @@ def mvb2_manual_optimisation_step(self, enc_loss, gen_loss):
     P.allreduce_grads([p for g in opt.param_groups for p in g["params"]])
     self.configure_gradient_clipping(opt, -1, gradient_clip_val=self.hparams.mvb2_optim_gradclip_val,
                                      gradient_clip_algorithm=self.hparams.mvb2_optim_gradclip_alg)
+    self.on_before_optimizer_step(opt, 0)       # Lightning calls the hook from inside the wrapped optimizer.step()
     opt.step()
     if self.hparams.use_lr_scheduler:
         self.lr_schedulers().step()
