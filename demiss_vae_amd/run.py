@@ -133,8 +133,9 @@ def init_distributed():
     import torch.distributed as dist
     if int(os.environ.get("WORLD_SIZE", 1)) > 1 and not dist.is_initialized():
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
+        # RCCL on the GPU; DMV_DIST_BACKEND=gloo lets several ranks share one GPU in rehearsals and tests
+        dist.init_process_group(os.environ.get("DMV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo"))
 
 
 class _DeferredScheduler:
@@ -294,7 +295,7 @@ class Checkpointer:
 
 def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None):
     from . import rng
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1))
     max_epochs = trainer_cfg.get("max_epochs")
     max_steps = trainer_cfg.get("max_steps", -1)
     max_steps = -1 if max_steps is None else max_steps
@@ -360,8 +361,15 @@ def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None):
     if checkpointer is not None:
         checkpointer.on_train_end(epoch, step)
     trainer.hip_graph_replays = run_step.replays
+    summary = {"steps": step, "hip_graph_replays": run_step.replays}
+    if P.world() > 1:
+        # replicas must hold identical parameters: largest difference between any two ranks
+        import torch.distributed as dist
+        flat = torch.cat([p.detach().flatten() for p in params])
+        hi, lo = P.all_reduce(flat.clone(), dist.ReduceOp.MAX), P.all_reduce(flat.clone(), dist.ReduceOp.MIN)
+        summary.update(world=P.world(), replica_spread=float((hi - lo).abs().max()))
     if P.rank() == 0:
-        log(json.dumps({"steps": step, "hip_graph_replays": run_step.replays}))
+        log(json.dumps(summary))
     return history
 
 
