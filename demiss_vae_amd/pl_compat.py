@@ -63,6 +63,14 @@ except Exception:  # ModuleNotFoundError here; any import-time failure means "no
                 for k, v in loc.get(code.co_varnames[pos], {}).items():
                     self.hparams.setdefault(k, v)
 
+        @classmethod
+        def load_from_checkpoint(cls, checkpoint_path, **kwargs):
+            """Rebuilds a model from a checkpoint written by demiss_vae_amd.run (tensors + the YAML node of the model),
+            as this class - the call the reference's refit script makes on Lightning checkpoints
+            (refit_encoder_using_iwae_and_estimate_loglik.py:125)."""
+            from demiss_vae_amd.run import load_model
+            return load_model(checkpoint_path, cls.__name__)
+
         # ---- plumbing
         @property
         def device(self):

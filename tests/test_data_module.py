@@ -246,6 +246,8 @@ def test_checkpoint_round_trip_and_path_resolution(tmp_path):
     assert found == exp + "/lightning_logs/version_1/checkpoints/last.ckpt"
     back = run.load_model(found, "MVBVAE")
     assert type(back).__name__ == "MVBVAE"
+    from vgiwae.models import MVBVAE_FID
+    assert type(MVBVAE_FID.load_from_checkpoint(found)).__name__ == "MVBVAE_FID"
     for (k, a), (k2, b) in zip(m.state_dict().items(), back.state_dict().items()):
         assert k == k2 and torch.equal(a, b)
     ck = torch.load(found, weights_only=True)
