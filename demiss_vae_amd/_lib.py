@@ -61,6 +61,7 @@ SIGNATURES = {
     "dmv_mlp_backward_ws_bytes": (_SZ, [C.POINTER(DmvNet), _I64]),
     "dmv_mlp_backward": (C.c_int, [C.POINTER(DmvNet), _P, _P, _P, _P, _I64, _I64, _P, _I64,
                                    C.POINTER(_P), C.POINTER(_P), _F, _P, _SZ, _P]),
+    "dmv_mlp_backward_wgrad": (C.c_int, [C.POINTER(DmvNet), _P, _P, _I64, _I64, _P, _P, _F, _P, _SZ, _P]),
     "dmv_latent_sample": (C.c_int, [C.POINTER(DmvObjCfg), _P, _P, _U64, _U64, _P, _I64, _P, _P, _P, _P]),
     "dmv_obj_terms": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "dmv_obj_bound": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -1409,18 +1409,20 @@ extern "C" size_t dmv_mlp_backward_ws_bytes(const DmvNet* net, int64_t rows) {
   return (size_t)(dacts + slab_floats) * sizeof(float);
 }
 
-extern "C" int dmv_mlp_backward(const DmvNet* net, const float* packed, const float* saved, const uint8_t* drop_keep,
-                                const float* gy, int64_t ldgy, int64_t rows, float* dx, int64_t lddx,
-                                float* const* grad_w, float* const* grad_b, float beta, void* ws, size_t ws_bytes,
-                                void* stream) {
+// run_chain: the input-gradient chain (fills the per-layer gradients in ws); grad_w != NULL: the weight-gradient GEMMs
+// over what the chain left in ws
+static int mlp_backward_impl(const DmvNet* net, const float* packed, const float* saved, const uint8_t* drop_keep,
+                             const float* gy, int64_t ldgy, int64_t rows, float* dx, int64_t lddx,
+                             float* const* grad_w, float* const* grad_b, float beta, void* ws, size_t ws_bytes,
+                             void* stream, bool run_chain) {
   int rc = dmv_check_net(net);
   if (rc) return rc;
-  if (!packed || !saved || !gy || rows < 0 || !ws) return DMV_E_BADARG;
+  if ((run_chain && !packed) || !saved || !gy || rows < 0 || !ws) return DMV_E_BADARG;
   if ((grad_w == nullptr) != (grad_b == nullptr)) return DMV_E_BADARG;
   if (rows == 0) return DMV_OK;
   if (ldgy < dmv_pad32(net->out_dim) || (ldgy & 3) || ((uintptr_t)gy & 15)) return DMV_E_BADARG;
   if (dx && (lddx < dmv_pad32(net->in_dim) || (lddx & 3) || ((uintptr_t)dx & 15))) return DMV_E_BADARG;
-  if (net->dropout_p > 0.f && !drop_keep) return DMV_E_BADARG;
+  if (run_chain && net->dropout_p > 0.f && !drop_keep) return DMV_E_BADARG;
   if (ws_bytes < dmv_mlp_backward_ws_bytes(net, rows)) return DMV_E_WORKSPACE;
   if ((uintptr_t)ws & 15) return DMV_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
@@ -1440,7 +1442,7 @@ extern "C" int dmv_mlp_backward(const DmvNet* net, const float* packed, const fl
   b.masks = (const uint32_t*)(acts + (2 * net->nb + 1) * rp * Hp);
   b.gy = gy; b.ldgy = ldgy; b.rows = rows;
   b.dacts = dacts; b.dx = dx; b.lddx = lddx;
-  {
+  if (run_chain) {
     int r2;
     switch (b.L.NT) {
       case 1: r2 = launch_bwd<1>(b, st); break;
@@ -1480,4 +1482,20 @@ extern "C" int dmv_mlp_backward(const DmvNet* net, const float* packed, const fl
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(rgrid), dim3(256), 0, st, ra);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
+}
+
+extern "C" int dmv_mlp_backward(const DmvNet* net, const float* packed, const float* saved, const uint8_t* drop_keep,
+                                const float* gy, int64_t ldgy, int64_t rows, float* dx, int64_t lddx,
+                                float* const* grad_w, float* const* grad_b, float beta, void* ws, size_t ws_bytes,
+                                void* stream) {
+  return mlp_backward_impl(net, packed, saved, drop_keep, gy, ldgy, rows, dx, lddx, grad_w, grad_b, beta, ws, ws_bytes,
+                           stream, true);
+}
+
+extern "C" int dmv_mlp_backward_wgrad(const DmvNet* net, const float* saved, const float* gy, int64_t ldgy, int64_t rows,
+                                      float* const* grad_w, float* const* grad_b, float beta, void* ws, size_t ws_bytes,
+                                      void* stream) {
+  if (!grad_w || !grad_b) return DMV_E_BADARG;
+  return mlp_backward_impl(net, nullptr, saved, nullptr, gy, ldgy, rows, nullptr, 0, grad_w, grad_b, beta, ws, ws_bytes,
+                           stream, false);
 }

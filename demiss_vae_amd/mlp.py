@@ -117,9 +117,30 @@ def mlp_forward(net: PackedNet, x: torch.Tensor, ldx: int, rows: int, *, in_mode
     return y, saved
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device) -> torch.cuda.Stream:
+    """one extra stream per device for work that may overlap the main stream's (weight-gradient GEMMs of small batches)"""
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+def overlap_pays(rows: int) -> bool:
+    """the weight-gradient GEMMs of a batch this small leave most of the GPU idle: worth a second stream"""
+    return 0 < rows <= 16384
+
+
 def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: int, *, need_dx: bool,
-                 need_param_grads: bool, drop_keep: Optional[torch.Tensor] = None):
-    """gy [rows, pad32(out_dim)] -> (dx [rows, pad32(in_dim)] or None, [gW0, gb0, gW1, ...] or None)."""
+                 need_param_grads: bool, drop_keep: Optional[torch.Tensor] = None,
+                 wgrad_stream: Optional[torch.cuda.Stream] = None, keepalive: Optional[list] = None):
+    """gy [rows, pad32(out_dim)] -> (dx [rows, pad32(in_dim)] or None, [gW0, gb0, gW1, ...] or None).
+
+    wgrad_stream: run the weight-gradient GEMMs there, after the input-gradient chain on the current stream; the
+    caller makes the current stream wait for it before the gradients are used and keeps `keepalive` (filled with the
+    buffers the side stream reads) alive until then."""
     d = net.dims
     dev = gy.device
     assert gy.shape == (rows, pad32(d.out_dim)) and gy.is_contiguous()
@@ -132,7 +153,16 @@ def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: in
         gw_arr, gb_arr = L.ptr_array(gws), L.ptr_array(gbs)
     nbytes = L.lib().dmv_mlp_backward_ws_bytes(C.byref(net.c), rows)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
-    if rows:
+    if rows and wgrad_stream is not None and need_param_grads:
+        lib = L.lib()
+        L.check(lib.dmv_mlp_backward(C.byref(net.c), L.ptr(net.packed()), L.ptr(saved), L.ptr(drop_keep),
+                                     L.ptr(gy), gy.shape[1], rows, L.ptr(dx), dx.shape[1] if need_dx else 0,
+                                     None, None, 0.0, L.ptr(ws), nbytes, L.stream_ptr()))
+        wgrad_stream.wait_stream(torch.cuda.current_stream())
+        L.check(lib.dmv_mlp_backward_wgrad(C.byref(net.c), L.ptr(saved), L.ptr(gy), gy.shape[1], rows, gw_arr, gb_arr, 0.0,
+                                           L.ptr(ws), nbytes, C.c_void_p(wgrad_stream.cuda_stream)))
+        keepalive += [ws, gy, saved]
+    elif rows:
         L.check(L.lib().dmv_mlp_backward(C.byref(net.c), L.ptr(net.packed()), L.ptr(saved), L.ptr(drop_keep),
                                          L.ptr(gy), gy.shape[1], rows, L.ptr(dx), dx.shape[1] if need_dx else 0,
                                          gw_arr, gb_arr, 0.0, L.ptr(ws), nbytes, L.stream_ptr()))

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib as L
 from . import rng
-from .mlp import PackedNet, mlp_forward, mlp_backward, pad32
+from .mlp import PackedNet, mlp_forward, mlp_backward, pad32, side_stream, overlap_pays
 
 
 @dataclass(frozen=True)
@@ -205,13 +205,25 @@ def _kl(c):
     return kl
 
 
-def _dec_side(c, dec: PackedNet, wgt_total, base_m, base_f, need_dx, need_param_grads):
+def _dec_side(c, dec: PackedNet, wgt_total, base_m, base_f, need_dx, need_param_grads, overlap=None):
+    """overlap: a list; when given (and the batch is small) the decoder's weight-gradient GEMMs go to the side stream
+    while the caller carries on upstream, and the list receives what must stay alive until the caller has joined"""
     lib, st = L.lib(), L.stream_ptr()
     d_dec = torch.empty_like(c.dec_out)
     L.check(lib.dmv_obj_backward_dec(C.byref(c.cfg), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
                                      L.ptr(wgt_total), None, base_m, base_f, L.ptr(d_dec), d_dec.shape[1], st))
+    side = side_stream(d_dec.device) if (overlap is not None and need_dx and need_param_grads and overlap_pays(c.N)) else None
+    if side is not None:
+        overlap.append(side)
     return mlp_backward(dec, c.dec_saved, d_dec, c.N, need_dx=need_dx, need_param_grads=need_param_grads,
-                        drop_keep=c.dec_keep)
+                        drop_keep=c.dec_keep, wgrad_stream=side, keepalive=overlap)
+
+
+def _join(overlap):
+    """the current stream waits for the side stream's weight gradients; only then may the buffers go"""
+    if overlap:
+        torch.cuda.current_stream().wait_stream(overlap[0])
+        overlap.clear()
 
 
 def _enc_side(c, enc: PackedNet, p: L.DmvLatentBwd, dZ, wgt_total, zscale, dlogit_total, kl_wgt):
@@ -305,11 +317,13 @@ class _FusedObjective(torch.autograd.Function):
         if k in ("iwae", "miwae") and gouts[0] is not None:
             g_b = gouts[0].float().contiguous()
             wt = (c.wgt.reshape(S, B, G) * g_b.reshape(1, B, 1)).reshape(-1).contiguous()
-            dZ, g_dec_params = _dec_side(c, dec, wt, 1.0, 0.0, True, True)
+            pending = []
+            dZ, g_dec_params = _dec_side(c, dec, wt, 1.0, 0.0, True, True, overlap=pending)
             if c.reparam:
                 d_enc = _implicit_d_enc(c, dZ, wt, 1.0, -1.0)
                 _, g_enc_params = mlp_backward(enc, c.enc_saved, d_enc, c.enc_rows, need_dx=False, need_param_grads=True,
                                                drop_keep=c.enc_keep)
+                _join(pending)
                 return (None,) * 10 + tuple(g_enc_params) + tuple(g_dec_params)
             mixture = c.q_kind == L.Q_STRATIFIED
             dl = (c.dlogit * g_b.reshape(B, 1)).contiguous() if mixture else None
@@ -318,6 +332,7 @@ class _FusedObjective(torch.autograd.Function):
             else:
                 p = _latent_params(prior=1.0, qown=-1.0, own_live=not (plan.STL or plan.DREG), use_zscale=plan.DREG)
             g_enc_params = _enc_side(c, enc, p, dZ, wt, c.zscale, dl, None)
+            _join(pending)
         elif k == "elbo_analytic" and gouts[0] is not None:
             g_b = gouts[0].float().contiguous()
             wt = per_sample(g_b)

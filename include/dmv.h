@@ -115,6 +115,13 @@ int dmv_mlp_backward(const DmvNet* net, const float* packed, const float* saved,
                      float* dx, int64_t lddx, float* const* grad_w, float* const* grad_b, float beta,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* The weight-gradient half of dmv_mlp_backward on its own, after a call of dmv_mlp_backward with grad_w == NULL and the
+ * same saved / gy / rows / ws (that call leaves the per-layer output gradients in ws).  Lets a caller put the
+ * weight-gradient GEMMs on a second stream while the backward pass continues upstream on the first. */
+int dmv_mlp_backward_wgrad(const DmvNet* net, const float* saved, const float* gy, int64_t ldgy, int64_t rows,
+                           float* const* grad_w, float* const* grad_b, float beta, void* ws, size_t ws_bytes,
+                           void* stream);
+
 /* ----- objective --------------------------------------------------------------------------
  * Sample rows are ordered n = (s*B + b)*G + g with s = z*I + i  (reference tensor shapes
  * [nz, I, B, (G,) .]).  Encoder-output addressing (in floats, per datapoint b and component g):
