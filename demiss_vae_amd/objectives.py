@@ -336,23 +336,29 @@ class _FusedObjective(torch.autograd.Function):
         elif k == "elbo_analytic" and gouts[0] is not None:
             g_b = gouts[0].float().contiguous()
             wt = per_sample(g_b)
-            dZ, g_dec_params = _dec_side(c, dec, wt, 1.0, 0.0, True, True)
+            pending = []
+            dZ, g_dec_params = _dec_side(c, dec, wt, 1.0, 0.0, True, True, overlap=pending)
             p = _latent_params(kl=-1.0)
             g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, g_b.reshape(B, 1).contiguous())
+            _join(pending)
         elif k == "cvi" and gouts[0] is not None:
             wt = per_sample(gouts[0])
-            dZ, g_dec_params = _dec_side(c, dec, wt, 1.0, 0.0, True, True)
+            pending = []
+            dZ, g_dec_params = _dec_side(c, dec, wt, 1.0, 0.0, True, True, overlap=pending)
             p = _latent_params(prior=1.0, qmix=-1.0, mix_live=not plan.STL, mix_kind=L.Q_IMPUTATION)
             g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, None)
+            _join(pending)
         elif k == "mvb" and gouts[0] is not None:
             wt = per_sample(gouts[0])
-            dZ, g_dec_params = _dec_side(c, dec, wt, 0.0, 1.0, True, True)
+            pending = []
+            dZ, g_dec_params = _dec_side(c, dec, wt, 0.0, 1.0, True, True, overlap=pending)
             if plan.kl_analytic:
                 p = _latent_params(kl=-1.0)
                 g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, gouts[0].float().contiguous())
             else:
                 p = _latent_params(prior=1.0, qown=-1.0, own_live=not plan.STL)
                 g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, None)
+            _join(pending)
         elif k == "mvb2":
             # vgiwae/shared/mvb2_manual_optimisation.py:6-8: the generator objective updates the decoder
             # only, the encoder objective the encoder only (through the decoder's input gradient).
