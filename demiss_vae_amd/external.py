@@ -107,6 +107,7 @@ class _Objective(torch.autograd.Function):
     def forward(ctx, c, dec_out, enc_out):
         lib, st = L.lib(), L.stream_ptr()
         plan = c.plan
+        # the inputs are outputs of the caller's torch modules: without gradient mode they do not require grad
         training = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dec = dec_out.detach().contiguous().float()
         assert dec.shape[0] == c.N and dec.shape[1] >= c.dims.dec_params

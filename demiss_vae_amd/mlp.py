@@ -192,11 +192,13 @@ class ResidualMLPFunction(torch.autograd.Function):
     (e.g. model.generator_network(Z), vgiwae/models/vae.py:279,309)."""
 
     @staticmethod
-    def forward(ctx, net: PackedNet, drop_keep, x, *params):
+    def forward(ctx, net: PackedNet, grad: bool, drop_keep, x, *params):
         d = net.dims
         x2 = x.reshape(-1, d.in_dim).contiguous().float()
         rows = x2.shape[0]
-        need = any(ctx.needs_input_grad[2:])
+        # grad: gradient mode at call time (needs_input_grad mirrors requires_grad even when gradients are switched
+        # off, and inside forward the mode always reads "off")
+        need = grad and any(ctx.needs_input_grad[3:])
         y, saved = mlp_forward(net, x2, d.in_dim, rows, save=need, drop_keep=drop_keep)
         ctx.net, ctx.saved, ctx.rows, ctx.drop_keep = net, saved, rows, drop_keep
         ctx.lead = x.shape[:-1]
@@ -207,11 +209,11 @@ class ResidualMLPFunction(torch.autograd.Function):
         net, d = ctx.net, ctx.net.dims
         g = torch.zeros((ctx.rows, pad32(d.out_dim)), dtype=torch.float32, device=gy.device)
         g[:, :d.out_dim] = gy.reshape(ctx.rows, d.out_dim)
-        need_dx = ctx.needs_input_grad[2]
-        need_p = any(ctx.needs_input_grad[3:])
+        need_dx = ctx.needs_input_grad[3]
+        need_p = any(ctx.needs_input_grad[4:])
         dx, grads = mlp_backward(net, ctx.saved, g, ctx.rows, need_dx=need_dx, need_param_grads=need_p,
                                  drop_keep=ctx.drop_keep)
         gx = dx[:, :d.in_dim].reshape(*ctx.lead, d.in_dim) if need_dx else None
         if grads is None:
             grads = [None] * (2 * d.num_layers)
-        return (None, None, gx, *grads)
+        return (None, None, None, gx, *grads)

@@ -15,6 +15,7 @@ Noise: pass `eps` (standard normal, reference sample shape) for reproducible par
 it None to draw from the on-device Philox stream (demiss_vae_amd.rng).
 """
 import ctypes as C
+import dataclasses
 from dataclasses import dataclass
 from typing import Optional
 
@@ -62,6 +63,7 @@ class _Plan:
     DREG: bool = False
     looser: bool = False
     kl_analytic: bool = False
+    grad: bool = True    # gradient mode at call time (inside an autograd function's forward it always reads "off")
 
 
 def _u8(M: torch.Tensor) -> torch.Tensor:
@@ -271,7 +273,8 @@ class _FusedObjective(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx, *params):
-        training = any(ctx.needs_input_grad[10:])
+        # needs_input_grad mirrors requires_grad of the inputs even when gradients are switched off (validation)
+        training = plan.grad and any(ctx.needs_input_grad[10:])
         if dims.q_is_reparam:
             assert plan.kind == "iwae" and not plan.DREG, "reparametrised mixtures: ELBO (MC KL) and IWAE bounds only"
             assert plan.STL or not training, "reparametrised mixtures are trained with var_latent_STL (as every config does)"
@@ -384,8 +387,8 @@ class _DemissTerms(torch.autograd.Function):
     parameters only, the second to the encoder parameters only (through the decoder's input gradient)."""
 
     @staticmethod
-    def forward(ctx, dims, nz, I, q_live, split, enc, dec, Xt, M, eps, enc_keep, dec_keep, *params):
-        training = any(ctx.needs_input_grad[12:])
+    def forward(ctx, dims, nz, I, q_live, split, grad, enc, dec, Xt, M, eps, enc_keep, dec_keep, *params):
+        training = grad and any(ctx.needs_input_grad[13:])
         plan = _Plan("terms", nz, I)
         c = _forward_core(dims, plan, enc, dec, Xt, M, eps, enc_keep, dec_keep, training)
         ctx.c, ctx.enc, ctx.dec, ctx.q_live, ctx.split = c, enc, dec, q_live, split
@@ -430,7 +433,7 @@ class _DemissTerms(torch.autograd.Function):
             dZ, g_dec_params = mlp_backward(dec, c.dec_saved, dec_cotangent(flat[0]), c.N, need_dx=True, need_param_grads=True,
                                             drop_keep=c.dec_keep)
             g_enc_params = encoder_grads(flat[0], dZ)
-        return (None,) * 12 + tuple(g_enc_params) + tuple(g_dec_params)
+        return (None,) * 13 + tuple(g_enc_params) + tuple(g_dec_params)
 
 
 def demiss_terms(dims, enc, dec, Xt, M, *, num_latent_samples=1, num_importance_samples=1, q_live=True, split=False, eps=None,
@@ -441,11 +444,12 @@ def demiss_terms(dims, enc, dec, Xt, M, *, num_latent_samples=1, num_importance_
     parameters as constants inside the two q terms ("sticking the landing" / doubly reparameterised estimators).
     Returns (terms,) or, with split, (terms_for_decoder, terms_for_encoder)."""
     assert not dims.q_is_mixture and not dims.q_is_reparam
-    return _DemissTerms.apply(dims, num_latent_samples, num_importance_samples, q_live, split, enc, dec, Xt, M, eps,
+    return _DemissTerms.apply(dims, num_latent_samples, num_importance_samples, q_live, split, torch.is_grad_enabled(), enc, dec, Xt, M, eps,
                               enc_keep, dec_keep, *enc.params(), *dec.params())
 
 
 def _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx=None):
+    plan = dataclasses.replace(plan, grad=torch.is_grad_enabled())
     return _FusedObjective.apply(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx, *enc.params(), *dec.params())
 
 

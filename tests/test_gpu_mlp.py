@@ -21,7 +21,7 @@ def test_mlp_golden(name):
     x = (torch.from_numpy(g["x"]) if "x" in g else make_noise(seed + 1, rows, spec.in_dim)).cuda().requires_grad_(True)
     gy = (torch.from_numpy(g["gy"]) if "gy" in g else make_noise(seed + 2, rows, spec.out_dim)).cuda()
     keep = G.keep_to_dev(gu.dropout_masks(seed + 3, spec, (rows,)))
-    y = dmv.ResidualMLPFunction.apply(net, keep, x, *net.params())
+    y = dmv.ResidualMLPFunction.apply(net, True, keep, x, *net.params())
     y.backward(gy)
     torch.testing.assert_close(y.detach().cpu(), torch.from_numpy(g["y"]), rtol=1e-5, atol=2e-6)
     torch.testing.assert_close(x.grad.cpu(), torch.from_numpy(g["dx"]), rtol=1e-4, atol=2e-6)
@@ -42,7 +42,7 @@ def test_mlp_vs_oracle(shape, act):
     x_cpu = make_noise(78, rows, i)
     gy_cpu = make_noise(79, rows, o)
     x = x_cpu.cuda().requires_grad_(True)
-    y = dmv.ResidualMLPFunction.apply(net, None, x, *net.params())
+    y = dmv.ResidualMLPFunction.apply(net, True, None, x, *net.params())
     y.backward(gy_cpu.cuda())
     p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
     x64 = x_cpu.double().requires_grad_(True)
@@ -62,7 +62,7 @@ def test_mlp_empty_and_errors():
     import gpu_util as G
     spec = NetSpec(4, 4, 1, 32)
     net = G.packed_net(spec, make_params(spec, 1))
-    y = dmv.ResidualMLPFunction.apply(net, None, torch.zeros(0, 4, device="cuda"), *net.params())
+    y = dmv.ResidualMLPFunction.apply(net, True, None, torch.zeros(0, 4, device="cuda"), *net.params())
     assert y.shape == (0, 4)
     with pytest.raises(RuntimeError):
         dmv.PackedNet(dmv.NetDims(4, 4, 1, 512), net.weights, net.biases)   # hidden width the kernels do not cover
@@ -88,7 +88,7 @@ def test_small_batch_and_large_batch_kernels_agree_bitwise():
             ys, dxs = [], []
             for xc, gc in zip(x.chunk(chunks), gy.chunk(chunks)):
                 xc = xc.clone().requires_grad_(True)
-                y = ResidualMLPFunction.apply(net, None, xc, *net.params())
+                y = ResidualMLPFunction.apply(net, True, None, xc, *net.params())
                 y.backward(gc)
                 ys.append(y.detach())
                 dxs.append(xc.grad)

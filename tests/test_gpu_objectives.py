@@ -201,3 +201,26 @@ def test_latent_sample_vector_and_scalar_kernels_agree():
     sg = torch.nn.functional.softplus(enc[:, G * Zd:2 * G * Zd]).reshape(B, G, Zd)
     want = mu.unsqueeze(0) + sg.unsqueeze(0) * eps.reshape(S, B, G, Zd)
     torch.testing.assert_close(Z2.reshape(S, B, G, Zd), want, rtol=1e-5, atol=1e-6)
+
+
+def test_no_grad_evaluation_saves_nothing_and_accepts_dropout_networks():
+    """Under torch.no_grad() (validation) the pipelines run in inference mode: no saved activations, and networks with
+    dropout need no masks (the parameters still have requires_grad=True, which autograd reports to the function)."""
+    import demiss_vae_amd as dmv
+    from oracle.recipes import NetSpec, make_batch, make_params
+    import gpu_util as G
+    enc_s, dec_s = NetSpec(16, 32, 1, 64, dropout=0.5), NetSpec(16, 16, 1, 64, dropout=0.5)
+    enc, dec = G.packed_net(enc_s, make_params(enc_s, 1)), G.packed_net(dec_s, make_params(dec_s, 2))
+    dims = dmv.ModelDims(D=8, Zd=16, encoder_use_mis_mask=True)
+    X, M = (t.cuda() for t in make_batch(3, 40, 8))
+    eps = torch.randn(1, 5, 40, 16, device="cuda")
+    torch.cuda.reset_peak_memory_stats()
+    with torch.no_grad():
+        b0, _ = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_importance_samples=5, eps=eps)
+    assert not b0.requires_grad and torch.isfinite(b0)
+    with pytest.raises(RuntimeError):            # training mode without masks is an error, not a silent no-dropout pass
+        dmv.estimate_iwelbo(dims, enc, dec, X, M, num_importance_samples=5, eps=eps)
+    plain_enc = G.packed_net(NetSpec(16, 32, 1, 64), make_params(enc_s, 1))
+    plain_dec = G.packed_net(NetSpec(16, 16, 1, 64), make_params(dec_s, 2))
+    b1, _ = dmv.estimate_iwelbo(dims, plain_enc, plain_dec, X, M, num_importance_samples=5, eps=eps)
+    torch.testing.assert_close(b0, b1.detach())   # inference with dropout networks = the same networks without dropout

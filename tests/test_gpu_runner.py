@@ -244,3 +244,23 @@ def test_two_rank_data_parallel_run_keeps_replicas_identical(workdir):
     assert summary["world"] == 2 and summary["replica_spread"] == 0.0
     assert [r["step"] for r in epochs] == [16, 32, 48]                  # 968 rows per rank, 64 per rank and step
     assert epochs[-1]["elbo/val"] > epochs[0]["elbo/val"]
+
+
+def test_stratified_mixture_config_with_dropout_replays(workdir):
+    """MissSIWAE (stratified mixture encoder, dropout in both networks: the miniboone configs' structure) and its refit
+    with the stratified refit class: recorded steps, dropout masks fresh on every replay, K-sample test estimate"""
+    text = IWAE_CONFIG.replace("logs/toy/iwae_i5", "logs/toy/miwae").replace("vgiwae.models.IWAE", "vgiwae.models.MultipleIWAE") \
+        .replace("    num_importance_samples: 5\n", "    num_importance_samples_for_each_component: 1\n") \
+        .replace("var_latent_distribution: normal_with_eps", "var_latent_distribution: stratified_mixture5_normal_with_eps") \
+        .replace("{input_dim: 10, output_dim: 4, num_residual_blocks: 1, residual_block_dim: 64}",
+                 "{input_dim: 10, output_dim: 25, num_residual_blocks: 1, residual_block_dim: 64, dropout_probability: 0.3}") \
+        .replace("{input_dim: 2, output_dim: 10, num_residual_blocks: 1, residual_block_dim: 64}",
+                 "{input_dim: 2, output_dim: 10, num_residual_blocks: 1, residual_block_dim: 64, dropout_probability: 0.3}") \
+        .replace("save_custom_epochs: [1]\n", "").replace("save_custom_steps: [5]\n", "").replace("max_epochs: 6", "max_epochs: 4")
+    assert "stratified_mixture5" in text and text.count("dropout_probability: 0.3") == 2
+    history, _, _ = launch(workdir, "miwae", text)
+    assert history[-1]["elbo/val"] > history[0]["elbo/val"]
+    refit = REFIT_CONFIG.replace("logs/toy/refit/iwae_i5", "logs/toy/refit/miwae").replace("logs/toy/iwae_i5", "logs/toy/miwae") \
+        .replace("refit_encoder_class: standard", "refit_encoder_class: stratified").replace("model_class: IWAE", "model_class: MultipleIWAE")
+    _, results, _ = launch(workdir, "refit_miwae", refit)
+    assert math.isfinite(results["est_loglik/test"])

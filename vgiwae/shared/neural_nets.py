@@ -86,7 +86,7 @@ class ResidualFCNetwork(nn.Module):
             raise RuntimeError("ResidualFCNetwork runs on the MI355X kernels only; move the model and inputs to cuda")
         net = self.packed_net()
         rows = inputs.numel() // self.input_dim
-        return dmv.ResidualMLPFunction.apply(net, self.keep_masks(rows), inputs, *net.params())
+        return dmv.ResidualMLPFunction.apply(net, torch.is_grad_enabled(), self.keep_masks(rows), inputs, *net.params())
 
 
 class FullyConnectedNetwork(nn.Module):
