@@ -121,7 +121,7 @@ def launch(workdir, name, text, *extra, recordable=True):
         assert summary["hip_graph_replays"] == 0
     elif recordable:      # every batch shape runs eagerly twice, then as a replay of its recording
         assert not any("not recordable" in str(l) for l in lines)
-        assert summary["hip_graph_replays"] >= summary["steps"] - 6, summary
+        assert summary["hip_graph_replays"] >= summary["steps"] - 8, summary      # (shape, imputing or not) kinds
     else:               # a step that synchronises with the host falls back to eager execution, loudly
         assert any("not recordable" in str(l) for l in lines) and summary["hip_graph_replays"] < summary["steps"]
     return history, results, lines
@@ -361,3 +361,61 @@ def test_image_config_with_convolutional_trunks(workdir):
     assert history[-1]["loss/train"] < history[0]["loss/train"]
     ckpts = os.listdir(workdir / "logs/mnist_bin/mvb2vae_pg/seed_m20220118_d20220118/lightning_logs/version_0/checkpoints")
     assert "last.ckpt" in ckpts and sum(c.startswith("epoch=") for c in ckpts) == 1
+
+
+def _variant(name, cls, extra, q="normal_with_eps", enc_out=4, sampler=None, epochs=3):
+    """a small config of another model family on the toy table, derived from the IWAE one"""
+    text = IWAE_CONFIG.replace("logs/toy/iwae_i5", f"logs/toy/{name}").replace("vgiwae.models.IWAE", f"vgiwae.models.{cls}") \
+        .replace("    num_importance_samples: 5\n", extra) \
+        .replace("var_latent_distribution: normal_with_eps", f"var_latent_distribution: {q}") \
+        .replace("{input_dim: 10, output_dim: 4,", "{input_dim: 10, output_dim: %d," % enc_out) \
+        .replace("save_custom_epochs: [1]\n", "").replace("save_custom_steps: [5]\n", "").replace("max_epochs: 6", f"max_epochs: {epochs}")
+    if sampler:
+        text = text.replace("    generator_network:\n", sampler + "    generator_network:\n", 1)
+    return text
+
+
+LAIR = """    mvb_objective: mvb2
+    mvb_eval_val_loss: True
+    mvb_delay_imputation: 1
+    mvb2_optim_gradclip_val: 1
+    mvb2_optim_gradclip_alg: norm
+    init_imputation_distribution: True
+    num_imputations_train: 5
+    num_imputations_val: 5
+    imputation_init_train: empirical
+    imputation_init_val: empirical
+    vae_sampler:
+      class_path: vgiwae.shared.vae_imputation.VAESampler_LAIR
+      init_args:
+        num_iterations: 4
+        num_imp_samples: 1
+        num_prior_replenish_proposals: 1
+        resample_final_imps: True
+        is_weights: dmis
+        resampling_scheme: global_resampling
+"""
+
+FAMILIES = {
+    # UCI DeMissVAE configs: LAIR with a prior-replenish proposal, several iterations, final resampling
+    "uci_demissvae": ("MVBVAE", "    kl_analytic: False\n", "normal_with_eps", 4, LAIR, "loss/val"),
+    "vae_analytic": ("VAE", "    kl_analytic: True\n", "normal_with_eps", 4, None, "elbo/val"),
+    "missvae_stratified": ("MultipleVAE", "", "stratified_mixture5_normal_with_eps", 25, None, "elbo/val"),
+    "reparam_iwae": ("IWAE", "    num_importance_samples: 5\n", "reparametrised_mixture5_normal_with_eps", 25, None, "elbo/val"),
+    "mvbiwae": ("MVBIWAE", "    num_importance_samples: 3\n    mvb_objective: mvb2_encallweighteddmmis_decall\n" + LAIR.split("    mvb2_optim")[0].replace("    mvb_objective: mvb2\n", "")
+                + LAIR[LAIR.index("    init_imputation"):], "normal_with_eps", 4, None, "loss/val"),
+}
+
+
+@pytest.mark.parametrize("family", sorted(FAMILIES))
+def test_other_model_families_through_the_runner(workdir, family):
+    cls, extra, q, enc_out, sampler, metric = FAMILIES[family]
+    text = _variant(family, cls, extra, q=q, enc_out=enc_out, sampler=sampler)
+    if family == "vae_analytic":
+        text = text.replace("    var_latent_STL: True\n", "    var_latent_STL: False\n")
+    if family == "uci_demissvae":
+        text = text.replace("    encoder_use_mis_mask: True\n", "").replace("{input_dim: 10, output_dim: 4,", "{input_dim: 5, output_dim: 4,")
+    history, _, _ = launch(workdir, family, text)
+    assert len(history) == 3 and all(math.isfinite(v) for row in history for v in row.values())
+    better = (lambda a, b: a < b) if metric.startswith("loss") else (lambda a, b: a > b)
+    assert better(history[-1][metric], history[0][metric]), [r[metric] for r in history]
