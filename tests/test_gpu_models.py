@@ -502,3 +502,36 @@ def test_posterior_divergences_match_reference(name):
     names = ("comp_fow", "comp_rev", "comp_jsd", "inc_fow", "inc_rev", "inc_jsd", "imp_fow", "imp_rev", "imp_jsd")
     for k, v in zip(names, out):
         torch.testing.assert_close(v.cpu(), torch.from_numpy(g[k]), rtol=2e-4, atol=2e-5, msg=k)
+
+
+def test_refit_test_step_with_torch_trunks_matches_the_streaming_estimator():
+    """RefitEncoderUsingIWAE.test_step for networks that are not residual MLPs (the image refit configs) against the
+    streaming estimator of the same networks: a stratified-mixture encoder sampled as a plain mixture, same noise and
+    component draws."""
+    from vgiwae.test.refit_encoder_using_iwae_and_estimate_loglik import RefitEncoderUsingIWAE, RefitEncoderClass
+    g = gu.load("loglik_stratified_K64")
+    spec, enc_p, dec_p = gu.model_case(g)
+    X, M = (t.cuda() for t in gu.batch_of(g))
+    K, B = int(g["K"]), int(g["B"])
+    eps, comp = torch.from_numpy(g["eps"]).cuda(), torch.from_numpy(g["comp_idx"]).cuda()
+
+    class Trunk(torch.nn.Module):                      # hides the residual MLP from the fused engine
+        def __init__(self, inner):
+            super().__init__()
+            self.inner, self.latent_dim, self.output_dim = inner, inner.input_dim, inner.output_dim
+
+        def forward(self, x):
+            return self.inner(x)
+    values = []
+    for wrap in (False, True):
+        model = _build("MultipleIWAE", spec, enc_p, dec_p, num_latent_samples=1, num_importance_samples_for_each_component=1,
+                       var_latent_STL=True).eval()
+        if wrap:
+            model.generator_network, model.var_latent_network = Trunk(model.generator_network), Trunk(model.var_latent_network)
+            assert not model.fused
+        refit = RefitEncoderUsingIWAE(RefitEncoderClass.stratified, var_latent_STL=True, num_test_importance_samples=K)
+        refit.set_model(model)
+        with torch.no_grad():
+            values.append(float(refit.test_step((X, M), 0, eps=eps, comp_idx=comp)))
+    np.testing.assert_allclose(values[0], float(g["est_loglik"]), atol=1e-4)
+    np.testing.assert_allclose(values[1], values[0], rtol=1e-5)

@@ -361,6 +361,14 @@ def test_image_config_with_convolutional_trunks(workdir):
     assert history[-1]["loss/train"] < history[0]["loss/train"]
     ckpts = os.listdir(workdir / "logs/mnist_bin/mvb2vae_pg/seed_m20220118_d20220118/lightning_logs/version_0/checkpoints")
     assert "last.ckpt" in ckpts and sum(c.startswith("epoch=") for c in ckpts) == 1
+    # refit the convolutional encoder and estimate the test log-likelihood (the image refit configs: 5 x 1000 samples)
+    refit = REFIT_CONFIG.replace("logs/toy/refit/iwae_i5", "logs/mnist_bin/refit").replace("logs/toy/iwae_i5", "logs/mnist_bin/mvb2vae_pg") \
+        .replace("dataset: toy_mog2_large", "dataset: mnist_bin\n  img_dims: [ 28, 28 ]").replace("missingness: 'uniform'", "missingness: quadrants") \
+        .replace("batch_size: 128", "batch_size: 32").replace("test_batch_size: 50", "test_batch_size: 5") \
+        .replace("num_importance_samples: 50\n", "num_importance_samples: 10\n").replace("num_test_importance_samples: 4096", "num_test_importance_samples: 200") \
+        .replace("model_class: IWAE", "model_class: MVBVAE_FID").replace("max_steps: 30", "max_steps: 6")
+    _, results, _ = launch(workdir, "mnist_refit", refit, recordable=None)
+    assert math.isfinite(results["est_loglik/test"]) and results["est_loglik/test"] < 0
 
 
 def _variant(name, cls, extra, q="normal_with_eps", enc_out=4, sampler=None, epochs=3):

@@ -64,11 +64,17 @@ def estimate_iwelbo(model, batch, var_latent_STL: bool = False, var_latent_DREG:
     dims, enc, dec = m.engine()
     streaming = sample_stratifieddistr_without_stratification_norsample or \
         (not torch.is_grad_enabled() and num_latent_samples == 1 and num_importance_samples >= 1024)
-    if streaming:
-        assert num_latent_samples == 1 and m.fused, "the streaming estimator runs the packed residual MLPs"
+    if streaming and m.fused:
+        assert num_latent_samples == 1, "the streaming estimator takes one outer sample"
         val, _ = estimate_loglik(dims, enc, dec, X, M, num_importance_samples=num_importance_samples, eps=eps,
                                  comp_idx=comp_idx)
         return val
+    if sample_stratifieddistr_without_stratification_norsample and dims.q_is_mixture:
+        # convolutional trunks (caller-network engine, all samples in one pass): a stratified mixture sampled as a
+        # plain mixture is the ancestrally sampled family with the same parameter layout
+        assert not torch.is_grad_enabled()
+        import dataclasses
+        dims = dataclasses.replace(dims, q_dist=dims.q_dist.replace("stratified", "reparam"))
     fn, fused = m.estimator("estimate_iwelbo")
     kw = {}
     if fused:
