@@ -173,6 +173,8 @@ class _StepRunner:
         key = [tuple(batch[0].shape)]
         if getattr(m, "train_imp_distribution", None) is not None:      # imputations start after a delay
             key.append(m.current_epoch >= h.mvb_delay_imputation)
+        if hasattr(m, "_log_due") and m._log_due():      # epochs on which mixture logits are copied to the host
+            return None
         if h.get("marginal_eval_train"):
             key.append(m.current_epoch % h.marginal_eval_freq == 0 or m.current_epoch == (m.trainer.max_epochs or 0) - 1)
         return tuple(key)
@@ -227,6 +229,8 @@ class _StepRunner:
         if not self.model.automatic_optimization:
             self.model._schedulers = _DeferredScheduler()
         key = self._key(batch)
+        if key is None:
+            return self._eager(batch)
         n = self.seen.get(key, 0)
         self.seen[key] = n + 1
         if n < 2 or key in self.eager_keys:         # lazily created state (optimiser, workspaces) must exist first
@@ -293,7 +297,19 @@ class Checkpointer:
         self._save("last.ckpt", epoch=epochs, global_step=step)
 
 
-def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None):
+class _RunLogger:
+    """the slice of Lightning's logger the models touch: the directory of this run (imputation / mixture-weight dumps)"""
+
+    def __init__(self, log_dir):
+        self.log_dir = log_dir
+        self.experiment = self
+
+    def get_logdir(self):
+        os.makedirs(self.log_dir, exist_ok=True)
+        return self.log_dir
+
+
+def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None, log_dir=None):
     from . import rng
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1))
     max_epochs = trainer_cfg.get("max_epochs")
@@ -305,6 +321,8 @@ def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None):
     trainer = types.SimpleNamespace(max_epochs=max_epochs, max_steps=max_steps, datamodule=datamodule, global_step=0,
                                     num_training_batches=len(train_loader), accumulate_grad_batches=1)
     model.trainer = trainer
+    if log_dir is not None and getattr(model, "logger", None) is None:
+        model.logger = _RunLogger(log_dir)
     model.set_datamodule(datamodule)
     model.to(dev)
     rng.set_seed(torch.initial_seed() + P.rank())
@@ -502,7 +520,7 @@ def main(argv=None, log=print):
         ckpt = Checkpointer(os.path.join(out, "checkpoints"), model, model_config,
                             keep_best=bool(cfg.get("add_checkpoint_callback", False)),
                             epochs=cfg.get("save_custom_epochs"), steps=cfg.get("save_custom_steps"))
-    history = fit(model, datamodule, trainer_cfg, log=log, checkpointer=ckpt)
+    history = fit(model, datamodule, trainer_cfg, log=log, checkpointer=ckpt, log_dir=out)
     results = {}
     if refit and cfg.get("run_test", True):
         log("Estimating test-log-likelihood.")

@@ -186,6 +186,7 @@ model:
     imputation_init_train: empirical
     imputation_init_val: empirical
     init_imputation_distribution: True
+    save_imputations: True
     latent_grid_steps: 50
     compute_complete_var_distribution_kl: True
     vae_sampler:

@@ -109,7 +109,8 @@ def workdir(tmp_path_factory):
     return root
 
 
-def launch(workdir, name, text, *extra, recordable=True):
+def launch(workdir, name, text, *extra, recordable=True, min_replays=lambda steps: steps - 8):
+    """min_replays: every (batch shape, imputing or not) kind of step runs eagerly twice before it is recorded"""
     from demiss_vae_amd import run
     path = workdir / f"{name}.yaml"
     path.write_text(text.replace("ROOT", str(workdir)))
@@ -121,7 +122,7 @@ def launch(workdir, name, text, *extra, recordable=True):
         assert summary["hip_graph_replays"] == 0
     elif recordable:      # every batch shape runs eagerly twice, then as a replay of its recording
         assert not any("not recordable" in str(l) for l in lines)
-        assert summary["hip_graph_replays"] >= summary["steps"] - 8, summary      # (shape, imputing or not) kinds
+        assert summary["hip_graph_replays"] >= min_replays(summary["steps"]), summary
     else:               # a step that synchronises with the host falls back to eager execution, loudly
         assert any("not recordable" in str(l) for l in lines) and summary["hip_graph_replays"] < summary["steps"]
     return history, results, lines
@@ -141,6 +142,8 @@ def test_demissvae_config_trains(workdir):
     ck = torch.load(out / "checkpoints" / "last.ckpt", weights_only=True)
     assert ck["epoch"] == 2 and any(k.startswith("generator_network.") for k in ck["state_dict"])
     assert [json.loads(l)["epoch"] for l in (out / "metrics.jsonl").read_text().splitlines()] == [0, 1]
+    imps = np.load(out / "imputations" / "train_imputations_last.npz")                     # save_imputations: True
+    assert imps["data_imps"].shape == (1936 * 5, 5) and int(imps["num_imputations"]) == 5
 
 
 def test_control_study_config_with_oracle_imputations(workdir):
@@ -260,8 +263,13 @@ def test_stratified_mixture_config_with_dropout_replays(workdir):
                  "{input_dim: 2, output_dim: 10, num_residual_blocks: 1, residual_block_dim: 64, dropout_probability: 0.3}") \
         .replace("save_custom_epochs: [1]\n", "").replace("save_custom_steps: [5]\n", "").replace("max_epochs: 6", "max_epochs: 4")
     assert "stratified_mixture5" in text and text.count("dropout_probability: 0.3") == 2
-    history, _, _ = launch(workdir, "miwae", text)
+    text = text.replace("    num_importance_samples_for_each_component: 1\n",
+                        "    num_importance_samples_for_each_component: 1\n"
+                        "    log_var_distribution_mixture_component_weights_epoch_frequency: 2\n")
+    history, _, _ = launch(workdir, "miwae", text, min_replays=lambda steps: steps // 2 - 8)   # epochs 1 and 3 replay
     assert history[-1]["elbo/val"] > history[0]["elbo/val"]
+    dump = np.load(workdir / "logs/toy/miwae/seed_m20220118_d20220118/lightning_logs/version_0/mixture_var_weight_logits.npz")
+    assert dump["mixture_weight_logits"].shape[0] == 2 and dump["mixture_weight_logits"].shape[-1] == 5    # epochs 0 and 2
     refit = REFIT_CONFIG.replace("logs/toy/refit/iwae_i5", "logs/toy/refit/miwae").replace("logs/toy/iwae_i5", "logs/toy/miwae") \
         .replace("refit_encoder_class: standard", "refit_encoder_class: stratified").replace("model_class: IWAE", "model_class: MultipleIWAE")
     _, results, _ = launch(workdir, "refit_miwae", refit)

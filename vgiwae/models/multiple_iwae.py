@@ -87,4 +87,10 @@ def estimate_multiple_iwelbo(model, batch, var_latent_STL: bool = False, var_lat
         kw["enc_keep"], kw["dec_keep"] = m.dropout_masks(X.shape[0], num_latent_samples * I * X.shape[0] * dims.C)
     bound, _ = fn(dims, enc, dec, X, M, num_latent_samples=num_latent_samples, num_importance_samples_for_each_component=I,
                   STL=var_latent_STL, looser=use_looser_bound, eps=eps, **kw)
+    if model.training and getattr(model, "_log_due", lambda: False)() and hasattr(model, "mixture_weight_logits_epoch"):
+        # diagnostic dump of the (normalised) mixture logits on logging epochs (multiple_iwae.py:220-226); the pipeline
+        # keeps the encoder output to itself, so this is one more encoder pass without gradients
+        with torch.no_grad():
+            p = m.predict_var_latent_params(X * M, M)
+            model.mixture_weight_logits_epoch.append(torch.log_softmax(p[..., -dims.C:], dim=-1).cpu().numpy())
     return bound
