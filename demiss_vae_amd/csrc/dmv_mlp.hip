@@ -1026,6 +1026,319 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_coop(BwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// 16-row tiles for the smallest batches (at most one round of 256 workgroups)
+// ------------------------------------------------------------------------------------------
+// The four-wave kernels above are bound by one wave's MFMA issue: 32 rows x Hp outputs x Hp inputs per layer
+// over four SIMDs.  While the batch does not fill the chip anyway, halving the rows per workgroup halves
+// that chain: v_mfma_f32_16x16x4_f32 (8 passes), weights as the A operand (lane (o, g = lane>>4): output o,
+// inputs 4 g + i), activations as the B operand (lane (m, g): row m).  The accumulator (lane (m, g), register i
+// <-> output 16 t + 4 g + i) is again the B operand of the next layer when the inputs are visited in the order
+// 16 t + 4 g + i (tile t, step i), and the A operand of (output tile ot, input tile t) is a quarter of two
+// consecutive fragments of the same packed image the 32-row kernels read: lane (o, g) takes the 16 bytes of
+// lane slot 32 (g & 1) + 16 (ot & 1) + o in fragment 2 t + (g >> 1) of tile ot >> 1.  Saved activations and
+// sign-bit words keep the layout of the other kernel families, which therefore mix freely with these.
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+static inline bool dmv_use_rows16(int64_t rows) { return (rows + 15) / 16 <= 256; }
+
+template <int NT>
+struct Rows16 {
+  static constexpr int NK = 2 * NT;                 // 16-wide tiles of the hidden width
+  static constexpr int TW = 2 * ((NT + 3) / 4);     // output tiles per wave (whole 32-wide tiles: sign-bit halfwords)
+  static constexpr int LDS_BYTES = NK * 1024;
+};
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// byte offset of this lane's 16 bytes inside the fragment pair of (output tile parity 0, input tile 0)
+__device__ __forceinline__ uint32_t r16_lane_off(int lane) {
+  const int m = lane & 15, g = lane >> 4;
+  return (uint32_t)((g >> 1) * 1024 + ((g & 1) * 32 + m) * 16);
+}
+
+// scalar offset of output tile ot (16 wide) in an image with S groups per 32-wide tile
+__device__ __forceinline__ uint32_t r16_tile_off(int ot, int S) {
+  return (uint32_t)(ot >> 1) * (uint32_t)S * 1024u + (uint32_t)(ot & 1) * 256u;
+}
+
+// bias of output tile ot as an A operand: lanes g = 0 carry bias[16 ot + o], the others zero
+__device__ __forceinline__ float r16_bias(__amdgpu_buffer_rsrc_t bimg, int lane, int ot) {
+  const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+      bimg, (uint32_t)(lane & 15) * 4u, (uint32_t)(ot >> 1) * 256u + (uint32_t)(ot & 1) * 64u, 0));
+  return lane < 16 ? v : 0.f;
+}
+
+// acc[i] (+)= W[tile t0 + i] in over the 32 NT hidden inputs; fragments two input tiles ahead
+template <int NT, bool FRESH, bool BIAS>
+__device__ __forceinline__ void r16_gemm(const f32x4* __restrict__ Wimg, const float* __restrict__ Bimg, int lane, int t0,
+                                         const f32x4 (&in)[Rows16<NT>::NK], f32x4 (&acc)[Rows16<NT>::TW]) {
+  constexpr int S = 4 * NT, TW = Rows16<NT>::TW, NK = Rows16<NT>::NK;
+  const uint32_t lo = r16_lane_off(lane);
+  const __amdgpu_buffer_rsrc_t img = make_rsrc(Wimg, NT * S * 1024u);
+  uint32_t base[TW];
+#pragma unroll
+  for (int i = 0; i < TW; ++i) base[i] = r16_tile_off(t0 + i, S);   // tiles past NK fall outside the resource: zeros
+  f32x4 w[3][TW];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int i = 0; i < TW; ++i) w[p][i] = (p < NK) ? buf_load4(img, lo, base[i] + (uint32_t)p * 2048u) : zero4();
+  if (BIAS) {
+    const __amdgpu_buffer_rsrc_t bimg = make_rsrc(Bimg, NT * 256u);
+#pragma unroll
+    for (int i = 0; i < TW; ++i) acc[i] = MFMA16(r16_bias(bimg, lane, t0 + i), 1.f, FRESH ? zero4() : acc[i]);
+  }
+#pragma unroll
+  for (int t = 0; t < NK; ++t) {
+    if (t + 2 < NK) {
+#pragma unroll
+      for (int i = 0; i < TW; ++i) w[(t + 2) % 3][i] = buf_load4(img, lo, base[i] + (uint32_t)(t + 2) * 2048u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float b = in[t][e];
+#pragma unroll
+      for (int i = 0; i < TW; ++i)
+        acc[i] = MFMA16(w[t % 3][i][e], b, (FRESH && !BIAS && t == 0 && e == 0) ? zero4() : acc[i]);
+    }
+  }
+}
+
+// one output tile (fragment offset `toff`) from all hidden inputs, single accumulator
+template <int NT>
+__device__ __forceinline__ f32x4 r16_gemm1(__amdgpu_buffer_rsrc_t img, uint32_t toff, int lane, const f32x4 (&in)[Rows16<NT>::NK],
+                                           f32x4 acc) {
+  constexpr int NK = Rows16<NT>::NK;
+  const uint32_t lo = r16_lane_off(lane);
+  f32x4 w[NK];
+#pragma unroll
+  for (int t = 0; t < NK; ++t) w[t] = buf_load4(img, lo, toff + (uint32_t)t * 2048u);
+#pragma unroll
+  for (int t = 0; t < NK; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = MFMA16(w[t][e], in[t][e], acc);
+  return acc;
+}
+
+// all-gather of the waves' output slices through LDS
+template <int NT>
+__device__ __forceinline__ void r16_exchange(float* lds, int lane, int t0, const f32x4 (&slice)[Rows16<NT>::TW],
+                                             f32x4 (&full)[Rows16<NT>::NK]) {
+  constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK;
+  f32x4* L4 = (f32x4*)lds;
+  __syncthreads();                                   // previous readers are done with the buffer
+#pragma unroll
+  for (int i = 0; i < TW; ++i)
+    if (t0 + i < NK) L4[(t0 + i) * 64 + lane] = slice[i];
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NK; ++t) full[t] = L4[t * 64 + lane];
+}
+
+template <int NT>
+__device__ __forceinline__ void r16_own_slice(const f32x4 (&full)[Rows16<NT>::NK], int wv, f32x4 (&slice)[Rows16<NT>::TW]) {
+  constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK;
+#pragma unroll
+  for (int ww = 0; ww < 4; ++ww)
+    if (ww == wv) {
+#pragma unroll
+      for (int i = 0; i < TW; ++i) slice[i] = full[ww * TW + i < NK ? ww * TW + i : NK - 1];   // past NK: never stored
+    }
+}
+
+// relu on a slice; with SAVE also its columns of the saved activation and its sign bits.  Halfword t of a
+// (row, h) mask line holds bit 4 q + e for feature 32 t + 8 q + 4 h + e: this lane owns q = 2 (ot & 1) + (g >> 1)
+// of line h = g & 1, the lane 32 further the other q of the same line.
+template <int NT, bool SAVE>
+__device__ __forceinline__ void r16_relu_save(f32x4 (&slice)[Rows16<NT>::TW], int lane, int t0, float* act_row, uint32_t* mask_line) {
+  constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK;
+  const int g = lane >> 4;
+#pragma unroll
+  for (int p = 0; p < TW / 2; ++p) {
+    uint32_t part = 0u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = 2 * p + j;
+      uint32_t nib = 0u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        slice[i][e] = __builtin_amdgcn_fmed3f(slice[i][e], 0.f, __builtin_inff());
+        nib |= (slice[i][e] > 0.f ? 1u : 0u) << e;
+      }
+      part |= nib << (8 * j + 4 * (g >> 1));
+      if (SAVE && t0 + i < NK) *(f32x4*)(act_row + 16 * (t0 + i)) = slice[i];
+    }
+    if (SAVE) {
+      part |= (uint32_t)__shfl_xor((int)part, 32);
+      if (g < 2 && t0 + 2 * p < NK) ((uint16_t*)mask_line)[(t0 >> 1) + p] = (uint16_t)part;
+    }
+  }
+}
+
+template <int NT, bool SAVE>
+__global__ __launch_bounds__(256, 1) void k_mlp_fwd_rows16(FwdArgs a) {
+  constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK, Hp = 32 * NT, MW = mask_words(NT);
+  __shared__ __attribute__((aligned(16))) float lds[Rows16<NT>::LDS_BYTES / 4];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t0 = wv * TW;
+  const int m = lane & 15, g = lane >> 4;
+  const int64_t row = (int64_t)blockIdx.x * 16 + m;
+  const bool live = row < a.rows;
+  const int64_t rl = live ? row : a.rows - 1;
+  const int64_t rp = (a.rows + 31) & ~(int64_t)31;
+  const int64_t act_stride = rp * Hp, mask_stride = rp * 2 * MW;
+  float* act_row = SAVE ? a.acts + row * Hp + 4 * g : nullptr;                    // layer 0; + l * act_stride
+  uint32_t* mask_line = SAVE ? a.masks + (row * 2 + (g & 1)) * MW : nullptr;      // layer 0; + l * mask_stride
+  const uint32_t lo = r16_lane_off(lane);
+
+  f32x4 A[NK], T[NK], acc[TW];
+
+  // ---- initial layer: this wave's output tiles from the network input
+  {
+    const int S = a.L.S_in;
+    const __amdgpu_buffer_rsrc_t img = make_rsrc(a.packed + a.L.w[0], (uint32_t)(NT * S) * 1024u);
+    const __amdgpu_buffer_rsrc_t bimg = make_rsrc(a.packed + a.L.b[0], NT * 256u);
+    uint32_t base[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+      base[i] = r16_tile_off(t0 + i, S);
+      acc[i] = MFMA16(r16_bias(bimg, lane, t0 + i), 1.f, zero4());
+    }
+    float* xs_row = SAVE ? a.xs + row * (32 * a.L.T_in) + 4 * g : nullptr;
+    for (int t = 0; 2 * t < S; ++t) {
+      const bool in_image = 2 * t + (g >> 1) < S;      // an odd group count leaves the last half tile empty
+      const f32x4 b = first_layer_input4(a, rl, 16 * t + 4 * g);
+      if (SAVE && wv == 0 && in_image) *(f32x4*)(xs_row + 16 * t) = b;
+      f32x4 w[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) {
+        w[i] = buf_load4(img, lo, base[i] + (uint32_t)t * 2048u);
+        if (!in_image) w[i] = zero4();
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TW; ++i) acc[i] = MFMA16(w[i][e], b[e], acc[i]);
+    }
+  }
+  r16_relu_save<NT, SAVE>(acc, lane, t0, act_row, mask_line);
+  r16_exchange<NT>(lds, lane, t0, acc, A);
+
+  // ---- residual blocks
+  for (int blk = 0; blk < a.nb; ++blk) {
+    const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
+    r16_gemm<NT, true, true>((const f32x4*)(a.packed + a.L.w[l1]), a.packed + a.L.b[l1], lane, t0, A, acc);
+    r16_relu_save<NT, SAVE>(acc, lane, t0, act_row + l1 * act_stride, mask_line + l1 * mask_stride);
+    r16_exchange<NT>(lds, lane, t0, acc, T);
+    r16_own_slice<NT>(A, wv, acc);                     // the residual stream is the accumulator of the second GEMM
+    r16_gemm<NT, false, true>((const f32x4*)(a.packed + a.L.w[l2]), a.packed + a.L.b[l2], lane, t0, T, acc);
+    r16_relu_save<NT, SAVE>(acc, lane, t0, act_row + l2 * act_stride, mask_line + l2 * mask_stride);
+    r16_exchange<NT>(lds, lane, t0, acc, A);
+  }
+
+  // ---- final layer: output tiles round-robin over the waves
+  {
+    const int lf = a.L.nl - 1;
+    constexpr int S = 4 * NT;
+    const __amdgpu_buffer_rsrc_t img = make_rsrc(a.packed + a.L.w[lf], (uint32_t)(a.L.OT * S) * 1024u);
+    const __amdgpu_buffer_rsrc_t bimg = make_rsrc(a.packed + a.L.b[lf], (uint32_t)a.L.OT * 256u);
+    for (int ot = wv; ot < 2 * a.L.OT; ot += 4) {
+      const f32x4 o = r16_gemm1<NT>(img, r16_tile_off(ot, S), lane, A, MFMA16(r16_bias(bimg, lane, ot), 1.f, zero4()));
+      if (live) *(f32x4*)(a.y + row * a.ldy + 16 * ot + 4 * g) = o;
+    }
+  }
+}
+
+// relu backward on a slice (sign bits of that layer's saved activation), then its columns of the layer-gradient buffer
+template <int NT>
+__device__ __forceinline__ void r16_mask_store(f32x4 (&slice)[Rows16<NT>::TW], int lane, int t0, const uint32_t* mask_line,
+                                               float scale, float* dact_row) {
+  constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK;
+  const int g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < TW; ++i) {
+    // register work is unconditional (tiles past NK hold zeros and are never stored): only the store is predicated
+    const int t32 = (t0 + i) >> 1;
+    const uint32_t half = ((const uint16_t*)mask_line)[t32 < NT ? t32 : NT - 1];
+    const uint32_t nib = half >> (8 * (i & 1) + 4 * (g >> 1));        // t0 is even: parity of the tile = parity of i
+#pragma unroll
+    for (int e = 0; e < 4; ++e) slice[i][e] = ((nib >> e) & 1u) ? slice[i][e] * scale : 0.f;
+    if (t0 + i < NK) *(f32x4*)(dact_row + 16 * (t0 + i)) = slice[i];
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k_mlp_bwd_rows16(BwdArgs a) {
+  constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK, Hp = 32 * NT, MW = mask_words(NT);
+  __shared__ __attribute__((aligned(16))) float lds[Rows16<NT>::LDS_BYTES / 4];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t0 = wv * TW;
+  const int m = lane & 15, g = lane >> 4;
+  const int64_t row = (int64_t)blockIdx.x * 16 + m;
+  const bool live = row < a.rows;
+  const int64_t rl = live ? row : a.rows - 1;
+  const int64_t rp = (a.rows + 31) & ~(int64_t)31;
+  const int64_t act_stride = rp * Hp, mask_stride = rp * 2 * MW;
+  const int lf = a.L.nl - 1;
+  float* dact_row = a.dacts + row * Hp + 4 * g;
+  const uint32_t* mask_line = a.masks + (row * 2 + (g & 1)) * MW;
+  const float dscale = a.drop_keep ? a.drop_scale : 1.f;
+  const uint32_t lo = r16_lane_off(lane);
+
+  f32x4 dA[NK], dT[NK], acc[TW];
+  // ---- this wave's tiles of Wf^T gy
+  {
+    const int S = a.L.S_out;
+    const __amdgpu_buffer_rsrc_t img = make_rsrc(a.packed + a.L.wt[lf], (uint32_t)(NT * S) * 1024u);
+    const float* gyr = a.gy + rl * a.ldgy + 4 * g;
+    uint32_t base[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) { base[i] = r16_tile_off(t0 + i, S); acc[i] = zero4(); }
+    for (int t = 0; 2 * t < S; ++t) {
+      const bool in_image = 2 * t + (g >> 1) < S;
+      // gy rows are pitched to a multiple of 32 columns, so the half tile past an odd group count is readable
+      f32x4 b = *(const f32x4*)(gyr + 16 * t);
+      if (!live || !in_image) b = zero4();
+      f32x4 w[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) {
+        w[i] = buf_load4(img, lo, base[i] + (uint32_t)t * 2048u);
+        if (!in_image) w[i] = zero4();
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TW; ++i) acc[i] = MFMA16(w[i][e], b[e], acc[i]);
+    }
+  }
+  r16_mask_store<NT>(acc, lane, t0, mask_line + (lf - 1) * mask_stride, 1.f, dact_row + (lf - 1) * act_stride);
+  r16_exchange<NT>(lds, lane, t0, acc, dA);
+
+  for (int blk = a.nb - 1; blk >= 0; --blk) {
+    const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
+    r16_gemm<NT, true, false>((const f32x4*)(a.packed + a.L.wt[l2]), nullptr, lane, t0, dA, acc);
+    r16_mask_store<NT>(acc, lane, t0, mask_line + l1 * mask_stride, dscale, dact_row + l1 * act_stride);
+    r16_exchange<NT>(lds, lane, t0, acc, dT);
+    r16_own_slice<NT>(dA, wv, acc);                                         // skip path
+    r16_gemm<NT, false, false>((const f32x4*)(a.packed + a.L.wt[l1]), nullptr, lane, t0, dT, acc);
+    r16_mask_store<NT>(acc, lane, t0, mask_line + (l1 - 1) * mask_stride, 1.f, dact_row + (l1 - 1) * act_stride);
+    r16_exchange<NT>(lds, lane, t0, acc, dA);
+  }
+
+  if (a.dx) {
+    constexpr int S = 4 * NT;
+    const __amdgpu_buffer_rsrc_t img = make_rsrc(a.packed + a.L.wt[0], (uint32_t)(a.L.T_in * S) * 1024u);
+    for (int it = wv; it < 2 * a.L.T_in; it += 4) {
+      const f32x4 o = r16_gemm1<NT>(img, r16_tile_off(it, S), lane, dA, zero4());
+      if (live) *(f32x4*)(a.dx + row * a.lddx + 16 * it + 4 * g) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // weight gradients: dW_l[n][k] = sum_r dY_l[r][n] X_l[r][k], db_l[n] = sum_r dY_l[r][n]
 // One wave = a block of up to 4x4 32x32 tiles of one layer over one slice of the rows; operands go
 // straight from row-major global memory into MFMA registers (lane = feature, reduction over rows).
@@ -1261,6 +1574,14 @@ template <int NT>
 static int launch_fwd(const FwdArgs& a, hipStream_t st) {
   const int64_t waves = (a.rows + 31) / 32;
   const unsigned grid = (unsigned)((waves + 3) / 4);
+  // smallest batches: four waves per 16-row tile (relu, no dropout)
+  if (a.act == DMV_ACT_RELU && !a.drop_keep && dmv_use_rows16(a.rows)) {
+    const unsigned tiles = (unsigned)((a.rows + 15) / 16);
+    if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true>), dim3(tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false>), dim3(tiles), dim3(256), 0, st, a);
+    DMV_HIP_CHECK_LAUNCH();
+    return DMV_OK;
+  }
   // small batches: four waves per 32-row tile (relu, no dropout)
   if (a.act == DMV_ACT_RELU && !a.drop_keep && dmv_use_coop(waves)) {
     if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_coop<NT, true>), dim3((unsigned)waves), dim3(256), 0, st, a);
@@ -1290,7 +1611,9 @@ template <int NT>
 static int launch_bwd(const BwdArgs& a, hipStream_t st) {
   const int64_t waves = (a.rows + 31) / 32;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  if (a.act == DMV_ACT_RELU && dmv_use_coop(waves))
+  if (a.act == DMV_ACT_RELU && dmv_use_rows16(a.rows))
+    hipLaunchKernelGGL((k_mlp_bwd_rows16<NT>), dim3((unsigned)((a.rows + 15) / 16)), dim3(256), 0, st, a);
+  else if (a.act == DMV_ACT_RELU && dmv_use_coop(waves))
     hipLaunchKernelGGL((k_mlp_bwd_coop<NT>), dim3((unsigned)waves), dim3(256), 0, st, a);
   else if (a.act == DMV_ACT_RELU)
     hipLaunchKernelGGL((k_mlp_bwd<NT, true>), dim3(grid), dim3(256), 0, st, a);

@@ -99,6 +99,46 @@ def test_small_batch_and_large_batch_kernels_agree_bitwise():
             torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * float(a.abs().max()))
 
 
+@pytest.mark.parametrize("hidden", [32, 64, 100, 128, 160, 192, 224, 256])
+@pytest.mark.parametrize("rows", [45, 1024])
+def test_sixteen_row_kernels_all_widths(hidden, rows):
+    """Batches of at most 4096 rows run on 16-row tiles (another MFMA shape, another summation order, quarter
+    fragments of the same packed images).  Every hidden tile count, odd fragment-group counts of the input and the
+    output width (20 -> 3 groups, 40 -> 5), ragged row counts: against the float64 oracle, and against the same rows
+    inside a batch large enough for the 32-row kernels."""
+    import demiss_vae_amd as dmv
+    import gpu_util as G
+    spec = NetSpec(20, 40, 2, hidden)
+    params = make_params(spec, 5)
+    x_cpu, gy_cpu = make_noise(6, rows, 20), make_noise(7, rows, 40)
+
+    def run(x_in, gy_in):
+        net = G.packed_net(spec, params)
+        x = x_in.cuda().requires_grad_(True)
+        y = dmv.ResidualMLPFunction.apply(net, True, None, x, *net.params())
+        y.backward(gy_in.cuda())
+        return y.detach().cpu(), x.grad.cpu(), G.grads_of(net, spec)
+
+    y, dx, got = run(x_cpu, gy_cpu)
+    p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    x64 = x_cpu.double().requires_grad_(True)
+    y64 = core.mlp_forward(p64, x64, spec)
+    y64.backward(gy_cpu.double())
+    torch.testing.assert_close(y.double(), y64.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dx.double(), x64.grad, rtol=1e-4, atol=1e-5)
+    for k, v in p64.items():
+        tol = 2e-5 * float(v.grad.abs().max()) + 1e-6
+        torch.testing.assert_close(got[k].cpu().double(), v.grad, rtol=1e-4, atol=tol, msg=lambda m: f"{k}: {m}")
+    # the same rows at the head of a 6000-row batch (32-row tiles); the padding rows carry no output gradient
+    pad = 6000 - rows
+    yb, dxb, gotb = run(torch.cat([x_cpu, make_noise(8, pad, 20)]), torch.cat([gy_cpu, torch.zeros(pad, 40)]))
+    torch.testing.assert_close(y, yb[:rows], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dx, dxb[:rows], rtol=1e-4, atol=1e-5)
+    for k in got:
+        tol = 2e-5 * float(gotb[k].abs().max()) + 1e-6
+        torch.testing.assert_close(got[k].cpu(), gotb[k].cpu(), rtol=1e-4, atol=tol, msg=lambda m: f"{k}: {m}")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fused", [False, True])
 def test_packed_weights_follow_optimizer_steps(fused):
