@@ -465,6 +465,31 @@ def inverse_cdf_categorical(log_w, u):
     return idx.clamp(max=log_w.shape[-1] - 1)
 
 
+def independent_resampling_gather(gen_params, idx):
+    """Proposal selection of the independent-resampling scheme (vgiwae/shared/vae_imputation.py:565-573, used by
+    ir_resampling :273-295; no shipped config selects it, restated for the reference's known-answer tests :801-854).
+    gen_params [I, B, K, P]; the I K proposals of a datapoint, flattened i-major, are cut into K consecutive groups
+    of I and idx [B, K] picks one member of each group -> [B, K, P]."""
+    I, B, K, P = gen_params.shape
+    flat = gen_params.permute(1, 0, 2, 3).reshape(B, I * K, P)          # j = i K + k
+    j = torch.arange(K)[None, :] * I + idx                              # group k2 holds j = k2 I .. k2 I + I - 1
+    return flat[torch.arange(B)[:, None], j]
+
+
+def systematic_sample(log_w, u, num_dependent=None):
+    """Systematic resampling (vgiwae/shared/vae_imputation.py:698-728; selectable as resampling_method, unused by the
+    shipped configs; restated for the known-answer test :856-876).  log_w [..., n]; u [..., 1] uniform in [0, 1);
+    returns [..., num_dependent] indices: sample m is the number of categories whose scaled cumulative
+    probability num_dependent * cdf_j + u lies below m + 1."""
+    n = log_w.shape[-1]
+    nd = n if num_dependent is None else num_dependent
+    p = torch.exp(log_w - torch.logsumexp(log_w, dim=-1, keepdim=True))
+    p = p / p.sum(dim=-1, keepdim=True)
+    level = torch.floor(p.cumsum(-1) * nd + u).clamp(min=0, max=nd)     # [..., n]
+    m = torch.arange(nd, dtype=level.dtype)
+    return (level.unsqueeze(-1) <= m).sum(dim=-2)
+
+
 # --------------------------------------------------------------------------------------
 # Imputation buffer (vgiwae/utils/imputation_distribution.py:77-79, 139-187)
 # --------------------------------------------------------------------------------------

@@ -337,3 +337,32 @@ def test_posterior_divergences(name):
     for k, v in zip(DIV_NAMES, out):
         torch.testing.assert_close(v, torch.from_numpy(g[k]), rtol=1e-4, atol=1e-5, msg=k)
     assert all((v > -1e-4).all() for v in out)                      # divergences
+
+
+# ------------------------------------------------------------------------------------- resampling helpers
+def test_resampling_helpers_known_answers():
+    """The reference's self-checks of its resampling helpers (vgiwae/shared/vae_imputation.py:799-876), against the
+    reference's outputs and restated as properties: the gather of independent resampling for I == K and I == 2K,
+    systematic sampling (exact indices for injected offsets, and the histogram property of :856-876)."""
+    g = gu.load("resampling_helpers")
+    for tag in ("ik", "i2k"):
+        G, idx = torch.from_numpy(g[f"gather_{tag}_params"]), torch.from_numpy(g[f"gather_{tag}_idx"])
+        out = core.independent_resampling_gather(G, idx)
+        assert torch.equal(out, torch.from_numpy(g[f"gather_{tag}_out"]))
+        I, B, K, _ = G.shape
+        for b in range(B):
+            for k in range(K):
+                j = int(idx[b, k])
+                assert torch.equal(out[b, k], G[k * (I // K) + j // K, b, j % K])
+    lw = torch.from_numpy(g["sys_log_w"])
+    for tag, nd in (("all", None), ("five", 5), ("one", 1)):
+        u = torch.from_numpy(g[f"sys_{tag}_u"])
+        assert torch.equal(core.systematic_sample(lw.expand(u.shape[:-1] + lw.shape[-1:]), u, nd), torch.from_numpy(g[f"sys_{tag}_idx"]))
+    gen = torch.Generator().manual_seed(10112)
+    probs = torch.randn(20, generator=gen).exp()
+    probs /= probs.sum()
+    for nd in (None, 5, 1):
+        n = 20000
+        idx = core.systematic_sample(probs.log().expand(n, 20), torch.rand(n, 1, generator=gen), nd)
+        hist = torch.bincount(idx.reshape(-1), minlength=20).double() / n
+        torch.testing.assert_close(hist, (probs * (nd or 20)).double(), rtol=0, atol=0.01)

@@ -942,6 +942,33 @@ def cases_dmis_known_answer(out):
          var_scale=var_scale, log_w=lw)
 
 
+def cases_resampling(out):
+    """Reference outputs of the two resampling helpers its own self-checks exercise (vae_imputation.py:799-876):
+    the independent-resampling gather for I == K and I == 2K, and systematic sampling with the uniform offsets
+    injected (torch.rand replaced for the duration of the call)."""
+    import vgiwae.shared.vae_imputation as vi
+    B, P, K = 6, 4, 5
+    arrays = {}
+    for tag, I in (("ik", K), ("i2k", 2 * K)):
+        G = make_noise(8100 + I, I, B, K, P)
+        idx = torch.randint(0, I, (B, K), generator=torch.Generator().manual_seed(8200 + I))
+        arrays[f"gather_{tag}_params"] = G
+        arrays[f"gather_{tag}_idx"] = idx
+        arrays[f"gather_{tag}_out"] = vi.select_gen_params_for_ir(G, idx, B, K)
+    lw = make_noise(8300, 3, 7, 20) * 1.5
+    orig = torch.rand
+    for tag, nd, shape in (("all", None, ()), ("five", 5, (4,)), ("one", 1, (4,))):
+        u = orig(tuple(shape) + (3, 7, 1), generator=torch.Generator().manual_seed(8400 + len(tag)))
+        torch.rand = lambda *a, **k: u.clone()
+        try:
+            idx = vi._systematic_sample(lw, num_dependent_samples=nd, sample_shape=shape)
+        finally:
+            torch.rand = orig
+        arrays[f"sys_{tag}_u"] = u
+        arrays[f"sys_{tag}_idx"] = idx
+    save(out, "resampling_helpers", sys_log_w=lw, **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -975,6 +1002,7 @@ def main():
         "mog_oracle": lambda: cases_mog_oracle(args.out),
         "trajectory": lambda: cases_trajectory(args.out),
         "posterior_divs": lambda: cases_posterior_divs(args.out),
+        "resampling": lambda: cases_resampling(args.out),
     }
     for name, fn in groups.items():
         if args.only and name not in args.only.split(","):
