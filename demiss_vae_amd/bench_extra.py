@@ -61,13 +61,17 @@ def missiwae_step(device, name, B, D, Zd, enc_shape, dec_shape, C=5, dropout=0.0
     return out
 
 
-def iwae_step(device, B, I=5):
-    """MissIWAE training step on UCI-gas shapes (configs/uci_gas/compare/mis50/iwae_i5_encm_stl.yaml), Adam included."""
+def iwae_step(device, B, I=5, *, name="UCI-gas", D=8, Zd=16, enc_shape=(16, 32, 2, 256), dec_shape=(16, 16, 2, 256),
+              gen_dist="normal_with_eps", mask_concat=True):
+    """MissIWAE training step, Adam included; by default on UCI-gas shapes
+    (configs/uci_gas/compare/mis50/iwae_i5_encm_stl.yaml)."""
     from oracle.recipes import NetSpec, make_batch
-    enc_s, dec_s = NetSpec(16, 32, 2, 256), NetSpec(16, 16, 2, 256)
+    enc_s, dec_s = NetSpec(*enc_shape), NetSpec(*dec_shape)
     enc, dec = _packed(device, enc_s, 1, True), _packed(device, dec_s, 2, True)
-    dims = ModelDims(D=8, Zd=16, encoder_use_mis_mask=True)
-    X, M = make_batch(3, B, 8)
+    dims = ModelDims(D=D, Zd=Zd, gen_dist=gen_dist, encoder_use_mis_mask=mask_concat)
+    X, M = make_batch(3, B, D)
+    if gen_dist.startswith("bern"):                       # about 13 % of the pixels on, as in binarised MNIST
+        X = (X > 1.1).float() * 2 - 1 if gen_dist == "bern_m1_p1" else (X > 1.1).float()
     X, M = X.to(device), M.to(device)
     opt = Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True)
 
@@ -80,7 +84,7 @@ def iwae_step(device, B, I=5):
     t = _sync_time(step, 30, 10)
     macs = lambda sp: sum(n * k for n, k in sp.layer_shapes())
     flops = 3 * 2 * B * (macs(enc_s) + I * macs(dec_s))
-    return {"workload": f"UCI-gas MissIWAE I={I} STL step incl. Adam, B={B}", "ms_per_step": round(t * 1e3, 4),
+    return {"workload": f"{name} MissIWAE I={I} STL step incl. Adam, B={B}", "ms_per_step": round(t * 1e3, 4),
             "samples_per_s": round(B * I / t, 1), "step_tflops": round(flops / t / 1e12, 2)}
 
 

@@ -1624,6 +1624,37 @@ static int launch_bwd(const BwdArgs& a, hipStream_t st) {
   return DMV_OK;
 }
 
+// hidden widths above 256 (9..16 tiles of 32): two activation sets no longer fit one wave's registers as 32-row
+// tiles; the 16-row kernels hold them (a quarter of Hp floats per lane and set) at every batch size
+template <int NT>
+static int launch_fwd_wide(const FwdArgs& a, hipStream_t st) {
+  const unsigned tiles = (unsigned)((a.rows + 15) / 16);
+  if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true>), dim3(tiles), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false>), dim3(tiles), dim3(256), 0, st, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+template <int NT>
+static int launch_bwd_wide(const BwdArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL((k_mlp_bwd_rows16<NT>), dim3((unsigned)((a.rows + 15) / 16)), dim3(256), 0, st, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+#define DMV_DISPATCH_WIDE(NTV, FN, ...)           \
+  switch (NTV) {                                  \
+    case 9: return FN<9>(__VA_ARGS__);            \
+    case 10: return FN<10>(__VA_ARGS__);          \
+    case 11: return FN<11>(__VA_ARGS__);          \
+    case 12: return FN<12>(__VA_ARGS__);          \
+    case 13: return FN<13>(__VA_ARGS__);          \
+    case 14: return FN<14>(__VA_ARGS__);          \
+    case 15: return FN<15>(__VA_ARGS__);          \
+    case 16: return FN<16>(__VA_ARGS__);          \
+    default: return DMV_E_UNSUPPORTED;            \
+  }
+
 #define DMV_DISPATCH_NT(NTV, FN, ...)             \
   switch (NTV) {                                  \
     case 1: return FN<1>(__VA_ARGS__);            \
@@ -1663,6 +1694,10 @@ extern "C" int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t i
   a.acts = saved ? saved + rp * dmv_pad32(net->in_dim) : nullptr;
   a.masks = saved ? (uint32_t*)(a.acts + (2 * net->nb + 1) * rp * dmv_pad32(net->hidden)) : nullptr;
   a.drop_keep = drop_keep;
+  if (a.L.NT > 8) {
+    if (drop_keep) return DMV_E_UNSUPPORTED;
+    DMV_DISPATCH_WIDE(a.L.NT, launch_fwd_wide, a, (hipStream_t)stream);
+  }
   DMV_DISPATCH_NT(a.L.NT, launch_fwd, a, (hipStream_t)stream);
 }
 
@@ -1783,7 +1818,7 @@ static int mlp_backward_impl(const DmvNet* net, const float* packed, const float
       case 6: r2 = launch_bwd<6>(b, st); break;
       case 7: r2 = launch_bwd<7>(b, st); break;
       case 8: r2 = launch_bwd<8>(b, st); break;
-      default: r2 = DMV_E_UNSUPPORTED;
+      default: r2 = [&]() -> int { DMV_DISPATCH_WIDE(b.L.NT, launch_bwd_wide, b, st); }();
     }
     if (r2) return r2;
   }

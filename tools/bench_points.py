@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Every bench point of the measurement plan in one run (training steps include Adam; inputs resident on the device):
 gas MissIWAE at B 512 / 4096 / 32768, toy DeMissVAE at B 64 / 4096 with K 5 / 25, hepmass and miniboone MissSIWAE at
-the configs' batch and 8x it, the K = 50 000 log-likelihood estimator on gas / hepmass / miniboone(C=5) shapes.
+the configs' batch and 8x it, the K = 50 000 log-likelihood estimator on gas / hepmass / miniboone(C=5) shapes, and the synthetic hidden-512 pair
+with 784-dimensional data.
 Writes one JSON object.  Usage: python tools/bench_points.py [out.json]"""
 import json
 import os
@@ -19,6 +20,13 @@ def main():
     for B in (512, 4096, 32768):
         out["gas_missiwae"].append(E.iwae_step(dev, B))
         print(out["gas_missiwae"][-1], flush=True)
+    # MFMA-sized 784-d layers: NOT a reference configuration (its image models are convolutional)
+    out["synthetic_784_h512"] = []
+    for B in (200, 4096):
+        out["synthetic_784_h512"].append(E.iwae_step(dev, B, name="synthetic 784-d pair, hidden 512 (not a reference config)", D=784,
+                                                     Zd=50, enc_shape=(784, 100, 2, 512), dec_shape=(50, 784, 2, 512),
+                                                     gen_dist="bern", mask_concat=False))
+        print(out["synthetic_784_h512"][-1], flush=True)
     for B in (64, 4096):
         for K in (5, 25):
             out["toy_demissvae"].append(E.demiss_toy_step(dev, B, K))
