@@ -52,28 +52,39 @@ struct PackArgs {
   float* packed;
 };
 
+// one thread = one lane slot of one fragment (16 bytes of an image) or one bias-fragment lane
 __global__ void k_pack(PackArgs a) {
   const int l = blockIdx.y;
   const int N = a.L.N[l], K = a.L.K[l];
   const int nt = (N + 31) / 32, S = a.L.S[l];
   const int kt = (K + 31) / 32, Sn = a.L.Sn[l];
-  const int64_t nfwd = (int64_t)nt * S * 256, ntr = (int64_t)kt * Sn * 256, nb = (int64_t)nt * 64;
+  const int64_t nfwd = (int64_t)nt * S * 64, ntr = (int64_t)kt * Sn * 64, nb = (int64_t)nt * 64;
   const float* W = a.w[l];
+  const bool row4 = (K & 3) == 0 && ((uintptr_t)W & 15) == 0;      // four consecutive inputs of a row as one load
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nfwd + ntr + nb;
        i += (int64_t)gridDim.x * blockDim.x) {
     if (i < nfwd) {
-      const int e = i & 3, lane = (i >> 2) & 63;
-      const int64_t g = i >> 8;
+      const int lane = i & 63;
+      const int64_t g = i >> 6;
       const int s = g % S, t = g / S;
-      const int n = 32 * t + (lane & 31), k = 8 * s + 4 * (lane >> 5) + e;
-      a.packed[a.L.w[l] + i] = (n < N && k < K) ? W[(int64_t)n * K + k] : 0.f;
+      const int n = 32 * t + (lane & 31), k0 = 8 * s + 4 * (lane >> 5);
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (n < N) {
+        if (row4 && k0 + 4 <= K) o = *(const f32x4*)(W + (int64_t)n * K + k0);
+        else
+          for (int e = 0; e < 4; ++e) o[e] = (k0 + e < K) ? W[(int64_t)n * K + k0 + e] : 0.f;
+      }
+      *(f32x4*)(a.packed + a.L.w[l] + 4 * i) = o;
     } else if (i < nfwd + ntr) {
       const int64_t j = i - nfwd;
-      const int e = j & 3, lane = (j >> 2) & 63;
-      const int64_t g = j >> 8;
+      const int lane = j & 63;
+      const int64_t g = j >> 6;
       const int s = g % Sn, t = g / Sn;
-      const int k = 32 * t + (lane & 31), n = 8 * s + 4 * (lane >> 5) + e;
-      a.packed[a.L.wt[l] + j] = (n < N && k < K) ? W[(int64_t)n * K + k] : 0.f;
+      const int k = 32 * t + (lane & 31), n0 = 8 * s + 4 * (lane >> 5);
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (k < K)
+        for (int e = 0; e < 4; ++e) o[e] = (n0 + e < N) ? W[(int64_t)(n0 + e) * K + k] : 0.f;
+      *(f32x4*)(a.packed + a.L.wt[l] + 4 * j) = o;
     } else {
       // bias as an MFMA A-operand fragment: lane (n, h = 0) carries bias[32 t + n], the h = 1 half is zero
       const int64_t j = i - nfwd - ntr;

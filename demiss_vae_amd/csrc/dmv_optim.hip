@@ -3,11 +3,12 @@
 // clip_grad_norm_ over all parameters; torch needs about a dozen launches for the same work, and its multi-tensor
 // Adam runs a 547 k-parameter model on ten workgroups).
 //
-//   k_opt_sumsq   partial sums of g^2 over fixed 4096-element chunks (one workgroup per chunk: the summation order
-//                 does not depend on the launch geometry)
+//   k_opt_sumsq   partial sums of g^2 over fixed 1024-element quarters of 4096-element chunks (one workgroup per
+//                 quarter: the summation order does not depend on the launch geometry)
 //   k_opt_prep    one workgroup: total norm -> clip coefficient min(1, max_norm / (norm + 1e-6)) (torch's
 //                 clip_grad_norm_), step counters += 1, bias corrections per group
-//   k_opt_apply   one workgroup per chunk:  g' = coef g;  m = m + (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;
+//   k_opt_apply   one workgroup per quarter chunk (a 547 k-parameter model fills the chip only at this grain;
+//                 16-byte accesses where the tensors allow):  g' = coef g;  m = m + (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;
 //                 [vmax = max(vmax, v)];  p -= (lr / (1 - b1^t)) m / (sqrt(v or vmax) / sqrt(1 - b2^t) + eps)
 // Tensor tables travel by value in the kernel arguments (like torch's multi-tensor kernels), so a recorded step
 // replays against the same gradient addresses without host copies.  Learning rates and step counters are read from
@@ -17,6 +18,8 @@
 namespace {
 
 constexpr int kChunk = 4096;
+constexpr int kSub = 4;                 // workgroups per chunk
+constexpr int kQuarter = kChunk / kSub;
 constexpr int kMaxT = DMV_OPT_MAX_TENSORS;
 constexpr int kMaxG = DMV_OPT_MAX_GROUPS;
 
@@ -71,15 +74,15 @@ __device__ inline float block_sum(float x, float* red) {
 
 __global__ void k_opt_sumsq(OptTable t, float* __restrict__ partial) {
   __shared__ float red[4];
-  const int chunk = blockIdx.x;
+  const int chunk = blockIdx.x / kSub;
   const int ti = find_tensor(t, chunk);
-  const int base = (chunk - t.first_chunk[ti]) * kChunk;
-  const int end = min(base + kChunk, t.numel[ti]);
+  const int base = (chunk - t.first_chunk[ti]) * kChunk + (blockIdx.x % kSub) * kQuarter;
+  const int end = min(base + kQuarter, t.numel[ti]);
   const float* g = t.g[ti];
   float acc = 0.f;
   for (int i = base + threadIdx.x; i < end; i += blockDim.x) { const float x = g[i]; acc += x * x; }
   const float s = block_sum(acc, red);
-  if (threadIdx.x == 0) partial[chunk] = s;
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
 __global__ void k_opt_prep(OptGroups gr, int n_chunks, float max_norm, const float* __restrict__ partial, OptState* st,
@@ -107,30 +110,52 @@ __global__ void k_opt_prep(OptGroups gr, int n_chunks, float max_norm, const flo
   }
 }
 
+struct AdamCoef {
+  float coef, b2, eps, omb1, omb2, step_size, bc2s;
+};
+
+__device__ __forceinline__ void adam_one(const AdamCoef& c, float g, float& p, float& m, float& v, float* vmax) {
+  const float gs = g * c.coef;
+  m = m + c.omb1 * (gs - m);
+  v = c.b2 * v + c.omb2 * gs * gs;
+  float d = v;
+  if (vmax) { d = fmaxf(*vmax, v); *vmax = d; }
+  p = p - c.step_size * (m / (sqrtf(d) / c.bc2s + c.eps));
+}
+
 __global__ void k_opt_apply(OptTable t, OptGroups gr, const OptState* __restrict__ st) {
-  const int chunk = blockIdx.x;
+  const int chunk = blockIdx.x / kSub;
   const int ti = find_tensor(t, chunk);
-  const int base = (chunk - t.first_chunk[ti]) * kChunk;
-  const int end = min(base + kChunk, t.numel[ti]);
+  const int base = (chunk - t.first_chunk[ti]) * kChunk + (blockIdx.x % kSub) * kQuarter;
+  const int end = min(base + kQuarter, t.numel[ti]);
+  if (base >= end) return;
   const int gi = t.group[ti];
-  const float coef = st->coef, b2 = gr.beta2[gi], eps = gr.eps[gi], omb1 = gr.omb1[gi], omb2 = gr.omb2[gi];
-  const float step_size = gr.lr[gi][0] / st->bc1[gi], bc2s = st->bc2_sqrt[gi];
+  AdamCoef c;
+  c.coef = st->coef; c.b2 = gr.beta2[gi]; c.eps = gr.eps[gi]; c.omb1 = gr.omb1[gi]; c.omb2 = gr.omb2[gi];
+  c.step_size = gr.lr[gi][0] / st->bc1[gi]; c.bc2s = st->bc2_sqrt[gi];
   float* p = t.p[ti];
   const float* g = t.g[ti];
   float* m = t.m[ti];
   float* v = t.v[ti];
   float* vm = t.vmax[ti];
-  for (int i = base + threadIdx.x; i < end; i += blockDim.x) {
-    const float gs = g[i] * coef;
-    float mi = m[i], vi = v[i];
-    mi = mi + omb1 * (gs - mi);
-    vi = b2 * vi + omb2 * gs * gs;
-    m[i] = mi;
-    v[i] = vi;
-    float d = vi;
-    if (vm) { d = fmaxf(vm[i], vi); vm[i] = d; }
-    p[i] = p[i] - step_size * (mi / (sqrtf(d) / bc2s + eps));
+  // a quarter starts at a multiple of 1024 elements: 16-byte accesses need only aligned tensor bases
+  const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vm) & 15) == 0;
+  const int i4 = base + 4 * (int)threadIdx.x;       // blockDim.x * 4 == kQuarter
+  if (vec && i4 + 4 <= end) {
+    f32x4 P = *(f32x4*)(p + i4), M = *(f32x4*)(m + i4), V = *(f32x4*)(v + i4), X;
+    const f32x4 G = *(const f32x4*)(g + i4);
+    if (vm) X = *(f32x4*)(vm + i4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pe = P[e], me = M[e], ve = V[e], xe = vm ? X[e] : 0.f;
+      adam_one(c, G[e], pe, me, ve, vm ? &xe : nullptr);
+      P[e] = pe; M[e] = me; V[e] = ve; X[e] = xe;
+    }
+    *(f32x4*)(p + i4) = P; *(f32x4*)(m + i4) = M; *(f32x4*)(v + i4) = V;
+    if (vm) *(f32x4*)(vm + i4) = X;
+    return;
   }
+  for (int i = i4; i < min(i4 + 4, end); ++i) adam_one(c, g[i], p[i], m[i], v[i], vm ? vm + i : nullptr);
 }
 
 }  // namespace
@@ -142,7 +167,7 @@ extern "C" size_t dmv_opt_ws_floats(int32_t n, const int64_t* numel) {
     if (numel[i] < 0 || numel[i] > 0x7fffffff) return 0;
     chunks += (size_t)((numel[i] + kChunk - 1) / kChunk);
   }
-  return (sizeof(OptState) + 3) / 4 + chunks + 1;
+  return (sizeof(OptState) + 3) / 4 + kSub * chunks + 1;
 }
 
 extern "C" int dmv_opt_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
@@ -186,12 +211,12 @@ extern "C" int dmv_opt_adam_step(int32_t n, float* const* params, const float* c
   float* partial = ws + (sizeof(OptState) + 3) / 4;
   hipStream_t s = (hipStream_t)stream;
   if (max_norm > 0.f) {
-    hipLaunchKernelGGL(k_opt_sumsq, dim3((unsigned)chunks), dim3(256), 0, s, t, partial);
+    hipLaunchKernelGGL(k_opt_sumsq, dim3((unsigned)(kSub * chunks)), dim3(256), 0, s, t, partial);
     DMV_HIP_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(k_opt_prep, dim3(1), dim3(256), 0, s, gr, chunks, max_norm, partial, st, norm_out);
+  hipLaunchKernelGGL(k_opt_prep, dim3(1), dim3(256), 0, s, gr, kSub * chunks, max_norm, partial, st, norm_out);
   DMV_HIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_opt_apply, dim3((unsigned)chunks), dim3(256), 0, s, t, gr, st);
+  hipLaunchKernelGGL(k_opt_apply, dim3((unsigned)(kSub * chunks)), dim3(kQuarter / 4), 0, s, t, gr, st);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }

@@ -28,6 +28,11 @@ class DeviceLoader:
         self.batch_size, self.shuffle, self.device, self.generator = batch_size, shuffle, device, generator
         self.drop_last = drop_last
         self.dataset = dataset
+        # True: full-size batches are written into the same tensors every time (marked `_dmv_persistent`), so a
+        # recorded step can take them as its inputs without a copy; a consumer must be done with a batch before
+        # asking for the next
+        self.reuse_buffers = False
+        self._bufs = None
 
     def __len__(self):
         return self.n // self.batch_size if self.drop_last else (self.n + self.batch_size - 1) // self.batch_size
@@ -39,4 +44,13 @@ class DeviceLoader:
             order = torch.arange(self.n, device=self.device)
         for i in range(len(self)):
             sel = order[i * self.batch_size:(i + 1) * self.batch_size]
-            yield tuple(a.index_select(0, sel) for a in self.arrays)
+            if self.reuse_buffers and sel.shape[0] == self.batch_size:
+                if self._bufs is None:
+                    self._bufs = tuple(a.new_empty((self.batch_size,) + tuple(a.shape[1:])) for a in self.arrays)
+                    for b in self._bufs:
+                        b._dmv_persistent = True
+                for a, b in zip(self.arrays, self._bufs):
+                    torch.index_select(a, 0, sel, out=b)
+                yield self._bufs
+            else:
+                yield tuple(a.index_select(0, sel) for a in self.arrays)

@@ -113,10 +113,23 @@ class _Means:
         self.sum, self.n = {}, {}
 
     def add(self, logged, weight=1):
+        sums, vals = [], []
         for k, v in logged.items():
-            v = v.detach().float() if isinstance(v, torch.Tensor) else float(v)
-            self.sum[k] = self.sum[k] + v * weight if k in self.sum else v * weight
+            if isinstance(v, torch.Tensor):
+                v = v.detach()
+                v = v if v.dtype == torch.float32 else v.float()
+                v = v if weight == 1 else v * weight
+                have = self.sum.get(k)
+                if isinstance(have, torch.Tensor) and have.device == v.device and have.shape == v.shape:
+                    sums.append(have)
+                    vals.append(v)
+                else:      # first sight: a copy (a replayed step hands out the same tensors every time)
+                    self.sum[k] = v.clone() if have is None else have + v
+            else:
+                self.sum[k] = self.sum.get(k, 0.0) + float(v) * weight
             self.n[k] = self.n.get(k, 0) + weight
+        if sums:
+            torch._foreach_add_(sums, vals)        # one launch for all metrics of the step
 
     def result(self, suffix=None):
         return {k: float(self.sum[k]) / self.n[k] for k in sorted(self.sum) if suffix is None or k.endswith(suffix)}
@@ -236,7 +249,8 @@ class _StepRunner:
         if n < 2 or key in self.eager_keys:         # lazily created state (optimiser, workspaces) must exist first
             return self._eager(batch, self.side if n < 2 else None)
         if key not in self.graphs:
-            static = tuple(t.clone() for t in batch)
+            # a loader that reuses its batch tensors hands over the recording's inputs themselves
+            static = tuple(t if getattr(t, "_dmv_persistent", False) else t.clone() for t in batch)
             m = self.model
             nets = tuple(m.engine()[1:]) if getattr(getattr(m, "model", m), "fused", False) else ()
             logged = {}
@@ -255,7 +269,8 @@ class _StepRunner:
             self.static[key] = (static, logged)
         static, logged = self.static[key]
         for dst, src in zip(static, batch):
-            dst.copy_(src)
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
         self.graphs[key]()
         self.replays += 1
         self.model._logged = dict(logged)
@@ -335,6 +350,8 @@ def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None, log_dir=No
     inner = getattr(model, "model", model)
     use_graph = bool(trainer_cfg.get("hip_graph", True)) and P.world() == 1 and getattr(inner, "fused", False)
     run_step = _StepRunner(model, opt, sched, params, clip_val, clip_alg, use_graph, log=log)
+    if use_graph and hasattr(train_loader, "reuse_buffers"):
+        train_loader.reuse_buffers = True          # each batch is consumed by its step before the next is drawn
     model.on_train_start()
     step, epoch, history, t0 = 0, 0, [], time.time()
     done = False
