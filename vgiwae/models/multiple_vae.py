@@ -26,8 +26,9 @@ class MultipleVAE(_MixtureLogitLogging, VAE):
     def training_step(self, batch, batch_idx) -> STEP_OUTPUT:
         elbo = self._bound(batch)
         self.log("elbo/train", elbo, on_step=True, on_epoch=True, prog_bar=False, logger=True)
-        self.log("loss/train", -elbo, on_step=True, on_epoch=True, prog_bar=True, logger=True)
-        return -elbo
+        loss = -elbo
+        self.log("loss/train", loss, on_step=True, on_epoch=True, prog_bar=True, logger=True)
+        return loss
 
     def validation_step(self, batch, batch_idx) -> Optional[STEP_OUTPUT]:
         with torch.no_grad():
