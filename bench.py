@@ -197,8 +197,19 @@ def dbg(msg):
         print(f"[bench rank {os.environ.get('RANK', 0)}] {msg}", file=sys.stderr, flush=True)
 
 
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner at
+    communicator creation): from here on file descriptor 1 is stderr for everything, and the returned handle is the
+    only way to the real stdout."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     args = parse()
+    out_stream = _claim_stdout()
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -226,7 +237,7 @@ def main():
     dims, enc, dec, enc_s, dec_s, X, M = make_gas(device, B, seed=20220118 + 1000 * rank)
     params = enc.params() + dec.params()
     if args.kernels_only:
-        print(json.dumps({"roofline": kernel_roofline(dec, dec_s, B * K, device)}))
+        print(json.dumps({"roofline": kernel_roofline(dec, dec_s, B * K, device)}), file=out_stream, flush=True)
         return
     groups = [{"params": dec.params(), "amsgrad": True, "lr": 1e-3}, {"params": enc.params(), "amsgrad": True, "lr": 1e-3}]
     if args.torch_optim:        # stock torch: clip_grad_norm_ + fused Adam (about a dozen launches)
@@ -331,7 +342,7 @@ def main():
     if rank == 0 and world > 1 and ll is not None:
         out["extra"] = {"loglik_eval_K50000": ll}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), file=out_stream, flush=True)
     if dist:
         td.barrier()
         td.destroy_process_group()
