@@ -290,6 +290,10 @@ def estimate_loglik(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, nu
     if mixture:
         Cn = dims.C
         logits = enc_out[:, 2 * Cn * Zd: 2 * Cn * Zd + Cn].contiguous()
+    if chunk * B >= 32768:
+        # whole rounds of the decoder kernel: 1024 one-wave tiles of 32 rows fill the chip once, and a launch that ends
+        # a quarter into a round (4096 x 50 rows = 6.25 rounds) pays for the whole round
+        chunk = max(1, (chunk * B // 32768) * 32768 // B)
     for k0 in range(0, K, chunk):
         Kc = min(chunk, K - k0)
         N = Kc * B
