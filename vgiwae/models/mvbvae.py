@@ -70,11 +70,12 @@ class MVBVAE(VAE):
         if kind is MVB_OBJECTIVE["mvb2"]:
             gen_obj, enc_obj = self.estimate_mvb2_objectives(Xt, M)
             gen_obj, enc_obj = gen_obj.mean(), enc_obj.mean()
+            gen_loss = -gen_obj
             if optimise:
-                self.mvb2_manual_optimisation_step(-enc_obj, -gen_obj)
+                self.mvb2_manual_optimisation_step(-enc_obj, gen_loss)
             self.log(f"mvb/{stage}", enc_obj, on_step=True, on_epoch=True, prog_bar=False, logger=True)
             self.log(f"cvi/{stage}", gen_obj, on_step=True, on_epoch=True, prog_bar=False, logger=True)
-            return -gen_obj
+            return gen_loss
         if kind is MVB_OBJECTIVE["mvb"]:
             obj = self.estimate_mvb_objective(Xt, M).mean()
             self.log(f"mvb/{stage}", obj, on_step=True, on_epoch=True, prog_bar=False, logger=True)
