@@ -258,7 +258,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         fwd_bwd()
         if dist:
-            allreduce_grads(params)
+            allreduce_grads(params, force=dist)
         if args.torch_optim:
             torch.nn.utils.clip_grad_norm_(params, 5.0, foreach=True)
         else:

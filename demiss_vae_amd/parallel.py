@@ -39,18 +39,25 @@ def all_reduce(t: torch.Tensor, op=None, group=None):
     return t
 
 
-def allreduce_grads(params: Sequence[torch.Tensor], group=None):
-    """Average .grad over ranks with one flat all-reduce (equal shard sizes assumed)."""
-    if world() == 1:
+def allreduce_grads(params: Sequence[torch.Tensor], group=None, force=False):
+    """Average .grad over ranks with one flat all-reduce (equal shard sizes assumed).  force: run the collective even
+    in a world of one rank (rehearsals of the RCCL path on a single GPU)."""
+    if world() == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return
     with_grad = [p for p in params if p.grad is not None]
     if not with_grad:
         return
-    flat = _flatten_dense_tensors([p.grad for p in with_grad])
-    all_reduce(flat, dist.ReduceOp.SUM, group)
-    flat.div_(dist.get_world_size(group))
-    for p, g in zip(with_grad, _unflatten_dense_tensors(flat, [p.grad for p in with_grad])):
-        p.grad.copy_(g)
+    grads = [p.grad for p in with_grad]
+    flat = _flatten_dense_tensors(grads)
+    if dist.get_backend(group) == "nccl":
+        all_reduce(flat, dist.ReduceOp.AVG, group)          # RCCL averages inside the reduction
+    else:
+        all_reduce(flat, dist.ReduceOp.SUM, group)
+        flat.div_(dist.get_world_size(group))
+    # the averaged gradients stay where they are: every .grad becomes a view of the flat buffer (one gather kernel and
+    # the collective per step, no copies back)
+    for p, g in zip(with_grad, _unflatten_dense_tensors(flat, grads)):
+        p.grad = g
 
 
 def lse_allreduce(run_max: torch.Tensor, run_sum: torch.Tensor, group=None):
