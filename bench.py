@@ -160,12 +160,13 @@ def kernel_roofline(dec, dec_s, rows, device):
     return roof
 
 
-def cpu_baseline(budget_s=15.0):
+def cpu_baseline(budget_s=15.0, threads=None):
     """The CPU oracle (stock PyTorch ops + autograd, the op sequence the reference issues) on the yaml batch
-    (B=512, K=5) of the same workload, repeated for about `budget_s` seconds on this host's cores."""
+    (B=512, K=5) of the same workload, repeated for about `budget_s` seconds on `threads` of this host's cores
+    (default: the box's CPU share, 16)."""
     from oracle import core
     from oracle.recipes import NetSpec, make_params, make_batch, make_noise
-    threads = min(16, os.cpu_count() or 1)
+    threads = min(16, os.cpu_count() or 1) if threads is None else threads
     torch.set_num_threads(threads)
     enc_s, dec_s = NetSpec(16, 32, 2, 256), NetSpec(16, 16, 2, 256)
     spec = core.ModelSpec(D=8, Zd=16, enc=enc_s, dec=dec_s, encoder_use_mis_mask=True)
@@ -339,6 +340,7 @@ def main():
             out["extra"] = extra
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
+            out.setdefault("extra", {})["cpu_baseline_single_thread"] = cpu_baseline(budget_s=6.0, threads=1)
     if rank == 0 and world > 1 and ll is not None:
         out["extra"] = {"loglik_eval_K50000": ll}
     if rank == 0:
