@@ -11,6 +11,8 @@ from typing import Any
 import torch
 import torch.nn as nn
 
+_UNIT = {}     # per device: the scalar 1 used as the root gradient of backward()
+
 try:  # pragma: no cover - depends on the environment
     import pytorch_lightning as _pl
     LightningModule = _pl.LightningModule
@@ -113,6 +115,12 @@ except Exception:  # ModuleNotFoundError here; any import-time failure means "no
             return self._schedulers
 
         def manual_backward(self, loss, *args, **kwargs):
+            if not args and "gradient" not in kwargs and loss.dim() == 0 and loss.dtype == torch.float32:
+                # the root gradient of a scalar loss, kept per device instead of filled anew every step
+                one = _UNIT.get(loss.device)
+                if one is None:
+                    one = _UNIT[loss.device] = torch.ones((), device=loss.device)
+                kwargs["gradient"] = one
             loss.backward(*args, **kwargs)
 
         def clip_gradients(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):

@@ -151,6 +151,19 @@ def init_distributed():
         dist.init_process_group(os.environ.get("DMV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo"))
 
 
+_UNIT = {}
+
+
+def _unit_gradient(loss):
+    """the root gradient of a scalar loss, kept per device: backward() would otherwise fill a fresh one every step"""
+    if loss.dim() != 0 or loss.dtype != torch.float32:
+        return None
+    one = _UNIT.get(loss.device)
+    if one is None:
+        one = _UNIT[loss.device] = torch.ones((), device=loss.device)
+    return one
+
+
 class _DeferredScheduler:
     """stands in for the scheduler while a step is recorded: the recording must not bake a learning rate in, so the
     real scheduler is stepped after every replay instead"""
@@ -197,7 +210,7 @@ class _StepRunner:
         if m.automatic_optimization:
             loss = m.training_step(batch, 0)
             opt.zero_grad(set_to_none=True)
-            loss.backward()
+            loss.backward(_unit_gradient(loss))
             P.allreduce_grads(self.params)
             m.on_before_optimizer_step(opt, 0)
             m.configure_gradient_clipping(opt, 0, gradient_clip_val=self.clip_val, gradient_clip_algorithm=self.clip_alg)
