@@ -183,6 +183,10 @@ class _StepRunner:
         self.model, self.opt, self.sched, self.params, self.log = model, opt, sched, params, log
         self.clip_val, self.clip_alg = clip_val, clip_alg
         self.use_graph = use_graph
+        # data parallelism: the recording ends with the backward pass; gradient exchange, clipping and the optimiser
+        # follow eagerly after every replay (no collective inside a recording)
+        self.split = use_graph and P.world() > 1
+        self.graph_grads = {}
         self.seen, self.graphs, self.static, self.eager_keys = {}, {}, {}, set()
         self.replays = 0
         self.side = torch.cuda.Stream() if use_graph else None
@@ -205,16 +209,24 @@ class _StepRunner:
             key.append(m.current_epoch % h.marginal_eval_freq == 0 or m.current_epoch == (m.trainer.max_epochs or 0) - 1)
         return tuple(key)
 
-    def _body(self, batch):
+    def _gradients(self, batch):
         m, opt = self.model, self.opt
+        loss = m.training_step(batch, 0)
+        opt.zero_grad(set_to_none=True)
+        loss.backward(_unit_gradient(loss))
+
+    def _update(self):
+        m, opt = self.model, self.opt
+        P.allreduce_grads(self.params)
+        m.on_before_optimizer_step(opt, 0)
+        m.configure_gradient_clipping(opt, 0, gradient_clip_val=self.clip_val, gradient_clip_algorithm=self.clip_alg)
+        opt.step()
+
+    def _body(self, batch):
+        m = self.model
         if m.automatic_optimization:
-            loss = m.training_step(batch, 0)
-            opt.zero_grad(set_to_none=True)
-            loss.backward(_unit_gradient(loss))
-            P.allreduce_grads(self.params)
-            m.on_before_optimizer_step(opt, 0)
-            m.configure_gradient_clipping(opt, 0, gradient_clip_val=self.clip_val, gradient_clip_algorithm=self.clip_alg)
-            opt.step()
+            self._gradients(batch)
+            self._update()
         else:
             m.training_step(batch, 0)          # the model steps its optimiser itself (two-loss DeMissVAE step)
 
@@ -271,9 +283,14 @@ class _StepRunner:
             def body():
                 m._logged = logged
                 logged.clear()
-                self._body(static)
+                if self.split:
+                    self._gradients(static)
+                else:
+                    self._body(static)
             try:
                 self.graphs[key] = GraphedStep(body, nets=nets, warmup=0)
+                if self.split:      # where the recording leaves the gradients (its own memory, same place every replay)
+                    self.graph_grads[key] = [p.grad for p in self.params]
             except Exception as e:                  # a step that synchronises with the host cannot be recorded
                 self.log(f"[run] step not recordable ({type(e).__name__}: {e}); steps of this kind run eagerly")
                 self.eager_keys.add(key)
@@ -287,6 +304,10 @@ class _StepRunner:
         self.graphs[key]()
         self.replays += 1
         self.model._logged = dict(logged)
+        if self.split:
+            for p, g in zip(self.params, self.graph_grads[key]):
+                p.grad = g          # (the exchange of the previous step re-pointed .grad at its flat buffer)
+            self._update()
         self._after()
 
 
@@ -361,7 +382,8 @@ def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None, log_dir=No
     model._optimizers, model._schedulers = opt, sched
     params = [p for g in opt.param_groups for p in g["params"]]
     inner = getattr(model, "model", model)
-    use_graph = bool(trainer_cfg.get("hip_graph", True)) and P.world() == 1 and getattr(inner, "fused", False)
+    use_graph = bool(trainer_cfg.get("hip_graph", True)) and getattr(inner, "fused", False) \
+        and (P.world() == 1 or model.automatic_optimization)
     run_step = _StepRunner(model, opt, sched, params, clip_val, clip_alg, use_graph, log=log)
     if use_graph and hasattr(train_loader, "reuse_buffers"):
         train_loader.reuse_buffers = True          # each batch is consumed by its step before the next is drawn

@@ -233,7 +233,8 @@ def test_gradvar_class_logs_through_recorded_steps(workdir):
 
 def test_two_rank_data_parallel_run_keeps_replicas_identical(workdir):
     """torchrun with two ranks sharing the GPU (gloo collectives staged through the host): every rank trains on its fixed
-    half of the split with half the batch, gradients are averaged before the clip, replicas stay bit-identical"""
+    half of the split with half the batch, gradients are averaged before the clip, replicas stay bit-identical; the
+    forward and backward passes of a step replay from a HIP graph, the collective stays outside it"""
     import subprocess
     import sys
     path = workdir / "iwae_dp.yaml"
@@ -247,6 +248,8 @@ def test_two_rank_data_parallel_run_keeps_replicas_identical(workdir):
     rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
     epochs, summary = [r for r in rows if "epoch" in r], [r for r in rows if "replica_spread" in r][0]
     assert summary["world"] == 2 and summary["replica_spread"] == 0.0
+    # forward + backward replay from a recording; exchange, clipping and optimiser follow eagerly after each replay
+    assert summary["hip_graph_replays"] >= summary["steps"] - 4
     assert [r["step"] for r in epochs] == [16, 32, 48]                  # 968 rows per rank, 64 per rank and step
     assert epochs[-1]["elbo/val"] > epochs[0]["elbo/val"]
 
