@@ -283,8 +283,14 @@ class _StepRunner:
             def body():
                 m._logged = logged
                 logged.clear()
-                if self.split:
+                if self.split and m.automatic_optimization:
                     self._gradients(static)
+                elif self.split:            # the model's own two-loss step, stopped after its backward passes
+                    m._defer_update = True
+                    try:
+                        m.training_step(static, 0)
+                    finally:
+                        m._defer_update = False
                 else:
                     self._body(static)
             try:
@@ -307,7 +313,10 @@ class _StepRunner:
         if self.split:
             for p, g in zip(self.params, self.graph_grads[key]):
                 p.grad = g          # (the exchange of the previous step re-pointed .grad at its flat buffer)
-            self._update()
+            if self.model.automatic_optimization:
+                self._update()
+            else:
+                self.model.finish_manual_update()
         self._after()
 
 
@@ -383,7 +392,7 @@ def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None, log_dir=No
     params = [p for g in opt.param_groups for p in g["params"]]
     inner = getattr(model, "model", model)
     use_graph = bool(trainer_cfg.get("hip_graph", True)) and getattr(inner, "fused", False) \
-        and (P.world() == 1 or model.automatic_optimization)
+        and (P.world() == 1 or model.automatic_optimization or hasattr(model, "finish_manual_update"))
     run_step = _StepRunner(model, opt, sched, params, clip_val, clip_alg, use_graph, log=log)
     if use_graph and hasattr(train_loader, "reuse_buffers"):
         train_loader.reuse_buffers = True          # each batch is consumed by its step before the next is drawn

@@ -254,6 +254,28 @@ def test_two_rank_data_parallel_run_keeps_replicas_identical(workdir):
     assert epochs[-1]["elbo/val"] > epochs[0]["elbo/val"]
 
 
+def test_two_rank_data_parallel_demissvae_replays(workdir):
+    """the two-loss DeMissVAE step under data parallelism: imputation update and both backward passes replay from the
+    recording, the step is completed outside it (exchange, clipping, optimiser); replicas stay bit-identical"""
+    import subprocess
+    import sys
+    path = workdir / "mvb2_dp.yaml"
+    path.write_text(CONFIG.replace("logs/toy/mvb2", "logs/toy/mvb2_dp").replace("max_epochs: 2", "max_epochs: 3")
+                    .replace("    save_imputations: True\n", ""))
+    env = dict(os.environ, DMV_DIST_BACKEND="gloo", PYTHONPATH=os.pathsep.join(filter(None, [os.getcwd(), os.environ.get("PYTHONPATH")])))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29534", "-m", "demiss_vae_amd.run", "--config", str(path),
+                          "--data.data_root", str(workdir / "data"), "--trainer.default_root_dir", str(workdir)],
+                         capture_output=True, text=True, timeout=110, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    epochs, summary = [r for r in rows if "epoch" in r], [r for r in rows if "replica_spread" in r][0]
+    assert summary["world"] == 2 and summary["replica_spread"] == 0.0
+    assert summary["hip_graph_replays"] >= summary["steps"] - 8, summary
+    assert all(math.isfinite(r["mvb/train"]) and math.isfinite(r["cvi/train"]) for r in epochs)
+    assert epochs[-1]["cvi/train"] > epochs[0]["cvi/train"]
+
+
 def test_stratified_mixture_config_with_dropout_replays(workdir):
     """MissSIWAE (stratified mixture encoder, dropout in both networks: the miniboone configs' structure) and its refit
     with the stratified refit class: recorded steps, dropout masks fresh on every replay, K-sample test estimate"""

@@ -13,7 +13,7 @@ import demiss_vae_amd as dmv
 from demiss_vae_amd.objectives import demiss_terms
 from demiss_vae_amd.pl_compat import STEP_OUTPUT
 from vgiwae.models.iwae import IWAE
-from vgiwae.shared.mvb2_manual_optimisation import mvb2_manual_optimisation_step
+from vgiwae.shared.mvb2_manual_optimisation import finish_manual_update, mvb2_manual_optimisation_step
 
 
 class MVB_IWAE_OBJ(Enum):
@@ -87,6 +87,7 @@ class MVBIWAE(IWAE):
                 "Encoder and decoder should use the same importance weights."
 
     mvb2_manual_optimisation_step = mvb2_manual_optimisation_step
+    finish_manual_update = finish_manual_update
 
     def on_train_epoch_end(self) -> None:
         super().on_train_epoch_end()

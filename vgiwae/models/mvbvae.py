@@ -8,7 +8,7 @@ import torch
 import demiss_vae_amd as dmv
 from demiss_vae_amd.pl_compat import STEP_OUTPUT
 from vgiwae.models.vae import VAE
-from vgiwae.shared.mvb2_manual_optimisation import mvb2_manual_optimisation_step
+from vgiwae.shared.mvb2_manual_optimisation import finish_manual_update, mvb2_manual_optimisation_step
 
 
 class MVB_OBJECTIVE(Enum):
@@ -27,6 +27,7 @@ class MVBVAE(VAE):
             self.automatic_optimization = False     # two losses, one manual step
 
     mvb2_manual_optimisation_step = mvb2_manual_optimisation_step
+    finish_manual_update = finish_manual_update
 
     def on_train_epoch_end(self) -> None:
         super().on_train_epoch_end()
