@@ -1,24 +1,28 @@
-"""Mixture whose sample() returns one draw per component (reference:
-vgiwae/shared/stratified_mixture_same_family.py:4-33); used only by the torch.distributions view of the model."""
+"""A MixtureSameFamily that, by default, draws one sample from every component instead of picking components at
+random (reference behaviour: vgiwae/shared/stratified_mixture_same_family.py:4-33).  Only the torch.distributions
+view of a model uses it; the kernels sample stratified mixtures themselves."""
 import torch
 from torch.distributions.mixture_same_family import MixtureSameFamily
 
 
 class StratifiedMixtureSameFamily(MixtureSameFamily):
-    sample_stratified = True
+    sample_stratified = True          # switched off per instance by set_sample_not_stratified()
 
     def set_sample_not_stratified(self):
         self.sample_stratified = False
 
-    def rsample(self, sample_shape=torch.Size()):
-        if not self.sample_stratified:
-            return super().rsample(sample_shape)
-        return self.component_distribution.rsample(sample_shape)
+    def _draw(self, method: str, sample_shape):
+        """stratified: the component distribution's own draw, shape sample_shape + batch + [components] + event;
+        otherwise the mixture's ancestral draw"""
+        if self.sample_stratified:
+            return getattr(self.component_distribution, method)(sample_shape)
+        return getattr(super(), method)(sample_shape)
 
     def sample(self, sample_shape=torch.Size()):
-        if not self.sample_stratified:
-            return super().sample(sample_shape)
-        return self.component_distribution.sample(sample_shape)
+        return self._draw("sample", sample_shape)
+
+    def rsample(self, sample_shape=torch.Size()):
+        return self._draw("rsample", sample_shape)
 
     def sample_not_stratified(self, sample_shape=torch.Size()):
-        return super().sample(sample_shape)
+        return MixtureSameFamily.sample(self, sample_shape)

@@ -1,3 +1,5 @@
 def construct_experiment_subdir(args):
-    """Experiment directory name used by the entry scripts (reference: vgiwae/utils/arg_utils.py:1-2)."""
-    return "{}/seed_m{}_d{}".format(args.experiment_subdir_base, args.seed_everything, args.data.setup_seed)
+    """`<experiment_subdir_base>/seed_m<model seed>_d<data seed>`: the run directory the entry scripts log under
+    (reference: vgiwae/utils/arg_utils.py:1-2)."""
+    seeds = "seed_m{}_d{}".format(args.seed_everything, args.data.setup_seed)
+    return "/".join((str(args.experiment_subdir_base), seeds))
