@@ -85,6 +85,7 @@ SIGNATURES = {
     "dmv_rows_scatter": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "dmv_impute_tail": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P, _P, _P, _U64, _U64, _P, _P, _P, _I32, _P, _P, _P, _P]),
     "dmv_categorical_draw": (C.c_int, [_I32, _I32, _I32, _P, _P, _U64, _U64, _P, _P, _P]),
+    "dmv_lair_row_map": (C.c_int, [_I32, _I32, _I32, _P, _P, _P]),
     "dmv_dropout_masks": (C.c_int, [_P, _I64, _F, _U64, _U64, _P, _P]),
 }
 

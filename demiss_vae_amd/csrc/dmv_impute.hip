@@ -275,6 +275,24 @@ extern "C" int dmv_categorical_draw(int32_t B, int32_t P, int32_t K, const float
   return DMV_OK;
 }
 
+// rows of the proposal table picked by the resampling draws: proposal v = i Kp + k of datapoint b sits in row
+// (i B + b) Kp + k of the [(i b k)] decoder outputs; the first K of the Kp draws are kept
+__global__ void k_lair_row_map(int32_t B, int32_t K, int32_t Kp, const int64_t* __restrict__ draws, int64_t* __restrict__ out) {
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < (int64_t)B * K; n += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = n / K, j = n - b * K;
+    const int64_t v = draws[b * Kp + j];
+    out[n] = ((v / Kp) * B + b) * Kp + v % Kp;
+  }
+}
+
+extern "C" int dmv_lair_row_map(int32_t B, int32_t K, int32_t Kp, const int64_t* draws, int64_t* row_map, void* stream) {
+  if (B < 1 || K < 1 || Kp < K || !draws || !row_map) return DMV_E_BADARG;
+  hipLaunchKernelGGL(k_lair_row_map, dim3(grid_for((int64_t)B * K, 256)), dim3(256), 0, (hipStream_t)stream, B, K, Kp, draws,
+                     row_map);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
 extern "C" int dmv_dropout_masks(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset,
                                  const uint64_t* offset_base, void* stream) {
   if (!keep || n < 0 || !(p >= 0.f && p < 1.f)) return DMV_E_BADARG;

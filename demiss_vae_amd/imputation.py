@@ -235,9 +235,9 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
             draw = torch.empty((B, Kp), dtype=torch.int64, device=dev)
             seed, off = rng.next_offset(B * Kp)
             L.check(lib.dmv_categorical_draw(B, I * Kp, Kp, L.ptr(logits), None, seed, off, rng.base_ptr(), L.ptr(draw), st))
-        draw = draw[:, :K]                                                       # keep the first K (:521-524)
-        i_sel, k_sel = draw // Kp, draw % Kp
-        row_map = ((i_sel * B + torch.arange(B, device=dev)[:, None]) * Kp + k_sel).reshape(-1).contiguous()
+        # keep the first K draws (:521-524); rows of the chosen proposals in the (i, b, k)-ordered decoder outputs
+        row_map = torch.empty(B * K, dtype=torch.int64, device=dev)
+        L.check(lib.dmv_lair_row_map(B, K, Kp, L.ptr(draw), L.ptr(row_map), st))
         clip = (cmin is not None or cmax is not None)
         last = (t == num_iterations - 1) and not resample_final_imps
         Xc = _tail(dims, dec_out, row_map, Xc, Mu, noise_x[t] if noise_x is not None else None,

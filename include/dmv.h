@@ -275,6 +275,12 @@ int dmv_impute_tail(int64_t N, int32_t D, int32_t gen_dist, const float* dec, in
 int dmv_categorical_draw(int32_t B, int32_t P, int32_t K, const float* logits, const float* u, uint64_t seed,
                          uint64_t offset, const uint64_t* offset_base, int64_t* idx, void* stream);
 
+/* Rows of the proposal table selected by the resampling draws (the gather of gr_resampling,
+ * vgiwae/shared/vae_imputation.py:193-198, after keeping the first K draws, :521-524): draws int64 [B][Kp] hold proposal
+ * numbers v = i*Kp + k; row_map int64 [B*K] receives (i*B + b)*Kp + k, the row of that proposal in tensors ordered
+ * (i, b, k) such as the decoder outputs handed to dmv_impute_tail. */
+int dmv_lair_row_map(int32_t B, int32_t K, int32_t Kp, const int64_t* draws, int64_t* row_map, void* stream);
+
 /* keep[i] = 1 with probability 1-p (dropout masks of the residual blocks, neural_nets.py:65,70) */
 int dmv_dropout_masks(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_base,
                       void* stream);

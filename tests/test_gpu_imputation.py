@@ -158,3 +158,18 @@ def test_loglik_philox_large_K_consistency():
     # untrained networks give heavy-tailed weights, so two independent 25k-sample estimates agree only loosely
     assert (a - b).abs().mean().item() < 1.0
     assert tot.mean().item() > float(g["est_loglik"]) - 0.5            # more samples: a tighter bound in expectation
+
+
+def test_lair_row_map_bit_exact():
+    """rows of the resampled proposals: the index arithmetic of the reference's gather (vae_imputation.py:193-198 after
+    :521-524), bit for bit against the tensor formula"""
+    from demiss_vae_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    for B, K, r, I in ((7, 5, 0, 1), (64, 5, 1, 3), (300, 3, 2, 2)):
+        Kp = K + r
+        draws = torch.randint(0, I * Kp, (B, Kp), generator=g).cuda()
+        out = torch.empty(B * K, dtype=torch.int64, device="cuda")
+        L.check(L.lib().dmv_lair_row_map(B, K, Kp, L.ptr(draws), L.ptr(out), L.stream_ptr()))
+        d = draws[:, :K]
+        ref = (((d // Kp) * B + torch.arange(B, device="cuda")[:, None]) * Kp + d % Kp).reshape(-1)
+        assert torch.equal(out, ref)

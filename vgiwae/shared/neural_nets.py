@@ -70,8 +70,10 @@ class ResidualFCNetwork(nn.Module):
     def packed_net(self) -> dmv.PackedNet:
         """Fragment-ordered image of the current parameters (rebuilt if the parameters were replaced, e.g.
         by .to(device); refreshed in place when an optimiser step changed them)."""
-        lin = self._linears()
-        ws, bs = [l.weight for l in lin], [l.bias for l in lin]
+        lin = self.__dict__.get("_layer_cache")          # the layer objects never change; their parameters may
+        if lin is None:
+            lin = self.__dict__["_layer_cache"] = self._linears()
+        ws, bs = [l._parameters["weight"] for l in lin], [l._parameters["bias"] for l in lin]
         p = self._packed
         if p is None or any(a is not b for a, b in zip(p.weights + p.biases, ws + bs)):
             p = self._packed = dmv.PackedNet(self.net_dims(), ws, bs)
