@@ -64,6 +64,7 @@ class _Plan:
     looser: bool = False
     kl_analytic: bool = False
     grad: bool = True    # gradient mode at call time (inside an autograd function's forward it always reads "off")
+    reduce_mean: bool = False   # mvb2: return the means over (b, k) instead of the [B, K] objectives
 
 
 def _u8(M: torch.Tensor) -> torch.Tensor:
@@ -298,6 +299,8 @@ class _FusedObjective(torch.autograd.Function):
                 enc_obj = _combine(c, (0, 1, 0, 0, 0)) - _kl(c)
             else:
                 enc_obj = _combine(c, (0, 1, 1, -1, 0))
+            if plan.reduce_mean:
+                return gen_obj.mean(), enc_obj.mean()
             return gen_obj, enc_obj
         raise NotImplementedError(k)
 
@@ -314,6 +317,8 @@ class _FusedObjective(torch.autograd.Function):
 
         def per_sample(g_bg):
             """[B] or [B,G] upstream gradient -> per-sample weights [N] (rows (s, b, g)), divided by nz."""
+            if plan.reduce_mean:        # scalar gradient of a mean over (b, g): the same weight for every sample row
+                return g_bg.float().reshape(1).expand(S * B * G) * (1.0 / (nz * B * G))
             g = g_bg.reshape(1, B, -1).float()
             return (g / nz).expand(S, B, G).contiguous().reshape(-1)
 
@@ -373,7 +378,9 @@ class _FusedObjective(torch.autograd.Function):
                 dZ, _ = _dec_side(c, dec, wt, 0.0, 1.0, True, False)
                 if plan.kl_analytic:
                     p = _latent_params(kl=-1.0)
-                    g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, g_enc.float().contiguous())
+                    kl_w = g_enc.float().reshape(1, 1).expand(B, G) * (1.0 / (B * G)) if plan.reduce_mean \
+                        else g_enc.float().contiguous()
+                    g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, kl_w)
                 else:
                     p = _latent_params(prior=1.0, qown=-1.0, own_live=not plan.STL)
                     g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, None)
@@ -498,11 +505,13 @@ def estimate_multiple_elbo(dims, enc, dec, X, M, *, num_latent_samples=1, STL=Fa
 
 
 def mvb2_objectives(dims, enc, dec, Xt, M, *, num_latent_samples=1, STL=False, kl_analytic=False, eps=None,
-                    enc_keep=None, dec_keep=None):
+                    enc_keep=None, dec_keep=None, reduce_mean=False):
     """DeMissVAE: (generator objective, encoder objective), each [B, K].  Xt, M [B,K,D]; eps [nz,B,K,Zd].
-    Gradients: the first output reaches the decoder parameters only, the second the encoder parameters only."""
+    Gradients: the first output reaches the decoder parameters only, the second the encoder parameters only.
+    reduce_mean: the two means over (b, k) instead (what the training step needs; its backward then forms the
+    per-sample weights in one launch instead of three)."""
     assert not dims.q_is_mixture
-    plan = _Plan("mvb2", num_latent_samples, 1, STL=STL, kl_analytic=kl_analytic)
+    plan = _Plan("mvb2", num_latent_samples, 1, STL=STL, kl_analytic=kl_analytic, reduce_mean=reduce_mean)
     return _run(dims, plan, enc, dec, Xt, M, eps, enc_keep, dec_keep)
 
 

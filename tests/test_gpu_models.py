@@ -74,6 +74,17 @@ def test_mvb2_manual_step_matches_reference_grads():
     # the packed weights follow the optimiser update: a second evaluation differs from the first
     gen2, _ = model.estimate_mvb2_objectives(Xt.cuda(), Mk.cuda(), eps=eps.cuda())
     assert not torch.allclose(gen2, gen_obj)
+    # the training step's route: scalar means out of the pipeline, ascent on them (no negations); same gradients
+    model2 = _build("MVBVAEMargLogprob", spec, enc_p, dec_p, num_latent_samples=1, var_latent_STL=True, kl_analytic=False,
+                    mvb_objective=MVB_OBJECTIVE["mvb2"], marginal_eval_freq=5, latent_grid_steps=500)
+    gen_m, enc_m = model2.estimate_mvb2_objectives(Xt.cuda(), Mk.cuda(), eps=eps.cuda(), reduce_mean=True)
+    assert gen_m.dim() == 0 and enc_m.dim() == 0
+    torch.testing.assert_close(gen_m, gen_obj.mean().detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(enc_m, enc_obj.mean().detach(), rtol=1e-6, atol=1e-6)
+    model2._optimizers = model2.configure_optimizers()["optimizer"]
+    model2.mvb2_manual_optimisation_step(enc_m, gen_m, maximise=True)
+    assert gu.check_grads(g, "genc", _grads(model2.var_latent_network, spec.enc), 1e-4, 2e-6) > 0
+    assert gu.check_grads(g, "gdec", _grads(model2.generator_network, spec.dec), 1e-4, 2e-6) > 0
 
 
 def test_refit_test_step_matches_reference():

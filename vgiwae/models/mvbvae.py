@@ -46,11 +46,13 @@ class MVBVAE(VAE):
         ek, dk = self.dropout_masks(B * K, self.hparams.num_latent_samples * B * K)
         return {"enc_keep": ek, "dec_keep": dk}
 
-    def estimate_mvb2_objectives(self, Xt, M, eps=None):
+    def estimate_mvb2_objectives(self, Xt, M, eps=None, reduce_mean=False):
         dims, enc, dec = self.engine()
-        return self.estimator("mvb2_objectives")[0](dims, enc, dec, Xt, M, num_latent_samples=self.hparams.num_latent_samples,
-                                                    STL=self.hparams.var_latent_STL, kl_analytic=self.hparams.kl_analytic,
-                                                    eps=eps, **self._masks(Xt))
+        extra = {"reduce_mean": True} if (reduce_mean and self.fused) else {}
+        out = self.estimator("mvb2_objectives")[0](dims, enc, dec, Xt, M, num_latent_samples=self.hparams.num_latent_samples,
+                                                   STL=self.hparams.var_latent_STL, kl_analytic=self.hparams.kl_analytic,
+                                                   eps=eps, **self._masks(Xt), **extra)
+        return tuple(o.mean() for o in out) if (reduce_mean and not extra) else out
 
     def estimate_cvi_objective(self, Xt, M, eps=None):
         assert not self.hparams.kl_analytic, "Analytic KL not possible with the CVI objective"
@@ -69,14 +71,12 @@ class MVBVAE(VAE):
     def _objective_step(self, Xt, M, stage, optimise):
         kind = self.hparams.mvb_objective
         if kind is MVB_OBJECTIVE["mvb2"]:
-            gen_obj, enc_obj = self.estimate_mvb2_objectives(Xt, M)
-            gen_obj, enc_obj = gen_obj.mean(), enc_obj.mean()
-            gen_loss = -gen_obj
-            if optimise:
-                self.mvb2_manual_optimisation_step(-enc_obj, gen_loss)
+            gen_obj, enc_obj = self.estimate_mvb2_objectives(Xt, M, reduce_mean=True)
+            if optimise:     # ascent on the objectives = descent on the losses the reference passes (mvbvae.py:118-120)
+                self.mvb2_manual_optimisation_step(enc_obj, gen_obj, maximise=True)
             self.log(f"mvb/{stage}", enc_obj, on_step=True, on_epoch=True, prog_bar=False, logger=True)
             self.log(f"cvi/{stage}", gen_obj, on_step=True, on_epoch=True, prog_bar=False, logger=True)
-            return gen_loss
+            return -gen_obj.detach()
         if kind is MVB_OBJECTIVE["mvb"]:
             obj = self.estimate_mvb_objective(Xt, M).mean()
             self.log(f"mvb/{stage}", obj, on_step=True, on_epoch=True, prog_bar=False, logger=True)
