@@ -21,7 +21,7 @@ import torch
 
 from . import _lib as L
 from . import rng
-from .mlp import PackedNet, mlp_forward, make_keep_masks
+from .mlp import PackedNet, mlp_forward, make_keep_masks, pad32
 from .objectives import ModelDims, _u8
 
 
@@ -196,18 +196,21 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
     cmin = clip_min.to(dev).float().contiguous() if clip_min is not None else None
     cmax = clip_max.to(dev).float().contiguous() if clip_max is not None else None
     Z_all, lw_all = [], []
+    Me = Mu
+    if r > 0:
+        # prior components: mu = 0, sigma = 1 (vgiwae/shared/vae_imputation.py:419-441) as encoder-output rows, and the
+        # masks of the replenished proposals: the same in every iteration
+        ldE = pad32(enc.dims.out_dim)
+        rep = torch.zeros((B, r, ldE), dtype=torch.float32, device=dev)
+        rep[:, :, Zd:2 * Zd] = float(softplus_inverse(torch.tensor(1.0 - (1e-5 if dims.q_eps else 0.0), dtype=torch.float32)))
+        Me = torch.cat([Mu, Mu[:, :1].expand(B, r, D)], dim=1).contiguous()
     for t in range(num_iterations):
         enc_out = _encode_rows(dims, enc, Xc.reshape(B * K, D), Mu.reshape(B * K, D), _keep(enc, B * K, training, dev))
         ldE = enc_out.shape[1]
-        Xe, Me = Xc, Mu
+        Xe = Xc
         if r > 0:
-            # prior components: mu = 0, sigma = 1 (vgiwae/shared/vae_imputation.py:419-441)
-            rep = torch.zeros((B, r, ldE), dtype=torch.float32, device=dev)
-            one = torch.ones((), device=dev) - (1e-5 if dims.q_eps else 0.0)
-            rep[:, :, Zd:2 * Zd] = softplus_inverse(one)
             enc_out = torch.cat([enc_out.reshape(B, K, ldE), rep], dim=1).reshape(B * Kp, ldE).contiguous()
             Xe = torch.cat([Xc, Xc[:, :1].expand(B, r, D)], dim=1).contiguous()
-            Me = torch.cat([Mu, Mu[:, :1].expand(B, r, D)], dim=1).contiguous()
         # proposals z[i, b, k] ~ q(. | component (b, k))
         N = I * B * Kp
         scfg = _sample_cfg(dims, B * Kp, I, ldE)
