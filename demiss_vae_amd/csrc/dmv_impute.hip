@@ -159,28 +159,48 @@ struct DrawArgs {
   int64_t* idx;         // [B][K]
 };
 
+// The unnormalised probabilities exp(logit - max) are computed once per datapoint and staged in LDS (up to kDrawStage
+// of them; longer rows fall back to recomputing from global memory); every draw then walks the same running sum in the
+// same order as before, from LDS.
+constexpr int kDrawStage = 1024;
+
 __global__ void k_categorical_draw(DrawArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  __shared__ float stage[4][kDrawStage];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x * (blockDim.x >> 6) + wv;
   if (b >= a.B) return;
   const float* lw = a.logits + (int64_t)b * a.P;
+  const bool staged = a.P <= kDrawStage;
   float mx = -INFINITY;
   for (int p = lane; p < a.P; p += 64) mx = fmaxf(mx, lw[p]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   float se = 0.f;
-  for (int p = lane; p < a.P; p += 64) se += expf(lw[p] - mx);
+  for (int p = lane; p < a.P; p += 64) {
+    const float e = expf(lw[p] - mx);
+    if (staged) stage[wv][p] = e;
+    se += e;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+  __builtin_amdgcn_wave_barrier();      // one wave writes and reads its own stage row: LDS order within the wave
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the stores have landed before other lanes read them
   for (int k = lane; k < a.K; k += 64) {
     const float u = a.u ? a.u[(int64_t)b * a.K + k]
                         : dmv_philox_uniform(a.seed, a.offset + (a.offset_base ? a.offset_base[0] : 0ull) + (uint64_t)b * a.K + k);
     const float target = u * se;
     float c = 0.f;
     int pick = a.P - 1;
-    for (int p = 0; p < a.P; ++p) {
-      c += expf(lw[p] - mx);
-      if (c > target) { pick = p; break; }
+    if (staged) {
+      for (int p = 0; p < a.P; ++p) {
+        c += stage[wv][p];
+        if (c > target) { pick = p; break; }
+      }
+    } else {
+      for (int p = 0; p < a.P; ++p) {
+        c += expf(lw[p] - mx);
+        if (c > target) { pick = p; break; }
+      }
     }
     a.idx[(int64_t)b * a.K + k] = pick;
   }

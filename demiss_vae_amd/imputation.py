@@ -230,7 +230,11 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
         terms = torch.empty((5, N), dtype=torch.float32, device=dev)
         L.check(lib.dmv_obj_terms(C.byref(cfg), L.Q_IMPUTATION, Kp, L.ptr(dec_out), dec_out.shape[1], L.ptr(Xe), L.ptr(Me),
                                   L.ptr(Z), Zd, L.ptr(enc_out), L.ptr(terms), None, st))
-        log_w = terms[0] + terms[2] - terms[4]                                   # [(i b k)]
+        # log_w = terms[0] + terms[2] - terms[4], rows (i b k): the bound kernel writes it as a by-product
+        log_w = torch.empty(N, dtype=torch.float32, device=dev)
+        per_b = torch.empty(B, dtype=torch.float32, device=dev)
+        L.check(lib.dmv_obj_bound(C.byref(cfg), L.BOUND_LSE, L.Q_IMPUTATION, 0, 0, None, L.ptr(terms), L.ptr(log_w), L.ptr(per_b),
+                                  None, None, None, None, st))
         logits = log_w.reshape(I, B, Kp).permute(1, 0, 2).reshape(B, I * Kp).contiguous()   # 'i b k -> b (i k)'
         if idx is not None:
             draw = idx[t].to(dev, torch.int64).t().contiguous()                 # [B, K+r]
