@@ -62,7 +62,7 @@ def missiwae_step(device, name, B, D, Zd, enc_shape, dec_shape, C=5, dropout=0.0
 
 
 def iwae_step(device, B, I=5, *, name="UCI-gas", D=8, Zd=16, enc_shape=(16, 32, 2, 256), dec_shape=(16, 16, 2, 256),
-              gen_dist="normal_with_eps", mask_concat=True):
+              gen_dist="normal_with_eps", mask_concat=True, graph=False):
     """MissIWAE training step, Adam included; by default on UCI-gas shapes
     (configs/uci_gas/compare/mis50/iwae_i5_encm_stl.yaml)."""
     from oracle.recipes import NetSpec, make_batch
@@ -81,7 +81,15 @@ def iwae_step(device, B, I=5, *, name="UCI-gas", D=8, Zd=16, enc_shape=(16, 32, 
         (-bound).backward()
         opt.step()
 
-    t = _sync_time(step, 30, 10)
+    if graph:       # the whole step recorded once and replayed (library noise stays fresh through its device counter)
+        from .graph import GraphedStep
+        for _ in range(3):
+            step()
+        replay = GraphedStep(step, nets=(enc, dec))
+        t = _sync_time(replay, 200, 20)
+        name = name + " (HIP-graph replay)"
+    else:
+        t = _sync_time(step, 30, 10)
     macs = lambda sp: sum(n * k for n, k in sp.layer_shapes())
     flops = 3 * 2 * B * (macs(enc_s) + I * macs(dec_s))
     return {"workload": f"{name} MissIWAE I={I} STL step incl. Adam, B={B}", "ms_per_step": round(t * 1e3, 4),

@@ -20,6 +20,9 @@ def main():
     for B in (512, 4096, 32768):
         out["gas_missiwae"].append(E.iwae_step(dev, B))
         print(out["gas_missiwae"][-1], flush=True)
+    for B in (512, 4096):       # launch-bound sizes again, replayed from a recording (what the runner does)
+        out["gas_missiwae"].append(E.iwae_step(dev, B, graph=True))
+        print(out["gas_missiwae"][-1], flush=True)
     # MFMA-sized 784-d layers: NOT a reference configuration (its image models are convolutional)
     out["synthetic_784_h512"] = []
     for B in (200, 4096):
