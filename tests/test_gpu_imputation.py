@@ -74,6 +74,16 @@ def test_lair_device_draws_match_inverse_cdf():
     ref = core.inverse_cdf_categorical(logits, u)
     # fp32 vs fp64 cumulative sums can disagree only when u sits on a bin edge
     assert (idx.cpu() != ref).float().mean().item() < 5e-3
+    # rows longer than one wave (several strides of the staging loop) and longer than the LDS stage (fallback path)
+    for B3, P3, K3 in ((9, 700, 70), (5, 1500, 12)):
+        lg3 = make_noise(8, B3, P3) * 2
+        u3 = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).random((B3, K3)).astype(np.float32))
+        d3 = torch.empty((B3, K3), dtype=torch.int64, device="cuda")
+        lg3g, u3g = lg3.cuda(), u3.cuda()
+        L.check(L.lib().dmv_categorical_draw(B3, P3, K3, L.ptr(lg3g), L.ptr(u3g), 0, 0, None, L.ptr(d3), L.stream_ptr()))
+        ref3 = core.inverse_cdf_categorical(lg3, u3)
+        assert ((d3.cpu() - ref3).abs() > 1).float().mean().item() == 0.0       # at most the neighbouring bin, on an edge
+        assert (d3.cpu() != ref3).float().mean().item() < 2e-2
     # Philox path: empirical frequencies follow softmax(logits)
     B2, P2, K2 = 4, 6, 64
     lg2 = (make_noise(7, 1, P2) * 1.5).expand(B2, P2).contiguous().cuda()
