@@ -278,8 +278,10 @@ def estimate_loglik(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, nu
     (vgiwae/test/refit_encoder_using_iwae_and_estimate_loglik.py:189-222), streamed over K in chunks with an
     online (max, sum-exp) so that no [K, B, .] tensor is materialised.
 
-    Stratified encoders are sampled without stratification (vgiwae/models/vae.py:298-301): the component of each
-    draw comes from comp_idx [K, B] (parity) or from device categorical draws.  eps [K, B, Zd] optional.
+    Mixture encoders are sampled ancestrally: a stratified one thereby "without stratification"
+    (vgiwae/models/vae.py:298-301), a reparametrised one as its own rsample does in the forward direction
+    (vgiwae/shared/reparametrized_mixture_same_family.py:27-58); both share one parameter layout.  The component of
+    each draw comes from comp_idx [K, B] (parity) or from device categorical draws.  eps [K, B, Zd] optional.
     return_state=True returns the running (max, sum) so ranks that shard K can combine them
     (parallel.lse_allreduce); k_total is then the global K."""
     B, D = X.shape
@@ -291,7 +293,7 @@ def estimate_loglik(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, nu
     in_mode = L.IN_CONCAT_MASKED if dims.encoder_use_mis_mask else L.IN_MASKED
     enc_out, _ = mlp_forward(enc, Xc, D, B, in_mode=in_mode, D=D, m=Mu, ldm=D, save=False)
     ldE = enc_out.shape[1]
-    mixture = dims.q_is_mixture
+    mixture = dims.q_is_mixture or dims.q_is_reparam
     run_max = torch.full((B,), float("-inf"), dtype=torch.float32, device=dev)
     run_sum = torch.zeros(B, dtype=torch.float32, device=dev)
     if mixture:

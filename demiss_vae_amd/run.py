@@ -486,6 +486,20 @@ def next_version_dir(exp_dir):
     return os.path.join(base, f"version_{n}")
 
 
+def run_version_dir(exp_dir):
+    """next_version_dir, chosen once per job: rank 0 picks and creates the directory, the other ranks are told its
+    name (a rank that looked later would find rank 0's directory in place and move on to the next number)"""
+    if P.world() == 1:
+        return next_version_dir(exp_dir)
+    import torch.distributed as dist
+    box = [None]
+    if P.rank() == 0:
+        box[0] = next_version_dir(exp_dir)
+        os.makedirs(box[0], exist_ok=True)
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 def save_checkpoint(model, path, model_config=None, extra=None):
     """state_dict + the primitive hyper-parameters + the YAML node that rebuilds the model: tensors and plain
     containers only, so `torch.load(weights_only=True)` reads it back."""
@@ -575,12 +589,14 @@ def main(argv=None, log=print):
         model = instantiate(cfg["model"])
         model_config = cfg["model"]
     seed_everything(cfg["seed_everything"])      # same generator state at the start of fitting whatever was built
-    out = next_version_dir(exp_dir)
+    out = run_version_dir(exp_dir)
     ckpt = None
     if P.rank() == 0:
-        ckpt = Checkpointer(os.path.join(out, "checkpoints"), model, model_config,
-                            keep_best=bool(cfg.get("add_checkpoint_callback", False)),
-                            epochs=cfg.get("save_custom_epochs"), steps=cfg.get("save_custom_steps"))
+        # snapshots at chosen epochs / steps belong to the checkpoint callback (train.py:66-79): none without it
+        keep = bool(cfg.get("add_checkpoint_callback", False))
+        ckpt = Checkpointer(os.path.join(out, "checkpoints"), model, model_config, keep_best=keep,
+                            epochs=cfg.get("save_custom_epochs") if keep else (),
+                            steps=cfg.get("save_custom_steps") if keep else ())
     history = fit(model, datamodule, trainer_cfg, log=log, checkpointer=ckpt, log_dir=out)
     results = {}
     if refit and cfg.get("run_test", True):

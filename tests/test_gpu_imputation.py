@@ -147,6 +147,30 @@ def test_loglik(name):
     assert abs(val.item() - float(g["est_loglik"])) < 1e-4 * max(1.0, abs(float(g["est_loglik"])))
 
 
+@pytest.mark.parametrize("name", [n for n in gu.names("reparam_") if str(gu.load(n)["cls"]) != "VAE" and int(gu.load(n)["nz"]) == 1])
+def test_loglik_reparametrised_mixture_encoder(name):
+    """The streaming estimator with a reparametrised-mixture encoder: the reference's `standard` refit class rsamples
+    the real mixture (test/refit_encoder_using_iwae_and_estimate_loglik.py:193-198), which in the forward direction is
+    ancestral sampling.  With the reference's recorded component draws and noise the streamed value must equal the
+    reference's IWAE bound of the same case (a proposal built from component 0 alone would be off by whole nats)."""
+    import dataclasses
+    import gpu_util as G
+    from demiss_vae_amd import imputation as imp
+    g = gu.load(name)
+    spec, enc_p, dec_p = gu.model_case(g)
+    q = "reparam_with_eps" if bool(g["with_eps"]) else "reparam"
+    dims = dataclasses.replace(G.model_dims(spec), q_dist=q)
+    enc = G.packed_net(spec.enc, enc_p, requires_grad=False)
+    dec = G.packed_net(spec.dec, dec_p, requires_grad=False)
+    X, M = (t.cuda() for t in gu.batch_of(g))
+    eps, comp = torch.from_numpy(g["eps"]), torch.from_numpy(g["comp_idx"])          # [1, I, B, C, Zd], [1, I, B]
+    I = int(g["I"])
+    own = torch.gather(eps, 3, comp[..., None, None].expand(*comp.shape, 1, spec.Zd)).squeeze(3)
+    val, _ = imp.estimate_loglik(dims, enc, dec, X, M, num_importance_samples=I, chunk=3, eps=own[0].cuda(),
+                                 comp_idx=comp[0].cuda())
+    np.testing.assert_allclose(val.item(), float(g["bound"]), rtol=1e-5)
+
+
 def test_loglik_philox_large_K_consistency():
     """K = 50 000 with device noise: two disjoint halves of the samples combine (max / sum-exp) to the estimate
     over all of them, and agree with each other within Monte-Carlo error."""

@@ -56,24 +56,29 @@ def estimate_iwelbo(model, batch, var_latent_STL: bool = False, var_latent_DREG:
                     sample_stratifieddistr_without_stratification_norsample=False, eps=None, comp_idx=None):
     """Batch-mean IWAE bound (vgiwae/models/iwae.py:125-154).
 
-    With gradients enabled this is the fused training pipeline.  Under no_grad with a large number of
-    importance samples, or for a stratified encoder sampled without stratification (the refit test step),
-    it is the streaming K-sample log-likelihood estimator."""
+    With gradients enabled this is the fused training pipeline.  The streaming K-sample estimator (no [K, B, .] tensor,
+    K folded chunk by chunk into a running logsumexp) takes over only where it computes the same estimator:
+      * a stratified encoder that the caller asks to sample as a plain mixture (the flag, vgiwae/models/vae.py:298-301;
+        the reference's own call raises for any other family, here the flag is ignored for them);
+      * under no_grad with >= 1024 importance samples, for families whose own sampling is ancestral anyway (a single
+        Gaussian or a reparametrised mixture).  A stratified encoder without the flag keeps its one-draw-per-component
+        sampling, and a network with live dropout keeps its masks: both stay on the non-streaming pipeline."""
     from demiss_vae_amd.imputation import estimate_loglik
     X, M = batch[:2]
     m = _inner(model)
     dims, enc, dec = m.engine()
-    streaming = sample_stratifieddistr_without_stratification_norsample or \
-        (not torch.is_grad_enabled() and num_latent_samples == 1 and num_importance_samples >= 1024)
-    if streaming and m.fused:
-        assert num_latent_samples == 1, "the streaming estimator takes one outer sample"
+    unstratified = sample_stratifieddistr_without_stratification_norsample and dims.q_is_mixture
+    if unstratified:
+        assert not torch.is_grad_enabled(), "Cannot use stratifieddistr_without_stratification_norsample with gradients."
+    dropout_live = m.fused and m.training and (enc.dims.dropout > 0 or dec.dims.dropout > 0)
+    big = not torch.is_grad_enabled() and num_importance_samples >= 1024 and not dims.q_is_mixture
+    if m.fused and num_latent_samples == 1 and not dropout_live and (unstratified or big):
         val, _ = estimate_loglik(dims, enc, dec, X, M, num_importance_samples=num_importance_samples, eps=eps,
                                  comp_idx=comp_idx)
         return val
-    if sample_stratifieddistr_without_stratification_norsample and dims.q_is_mixture:
-        # convolutional trunks (caller-network engine, all samples in one pass): a stratified mixture sampled as a
-        # plain mixture is the ancestrally sampled family with the same parameter layout
-        assert not torch.is_grad_enabled()
+    if unstratified:
+        # all samples in one pass (convolutional trunks; residual MLPs with live dropout): a stratified mixture sampled
+        # as a plain mixture is the ancestrally sampled family with the same parameter layout
         import dataclasses
         dims = dataclasses.replace(dims, q_dist=dims.q_dist.replace("stratified", "reparam"))
     fn, fused = m.estimator("estimate_iwelbo")

@@ -85,7 +85,9 @@ class RefitEncoderUsingIWAE(LightningModule, PLEstimateTotalTrainSteps):
             elbo = estimate_iwelbo(self, batch, var_latent_STL=h.var_latent_STL, var_latent_DREG=h.var_latent_DREG,
                                    num_latent_samples=h.num_test_latent_samples,
                                    num_importance_samples=h.num_test_importance_samples,
-                                   sample_stratifieddistr_without_stratification_norsample=True, eps=eps, comp_idx=comp_idx)
+                                   sample_stratifieddistr_without_stratification_norsample=(
+                                       h.refit_encoder_class is RefitEncoderClass.stratified),
+                                   eps=eps, comp_idx=comp_idx)
         self.log("est_loglik/test", elbo, on_step=True, on_epoch=True, prog_bar=False, logger=True)
         return elbo
 

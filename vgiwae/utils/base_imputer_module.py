@@ -57,9 +57,14 @@ class ImputerModuleBase(LightningModule):
         if mode == "dataset":
             if stage not in ("train", "val"):
                 raise NotImplementedError(f"Invalid stage={stage}")
-            core = self.datamodule.train_data_core
-            return (torch.as_tensor(core.data_min * 1.5, device=X.device, dtype=torch.float32),
-                    torch.as_tensor(core.data_max * 1.5, device=X.device, dtype=torch.float32))
+            # built once per device: a host-to-device copy inside the step could not be recorded in a HIP graph
+            cached = getattr(self, "_dataset_clip", None)
+            if cached is None or cached[0].device != X.device:
+                core = self.datamodule.train_data_core
+                cached = (torch.as_tensor(core.data_min * 1.5, device=X.device, dtype=torch.float32),
+                          torch.as_tensor(core.data_max * 1.5, device=X.device, dtype=torch.float32))
+                self._dataset_clip = cached
+            return cached
         if mode == "batch":
             # 1.5 x the per-dimension range of the observed values of this batch
             M = imputed_batch[1][:, 0]
