@@ -79,6 +79,7 @@ SIGNATURES = {
     "dmv_grid_marginal": (C.c_int, [_I32, _I32, _I64, _P, _I64, _P, _I32, _P, _P, _P, _P, _P, _P]),
     "dmv_opt_ws_floats": (_SZ, [_I32, _P]),
     "dmv_opt_adam_step": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _SZ, _P, _P]),
+    "dmv_opt_adam_step_static": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _P]),
     "dmv_grid_divergences": (C.c_int, [_I32, _I32, _I32, _I64, _P, _P, _P, _F, _I32, _P, _P, _P, _I32, _P, _P, _P, _P]),
     "dmv_lse_update": (C.c_int, [_I32, _I64, _P, _I32, _P, _P, _P]),
     "dmv_rows_gather": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),

@@ -14,6 +14,7 @@
 // replays against the same gradient addresses without host copies.  Learning rates and step counters are read from
 // device memory: schedulers and replays change them without re-recording.
 #include "dmv_common.h"
+#include <mutex>
 
 namespace {
 
@@ -170,13 +171,12 @@ extern "C" size_t dmv_opt_ws_floats(int32_t n, const int64_t* numel) {
   return (sizeof(OptState) + 3) / 4 + kSub * chunks + 1;
 }
 
-extern "C" int dmv_opt_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
-                                 float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
-                                 const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm,
-                                 float* ws, size_t ws_floats, float* norm_out, void* stream) {
-  if (n < 1 || n > kMaxT || n_groups < 1 || n_groups > kMaxG) return DMV_E_UNSUPPORTED;
-  if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !group_of || !groups || !ws) return DMV_E_BADARG;
-  if (ws_floats < dmv_opt_ws_floats(n, numel) || dmv_opt_ws_floats(n, numel) == 0) return DMV_E_WORKSPACE;
+// Both entry points: argument checks, the tables, the three launches.  ws: a device address with room for
+// dmv_opt_ws_floats(n, numel) floats (the caller's workspace, or this GPU's copy of the static array below).
+static int adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
+                     float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
+                     const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm,
+                     float* ws, float* norm_out, void* stream) {
   OptTable t;
   t.n = n;
   int chunks = 0;
@@ -219,4 +219,75 @@ extern "C" int dmv_opt_adam_step(int32_t n, float* const* params, const float* c
   hipLaunchKernelGGL(k_opt_apply, dim3((unsigned)(kSub * chunks)), dim3(kQuarter / 4), 0, s, t, gr, st);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
+}
+
+static int check_tables(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, const int64_t* numel, const int32_t* group_of, int32_t n_groups,
+                        const DmvAdamGroup* groups) {
+  if (n < 1 || n > kMaxT || n_groups < 1 || n_groups > kMaxG) return DMV_E_UNSUPPORTED;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !group_of || !groups) return DMV_E_BADARG;
+  return DMV_OK;
+}
+
+extern "C" int dmv_opt_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
+                                 float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
+                                 const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm,
+                                 float* ws, size_t ws_floats, float* norm_out, void* stream) {
+  const int rc = check_tables(n, params, grads, exp_avg, exp_avg_sq, numel, group_of, n_groups, groups);
+  if (rc) return rc;
+  if (!ws) return DMV_E_BADARG;
+  if (ws_floats < dmv_opt_ws_floats(n, numel) || dmv_opt_ws_floats(n, numel) == 0) return DMV_E_WORKSPACE;
+  return adam_step(n, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq, numel, group_of, n_groups, groups, max_norm,
+                   ws, norm_out, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// The same step for callers that cannot allocate: the workspace (clip coefficient, bias corrections, partial sums of
+// squares) lives in a file-scope device array instead of a caller buffer.  Every GPU that runs the library holds its
+// own copy of the array at its own address until the process ends; `scratch` below is only the host-side handle of
+// the symbol, never a device address: the address on a GPU comes from hipGetSymbolAddress, looked up once per device
+// (with that device current) and kept.
+// ------------------------------------------------------------------------------------------
+static __device__ __align__(256) float scratch[DMV_OPT_STATIC_WS_FLOATS];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_lock;
+float* g_scratch_ptr[kMaxDevices];   // per device: where that GPU keeps its copy of `scratch` (null: not looked up yet)
+
+// Device address of the current device's copy of `scratch`; > 0: a hipError_t, < 0: DMV_E_*.
+int scratch_address(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= kMaxDevices) return DMV_E_UNSUPPORTED;
+  std::lock_guard<std::mutex> hold(g_scratch_lock);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return (int)e;
+    if (!p) return DMV_E_BADARG;
+    g_scratch_ptr[dev] = (float*)p;
+  }
+  *out = g_scratch_ptr[dev];
+  return DMV_OK;
+}
+}  // namespace
+
+extern "C" int dmv_opt_adam_step_static(int32_t n, float* const* params, const float* const* grads,
+                                        float* const* exp_avg, float* const* exp_avg_sq, float* const* max_exp_avg_sq,
+                                        const int64_t* numel, const int32_t* group_of, int32_t n_groups,
+                                        const DmvAdamGroup* groups, float max_norm, float* norm_out, void* stream) {
+  const int rc = check_tables(n, params, grads, exp_avg, exp_avg_sq, numel, group_of, n_groups, groups);
+  if (rc) return rc;
+  const size_t need = dmv_opt_ws_floats(n, numel);
+  if (need == 0) return DMV_E_BADARG;
+  if (need > (size_t)DMV_OPT_STATIC_WS_FLOATS) return DMV_E_WORKSPACE;   // more parameters than the static array serves
+  float* ws = nullptr;
+  const int rs = scratch_address(&ws);
+  if (rs) return rs;
+  // nothing in the array has to start at zero: k_opt_sumsq writes every partial sum k_opt_prep reads, and k_opt_prep
+  // writes the whole state block before k_opt_apply reads it, on the same stream
+  return adam_step(n, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq, numel, group_of, n_groups, groups, max_norm,
+                   ws, norm_out, stream);
 }

@@ -321,6 +321,22 @@ int dmv_opt_adam_step(int32_t n, float* const* params, const float* const* grads
                       const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm, float* ws,
                       size_t ws_floats, float* norm_out, void* stream);
 
+/* dmv_opt_adam_step for callers that cannot allocate device memory or bring a workspace (code running under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments
+ * minus ws / ws_floats, same kernels, same results bit for bit; the workspace is a file-scope device array of
+ * DMV_OPT_STATIC_WS_FLOATS floats (256 KiB, held by every GPU the library runs on until the process ends).
+ *   - limit: dmv_opt_ws_floats(n, numel) <= DMV_OPT_STATIC_WS_FLOATS, i.e. about 16 300 chunks of 4096 parameters
+ *     (~66 M parameters); beyond it the call returns DMV_E_WORKSPACE and touches nothing;
+ *   - the call allocates and frees nothing; its first call on a device looks the array's address up
+ *     (hipGetSymbolAddress), so make that first call outside any capture;
+ *   - every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two host threads)
+ *     race on it.  Calls ordered on one stream are safe; nothing in the array needs clearing between calls. */
+#define DMV_OPT_STATIC_WS_FLOATS 65536
+int dmv_opt_adam_step_static(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
+                             float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
+                             const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm,
+                             float* norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
