@@ -273,7 +273,7 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
 # ------------------------------------------------------------------------------------------ log-likelihood
 @torch.no_grad()
 def estimate_loglik(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_importance_samples, chunk=4096,
-                    eps=None, comp_idx=None, k_offset=0, k_total=None, return_state=False):
+                    eps=None, comp_idx=None, k_shard=None, k_range=None, return_state=False, group=None):
     """K-sample importance-sampling estimate of log p(x_o) per datapoint
     (vgiwae/test/refit_encoder_using_iwae_and_estimate_loglik.py:189-222), streamed over K in chunks with an
     online (max, sum-exp) so that no [K, B, .] tensor is materialised.
@@ -282,8 +282,14 @@ def estimate_loglik(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, nu
     (vgiwae/models/vae.py:298-301), a reparametrised one as its own rsample does in the forward direction
     (vgiwae/shared/reparametrized_mixture_same_family.py:27-58); both share one parameter layout.  The component of
     each draw comes from comp_idx [K, B] (parity) or from device categorical draws.  eps [K, B, Zd] optional.
-    return_state=True returns the running (max, sum) so ranks that shard K can combine them
-    (parallel.lse_allreduce); k_total is then the global K."""
+
+    Sharding K over GPUs: k_shard = (rank, world) makes this rank fold only its contiguous share of the K samples and
+    combines the ranks' (max, sum-exp) states with two all-reduces of B floats (parallel.sharded_loglik); every rank
+    returns the full-K estimate.  Noise is addressed by the global sample number (explicit eps / comp_idx are sliced;
+    the Philox counter of latent element (k, b, j) is base + (k B + b) Zd + j whatever the chunking or the sharding),
+    so for a single-Gaussian encoder the sharded estimate equals the one-rank estimate up to summation order when the
+    ranks share the Philox seed.  k_range = (lo, hi) with return_state=True returns the raw state of those samples."""
+    from . import parallel as P
     B, D = X.shape
     K = num_importance_samples
     dev = X.device
@@ -294,8 +300,6 @@ def estimate_loglik(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, nu
     enc_out, _ = mlp_forward(enc, Xc, D, B, in_mode=in_mode, D=D, m=Mu, ldm=D, save=False)
     ldE = enc_out.shape[1]
     mixture = dims.q_is_mixture or dims.q_is_reparam
-    run_max = torch.full((B,), float("-inf"), dtype=torch.float32, device=dev)
-    run_sum = torch.zeros(B, dtype=torch.float32, device=dev)
     if mixture:
         Cn = dims.C
         logits = enc_out[:, 2 * Cn * Zd: 2 * Cn * Zd + Cn].contiguous()
@@ -303,38 +307,48 @@ def estimate_loglik(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, nu
         # whole rounds of the decoder kernel: 1024 one-wave tiles of 32 rows fill the chip once, and a launch that ends
         # a quarter into a round (4096 x 50 rows = 6.25 rounds) pays for the whole round
         chunk = max(1, (chunk * B // 32768) * 32768 // B)
-    for k0 in range(0, K, chunk):
-        Kc = min(chunk, K - k0)
-        N = Kc * B
-        cfg = L.DmvObjCfg()
-        cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, 1, 1, Kc, D, Zd
-        cfg.gen_dist, cfg.q_eps, cfg.x_per_component = L.GEN[dims.gen_dist], dims.q_eps, 0
-        comp = None
-        if mixture:
-            cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, Zd, dims.C * Zd, 2 * dims.C * Zd
-            if comp_idx is not None:
-                comp = comp_idx[k0:k0 + Kc].reshape(-1).to(dev, torch.int64).contiguous()
+    # counters for all K samples are reserved at once (every rank reserves the same ranges), a chunk uses its slice
+    z_seed, z_off = rng.next_offset(K * B * Zd) if eps is None else (0, 0)
+    c_seed, c_off = rng.next_offset(K * B) if (mixture and comp_idx is None) else (0, 0)
+
+    def fold(lo, hi):
+        run_max = torch.full((B,), float("-inf"), dtype=torch.float32, device=dev)
+        run_sum = torch.zeros(B, dtype=torch.float32, device=dev)
+        for k0 in range(lo, hi, chunk):
+            Kc = min(chunk, hi - k0)
+            N = Kc * B
+            cfg = L.DmvObjCfg()
+            cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, 1, 1, Kc, D, Zd
+            cfg.gen_dist, cfg.q_eps, cfg.x_per_component = L.GEN[dims.gen_dist], dims.q_eps, 0
+            comp = None
+            if mixture:
+                cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, Zd, dims.C * Zd, 2 * dims.C * Zd
+                if comp_idx is not None:
+                    comp = comp_idx[k0:k0 + Kc].reshape(-1).to(dev, torch.int64).contiguous()
+                else:
+                    d = torch.empty((B, Kc), dtype=torch.int64, device=dev)
+                    L.check(lib.dmv_categorical_draw(B, dims.C, Kc, L.ptr(logits), None, c_seed, c_off + k0 * B, rng.base_ptr(),
+                                                     L.ptr(d), st))
+                    comp = d.t().contiguous().reshape(-1)
             else:
-                d = torch.empty((B, Kc), dtype=torch.int64, device=dev)
-                seed, off = rng.next_offset(B * Kc)
-                L.check(lib.dmv_categorical_draw(B, dims.C, Kc, L.ptr(logits), None, seed, off, rng.base_ptr(), L.ptr(d), st))
-                comp = d.t().contiguous().reshape(-1)
-        else:
-            cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, 0, Zd, 0
-        Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
-        if eps is not None:
-            e = eps[k0:k0 + Kc].reshape(N, Zd).contiguous().float()
-            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(e), 0, 0, None, Zd, L.ptr(comp), L.ptr(Z), None, st))
-        else:
-            seed, off = rng.next_offset(N * Zd)
-            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, rng.base_ptr(), Zd, L.ptr(comp), L.ptr(Z), None, st))
-        dec_out, _ = mlp_forward(dec, Z, Zd, N, save=False)
-        terms = torch.empty((5, N), dtype=torch.float32, device=dev)
-        q_kind = L.Q_STRATIFIED if mixture else L.Q_OWN
-        L.check(lib.dmv_obj_terms(C.byref(cfg), q_kind, dims.C if mixture else 1, L.ptr(dec_out), dec_out.shape[1],
-                                  L.ptr(Xc), L.ptr(Mu), L.ptr(Z), Zd, L.ptr(enc_out), L.ptr(terms), None, st))
-        L.check(lib.dmv_lse_update(B, Kc, L.ptr(terms), 4 if mixture else 3, L.ptr(run_max), L.ptr(run_sum), st))
-    if return_state:
+                cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, 0, Zd, 0
+            Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
+            if eps is not None:
+                e = eps[k0:k0 + Kc].reshape(N, Zd).contiguous().float()
+                L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(e), 0, 0, None, Zd, L.ptr(comp), L.ptr(Z), None, st))
+            else:
+                L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, z_seed, z_off + k0 * B * Zd, rng.base_ptr(), Zd,
+                                              L.ptr(comp), L.ptr(Z), None, st))
+            dec_out, _ = mlp_forward(dec, Z, Zd, N, save=False)
+            terms = torch.empty((5, N), dtype=torch.float32, device=dev)
+            q_kind = L.Q_STRATIFIED if mixture else L.Q_OWN
+            L.check(lib.dmv_obj_terms(C.byref(cfg), q_kind, dims.C if mixture else 1, L.ptr(dec_out), dec_out.shape[1],
+                                      L.ptr(Xc), L.ptr(Mu), L.ptr(Z), Zd, L.ptr(enc_out), L.ptr(terms), None, st))
+            L.check(lib.dmv_lse_update(B, Kc, L.ptr(terms), 4 if mixture else 3, L.ptr(run_max), L.ptr(run_sum), st))
         return run_max, run_sum
-    per_b = run_max + torch.log(run_sum) - math.log(K if k_total is None else k_total)
+
+    if return_state:
+        return fold(*(k_range if k_range is not None else (0, K)))
+    assert k_range is None, "k_range goes with return_state=True (the caller combines the states)"
+    per_b = P.sharded_loglik(K, fold, shard=k_shard if k_shard is not None else (0, 1), group=group)
     return per_b.mean(), per_b

@@ -73,6 +73,40 @@ def lse_allreduce(run_max: torch.Tensor, run_sum: torch.Tensor, group=None):
     return m, s
 
 
+def sharded_loglik(K: int, fold, shard=None, group=None):
+    """Per-datapoint log (1/K) sum_k exp(log_w_k) with the K importance samples split over the ranks
+    (vgiwae/test/refit_encoder_using_iwae_and_estimate_loglik.py:189-222 computes it on one device).
+
+    fold(lo, hi) -> (run_max, run_sum): the streaming-logsumexp state of the samples lo <= k < hi, this rank's
+    contiguous share of the K (an empty share gives (-inf, 0)).  The states are combined with lse_allreduce; every
+    rank returns the same [B] tensor.  shard = (rank, world) overrides the process group's."""
+    r, w = (rank(), world()) if shard is None else shard
+    lo, hi = shard_slice(K, r, w)
+    m, s = fold(lo, hi)
+    if w > 1:
+        m, s = lse_allreduce(m, s, group)
+    return m + torch.log(s) - math.log(K)
+
+
+def allreduce_weighted_means(sums: dict, weights: dict, device=None, group=None):
+    """Means of quantities accumulated as (sum of weight * value, sum of weights) per key on every rank: one SUM
+    all-reduce of all of them (ranks that saw no batch contribute zeros; the key sets are united first)."""
+    if world() == 1:
+        return {k: float(sums[k]) / float(weights[k]) for k in sorted(sums)}
+    mine = sorted(sums)
+    every = [None] * world()
+    dist.all_gather_object(every, mine, group=group)
+    keys = sorted(set().union(*every))
+    if device is None and dist.get_backend(group) == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())      # RCCL reduces device tensors only
+    vec = torch.tensor([float(sums.get(k, 0.0)) for k in keys] + [float(weights.get(k, 0.0)) for k in keys],
+                       dtype=torch.float64, device=device)
+    all_reduce(vec, dist.ReduceOp.SUM, group)
+    vec = vec.cpu()
+    n = len(keys)
+    return {k: float(vec[i]) / float(vec[n + i]) for i, k in enumerate(keys)}
+
+
 def shard_slice(n: int, r: int = None, w: int = None):
     """Contiguous, near-equal shard [lo, hi) of n items for rank r of w."""
     r = rank() if r is None else r

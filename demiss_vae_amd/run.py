@@ -452,18 +452,46 @@ def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None, log_dir=No
     return history
 
 
-def test(model, datamodule, log=print):
+def test(model, datamodule, log=print, shard="auto"):
     """One pass over the test split through `test_step` (what trainer.test does for these models); returns the means
-    of everything logged, weighted by batch size."""
+    of everything logged, weighted by batch size.
+
+    Under torch.distributed the work is split over the ranks (one process per GPU):
+      points   batch i goes to rank i mod world; no exchange until one final SUM all-reduce of (sum, count) per metric;
+      samples  every rank sees every batch and folds its share of the K importance samples; the (max, sum-exp) states
+               are combined per batch with a logsumexp all-reduce of 2 x B floats (models with `can_shard_samples`);
+      auto     samples when the test split has fewer batches than ranks (small test sets), else points.
+    Device noise of batch i is drawn from counter range i << 40 of one Philox stream shared by all ranks, so for
+    single-Gaussian encoders the result does not depend on the number of ranks or on the mode."""
+    from . import rng
     datamodule.setup("test")
     model.eval()
+    loader = datamodule.test_dataloader()
+    r, w = P.rank(), P.world()
+    if shard == "auto":
+        shard = "samples" if (len(loader) < w and getattr(model, "can_shard_samples", False)) else "points"
+    assert shard in ("points", "samples"), shard
+    if shard == "samples" and w > 1:
+        assert getattr(model, "can_shard_samples", False), "this model's test step cannot split importance samples"
+        model.loglik_shard = (r, w)
+    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
     means = _Means()
+    device = None
     with torch.no_grad():
-        for i, batch in enumerate(datamodule.test_dataloader()):
+        for i, batch in enumerate(loader):
+            device = batch[0].device
+            if shard == "points" and i % w != r:
+                continue
+            rng.set_state(seed, i << 40)
             model._logged = {}
             model.test_step(batch, i)
             means.add(model._logged, weight=batch[0].shape[0])
-    out = means.result()
+    if hasattr(model, "loglik_shard"):
+        del model.loglik_shard
+    if shard == "points" and w > 1:
+        out = P.allreduce_weighted_means(means.sum, means.n, device=device)
+    else:
+        out = means.result()
     if P.rank() == 0:
         log(json.dumps(out))
     return out
@@ -601,7 +629,7 @@ def main(argv=None, log=print):
     results = {}
     if refit and cfg.get("run_test", True):
         log("Estimating test-log-likelihood.")
-        results = test(model, datamodule, log=log)
+        results = test(model, datamodule, log=log, shard=trainer_cfg.get("test_shard", "auto"))
     if P.rank() == 0:
         with open(os.path.join(out, "metrics.jsonl"), "w") as f:
             for row in history:

@@ -194,6 +194,42 @@ def test_iwae_config_then_refit_and_test_loglik(workdir):
     assert moved == {"var_latent_network"}
 
 
+def test_two_rank_sharded_loglik_equals_one_rank(workdir):
+    """The K-sample test log-likelihood under torch.distributed (two ranks sharing the GPU, gloo): test points dealt to
+    the ranks, or the importance samples of every batch split over the ranks and combined with the logsumexp
+    all-reduce, give the one-rank value (device noise is addressed by batch and global sample number, so the draws
+    are the same in every layout); with the reference's recorded noise the K-sharded estimator reproduces the
+    reference's est_loglik of the golden cases."""
+    import subprocess
+    import sys
+    ckdir = workdir / "logs/toy/iwae_i5/seed_m20220118_d20220118/lightning_logs/version_0/checkpoints"
+    if not (ckdir / "last.ckpt").exists():
+        launch(workdir, "iwae", IWAE_CONFIG)
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "loglik_shard_worker.py")
+    args = [worker, str(ckdir / "last.ckpt"), str(workdir / "data"), "4096"]
+    env = dict(os.environ, DMV_DIST_BACKEND="gloo", PYTHONPATH=os.pathsep.join(filter(None, [os.getcwd(), os.environ.get("PYTHONPATH")])))
+
+    def run_world(n):
+        cmd = [sys.executable] + args if n == 1 else \
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+             "--master-port", "29541"] + args
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=110, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")][0]
+
+    one, two = run_world(1), run_world(2)
+    assert one["world"] == 1 and two["world"] == 2
+    ref = one["points"]
+    assert math.isfinite(ref)
+    for mode in ("points", "samples", "auto"):
+        assert abs(one[mode] - ref) <= 1e-5 * abs(ref), (mode, one)
+        assert abs(two[mode] - ref) <= 1e-5 * abs(ref), (mode, two, ref)
+    for name in ("loglik_standard_K64", "loglik_stratified_K64", "loglik_standard_K4096"):
+        for res in (one, two):
+            got, want = res[name]
+            assert abs(got - want) < 1e-4 * max(1.0, abs(want)), (name, res["world"], got, want)
+
+
 def test_fid_metric_against_a_trained_encoder(workdir):
     """the *_FID classes: train a complete-data VAE, then a model whose FID is measured in its encoder's feature space"""
     vae = IWAE_CONFIG.replace("logs/toy/iwae_i5", "logs/toy/vae_complete").replace("vgiwae.models.IWAE", "vgiwae.models.VAE") \

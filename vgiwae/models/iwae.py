@@ -53,7 +53,7 @@ def log_weights_to_iwelbo(log_weights, *, create_Z_hook=None, var_latent_DREG=Fa
 
 def estimate_iwelbo(model, batch, var_latent_STL: bool = False, var_latent_DREG: bool = False,
                     num_latent_samples: int = 1, num_importance_samples: int = 1, *,
-                    sample_stratifieddistr_without_stratification_norsample=False, eps=None, comp_idx=None):
+                    sample_stratifieddistr_without_stratification_norsample=False, eps=None, comp_idx=None, k_shard=None):
     """Batch-mean IWAE bound (vgiwae/models/iwae.py:125-154).
 
     With gradients enabled this is the fused training pipeline.  The streaming K-sample estimator (no [K, B, .] tensor,
@@ -62,7 +62,9 @@ def estimate_iwelbo(model, batch, var_latent_STL: bool = False, var_latent_DREG:
         the reference's own call raises for any other family, here the flag is ignored for them);
       * under no_grad with >= 1024 importance samples, for families whose own sampling is ancestral anyway (a single
         Gaussian or a reparametrised mixture).  A stratified encoder without the flag keeps its one-draw-per-component
-        sampling, and a network with live dropout keeps its masks: both stay on the non-streaming pipeline."""
+        sampling, and a network with live dropout keeps its masks: both stay on the non-streaming pipeline.
+    k_shard = (rank, world), streaming estimator only: the importance samples are split over the ranks of the process
+    group and combined with a logsumexp all-reduce (demiss_vae_amd.imputation.estimate_loglik)."""
     from demiss_vae_amd.imputation import estimate_loglik
     X, M = batch[:2]
     m = _inner(model)
@@ -74,8 +76,9 @@ def estimate_iwelbo(model, batch, var_latent_STL: bool = False, var_latent_DREG:
     big = not torch.is_grad_enabled() and num_importance_samples >= 1024 and not dims.q_is_mixture
     if m.fused and num_latent_samples == 1 and not dropout_live and (unstratified or big):
         val, _ = estimate_loglik(dims, enc, dec, X, M, num_importance_samples=num_importance_samples, eps=eps,
-                                 comp_idx=comp_idx)
+                                 comp_idx=comp_idx, k_shard=k_shard)
         return val
+    assert k_shard is None or k_shard[1] == 1, "importance samples are sharded by the streaming estimator only"
     if unstratified:
         # all samples in one pass (convolutional trunks; residual MLPs with live dropout): a stratified mixture sampled
         # as a plain mixture is the ancestrally sampled family with the same parameter layout

@@ -78,8 +78,18 @@ class RefitEncoderUsingIWAE(LightningModule, PLEstimateTotalTrainSteps):
         self.log("elbo/val", elbo, on_step=True, on_epoch=True, prog_bar=False, logger=True)
         self.log("loss/val", -elbo, on_step=True, on_epoch=True, prog_bar=True, logger=True)
 
+    @property
+    def can_shard_samples(self):
+        """The K importance samples of a test batch can be split over GPUs: the streaming estimator computes them
+        (residual-MLP networks, one outer sample; see vgiwae.models.iwae.estimate_iwelbo)."""
+        h, m = self.hparams, self.model
+        stratified = h.refit_encoder_class is RefitEncoderClass.stratified
+        return bool(m.fused and h.num_test_latent_samples == 1 and not self.training and
+                    (stratified or (h.num_test_importance_samples >= 1024 and not m.model_dims().q_is_mixture)))
+
     def test_step(self, batch, batch_idx, eps=None, comp_idx=None) -> Optional[STEP_OUTPUT]:
-        """K-sample estimate of log p(x); a stratified encoder is sampled as a plain mixture (:189-222)."""
+        """K-sample estimate of log p(x); a stratified encoder is sampled as a plain mixture (:189-222).  The runner
+        sets `loglik_shard = (rank, world)` when the importance samples, not the test points, are split over GPUs."""
         h = self.hparams
         with torch.no_grad():
             elbo = estimate_iwelbo(self, batch, var_latent_STL=h.var_latent_STL, var_latent_DREG=h.var_latent_DREG,
@@ -87,7 +97,7 @@ class RefitEncoderUsingIWAE(LightningModule, PLEstimateTotalTrainSteps):
                                    num_importance_samples=h.num_test_importance_samples,
                                    sample_stratifieddistr_without_stratification_norsample=(
                                        h.refit_encoder_class is RefitEncoderClass.stratified),
-                                   eps=eps, comp_idx=comp_idx)
+                                   eps=eps, comp_idx=comp_idx, k_shard=getattr(self, "loglik_shard", None))
         self.log("est_loglik/test", elbo, on_step=True, on_epoch=True, prog_bar=False, logger=True)
         return elbo
 
