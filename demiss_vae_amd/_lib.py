@@ -16,7 +16,7 @@ ACT = {"relu": 0, "leaky_relu": 1, "tanh": 2, "sigmoid": 3}
 IN_PLAIN, IN_MASKED, IN_CONCAT, IN_CONCAT_MASKED = 0, 1, 2, 3
 GEN = {"normal": 0, "normal_with_eps": 1, "bern": 2, "bern_m1_p1": 3}
 Q_OWN, Q_STRATIFIED, Q_IMPUTATION = 0, 1, 2
-BOUND_LSE, BOUND_WEIGHTED = 0, 1
+BOUND_LSE, BOUND_WEIGHTED, BOUND_PER_COMPONENT, TERMS_ONLY = 0, 1, 2, -1
 
 
 class DmvNet(C.Structure):
@@ -36,6 +36,14 @@ class DmvLatentBwd(C.Structure):
                 ("base_w", C.c_float), ("kl_coef", C.c_float),
                 ("own_live", C.c_int32), ("mix_live", C.c_int32), ("use_zscale", C.c_int32),
                 ("mix_kind", C.c_int32)]
+
+
+class DmvObjFwd(C.Structure):
+    _fields_ = [("q_kind", C.c_int32), ("mix_C", C.c_int32), ("kind", C.c_int32), ("use_logpi", C.c_int32), ("dreg", C.c_int32),
+                ("coefA", C.c_float * 5), ("coefB", C.c_float * 5),
+                ("terms", C.c_void_p), ("comp_lp", C.c_void_p), ("log_w", C.c_void_p),
+                ("bound", C.c_void_p), ("mean_out", C.c_void_p), ("wgt", C.c_void_p), ("zscale", C.c_void_p), ("dlogit", C.c_void_p),
+                ("objA", C.c_void_p), ("objB", C.c_void_p), ("meanA_out", C.c_void_p), ("meanB_out", C.c_void_p)]
 
 
 class DmvAdamGroup(C.Structure):
@@ -67,9 +75,10 @@ SIGNATURES = {
     "dmv_obj_bound": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmv_obj_combine": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(_F), _P, _P, _P, _P]),
     "dmv_kl_std_normal": (C.c_int, [C.POINTER(DmvObjCfg), _P, _P, _P]),
-    "dmv_obj_backward_dec": (C.c_int, [C.POINTER(DmvObjCfg), _P, _I64, _P, _P, _P, _P, _F, _F, _P, _I64, _P]),
+    "dmv_obj_forward": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvObjFwd), _P, _I64, _P, _P, _P, _I64, _P, _P]),
+    "dmv_obj_backward_dec": (C.c_int, [C.POINTER(DmvObjCfg), _P, _I64, _P, _P, _P, _P, _P, _F, _F, _P, _I64, _P]),
     "dmv_obj_backward_latent": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvLatentBwd), _P, _P, _P, _I64, _P, _I64,
-                                          _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                          _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmv_obj_backward_dec_terms": (C.c_int, [C.POINTER(DmvObjCfg), _P, _I64, _P, _P, _P, _P, _P, _I64, _P]),
     "dmv_obj_backward_latent_terms": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _P, _P, _P, _I64, _P, _I64,
                                                 _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -120,6 +129,11 @@ def check(rc):
 def ptr(t):
     """Device address of a tensor (None -> NULL)."""
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def addr(t):
+    """Device address as an integer for pointer fields of ctypes structures (None -> NULL)."""
+    return None if t is None else t.data_ptr()
 
 
 def ptr_array(tensors):

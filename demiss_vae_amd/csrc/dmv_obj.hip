@@ -5,49 +5,14 @@
 // flattened).  See include/dmv.h for the encoder-output addressing.
 #include "dmv_common.h"
 #include "dmv_rng.h"
-
-#define LOG_SQRT_2PI 0.9189385332046727f
-
-struct QAddr {
-  int64_t sb, sg, raw_off, logit_off;
-  float eps;
-};
-
-__device__ __forceinline__ float q_mu(const float* enc, const QAddr& q, int64_t b, int g, int j) {
-  return enc[b * q.sb + g * q.sg + j];
-}
-__device__ __forceinline__ float q_sigma(const float* enc, const QAddr& q, int64_t b, int g, int j) {
-  return dmv_softplus(enc[b * q.sb + g * q.sg + q.raw_off + j]) + q.eps;
-}
-__device__ __forceinline__ float log_normal(float x, float mu, float sigma) {
-  const float d = x - mu;
-  return -(d * d) / (2.f * sigma * sigma) - dmv_log(sigma) - LOG_SQRT_2PI;
-}
-// -BCEWithLogits(l, v) = -((1 - v) l - logsigmoid(l)),  logsigmoid(l) = min(l, 0) - log1p(exp(-|l|))
-__device__ __forceinline__ float log_bern(float v, float l) {
-  const float ls = fminf(l, 0.f) - dmv_log1p_pos(dmv_exp(-fabsf(l)));
-  return -((1.f - v) * l - ls);
-}
-
-// sub-wave sum over R consecutive lanes (R power of two <= 64)
-template <int R>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = R / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-template <int R>
-__device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-  for (int o = R / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
+#include "dmv_objmath.h"
 
 // ------------------------------------------------------------------------------------------
 // z = mu + sigma * eps
 // ------------------------------------------------------------------------------------------
 struct SampleArgs {
   int64_t N;       // sample rows
+  int S;           // N / (B G): outer x importance samples
   int B, G, Zd;
   QAddr q;
   const float* enc;
@@ -60,19 +25,25 @@ struct SampleArgs {
   const uint64_t* offset_base;   // nullable device counter added to offset (advanced by the caller between replays)
 };
 
+// Launch geometry of the row kernels below: blockIdx.y = s (outer x importance sample), blockIdx.x * blockDim.y +
+// threadIdx.y = the (b, g) pair, threadIdx.x = position inside the row.  Rows of one s are consecutive in memory, so
+// consecutive threads touch consecutive addresses, and b, g come from one 32-bit division.
 __global__ void k_latent_sample(SampleArgs a) {
-  const int64_t total = a.N * a.ldz;
+  const int BG = a.B * a.G;
+  const int bg = blockIdx.x * blockDim.y + threadIdx.y;
+  if (bg >= BG) return;
+  const int64_t b = bg / a.G;
   const uint64_t off = a.offset + (a.offset_base ? a.offset_base[0] : 0ull);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = i / a.ldz;
-    const int j = (int)(i - n * a.ldz);
-    if (j >= a.Zd) { a.Z[i] = 0.f; if (a.eps_out) a.eps_out[i] = 0.f; continue; }
-    int g = (int)(n % a.G);
-    const int64_t b = (n / a.G) % a.B;
-    if (a.comp_idx) g = (int)a.comp_idx[n];
-    const float e = a.eps ? a.eps[i] : dmv_philox_normal(a.seed, off + (uint64_t)i);
-    if (a.eps_out) a.eps_out[i] = e;
-    a.Z[i] = q_mu(a.enc, a.q, b, g, j) + q_sigma(a.enc, a.q, b, g, j) * e;
+  for (int s = blockIdx.y; s < a.S; s += gridDim.y) {
+    const int64_t n = (int64_t)s * BG + bg;
+    const int g = a.comp_idx ? (int)a.comp_idx[n] : bg - (int)b * a.G;
+    for (int j = threadIdx.x; j < (int)a.ldz; j += blockDim.x) {
+      const int64_t i = n * a.ldz + j;
+      if (j >= a.Zd) { a.Z[i] = 0.f; if (a.eps_out) a.eps_out[i] = 0.f; continue; }
+      const float e = a.eps ? a.eps[i] : dmv_philox_normal(a.seed, off + (uint64_t)i);
+      if (a.eps_out) a.eps_out[i] = e;
+      a.Z[i] = q_mu(a.enc, a.q, b, g, j) + q_sigma(a.enc, a.q, b, g, j) * e;
+    }
   }
 }
 
@@ -122,7 +93,7 @@ __global__ void k_obj_terms(TermsArgs a) {
       for (int e = 0; e < 4; ++e) {
         const float lp = log_bern(a.gen_dist == DMV_GEN_BERN ? x4[e] : (x4[e] + 1.f) * 0.5f, l4[e]);
         gf += lp;
-        gm += ((m4 >> (8 * e)) & 0xffu) ? lp : 0.f;
+        gm += lp * (((m4 >> (8 * e)) & 0xffu) ? 1.f : 0.f);
       }
     }
   } else
@@ -138,7 +109,8 @@ __global__ void k_obj_terms(TermsArgs a) {
       lp = log_bern((x + 1.f) * 0.5f, dec[d]);
     }
     gf += lp;
-    gm += M[d] ? lp : 0.f;   // the reference multiplies by float(M): identical unless lp is not finite
+    gm += lp * (M[d] ? 1.f : 0.f);   // the product the reference forms (shared/iwae.py:20): a non-finite lp at a
+                                     // missing entry makes the row's log-weight NaN there and here alike
   }
   const float* z = a.Z + nn * a.ldz;
   float pr = 0.f, qo = 0.f;
@@ -362,7 +334,7 @@ __global__ void k_obj_combine(CombineArgs a) {
 // ------------------------------------------------------------------------------------------
 struct BwdDecArgs {
   int64_t N;
-  int B, G, D;
+  int B, G, D, S;
   int gen_dist, x_per_component;
   const float* dec;
   int64_t ld_dec;
@@ -370,73 +342,127 @@ struct BwdDecArgs {
   const uint8_t* M;
   const float* wgt;     // nullable
   const float* wgt_f;   // nullable: separate per-row weight of the unmasked term (wgt then weighs the masked one only)
+  const float* gb;      // nullable [B]: upstream gradient of each datapoint's bound, multiplied into the row weights
   const float* gscale;  // nullable device scalar
   float base_m, base_f;
   float* d_dec;
   int64_t ld_ddec;
 };
 
+// generic form: one thread per output element (row geometry of k_latent_sample: threadIdx.x walks the row)
 __global__ void k_obj_bwd_dec(BwdDecArgs a) {
+  const int BG = a.B * a.G;
+  const int bg = blockIdx.x * blockDim.y + threadIdx.y;
+  if (bg >= BG) return;
   const float gs = a.gscale ? a.gscale[0] : 1.f;
-  const int64_t total = a.N * a.ld_ddec;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = i / a.ld_ddec;
-    const int c = (int)(i - n * a.ld_ddec);
-    const bool normal = a.gen_dist <= DMV_GEN_NORMAL_EPS;
-    const int P = normal ? 2 * a.D : a.D;
-    if (c >= P) { a.d_dec[i] = 0.f; continue; }
-    const int d = c < a.D ? c : c - a.D;
-    const int g = (int)(n % a.G);
-    const int64_t b = (n / a.G) % a.B;
-    const int64_t xrow = a.x_per_component ? (b * a.G + g) : b;
-    const float x = a.X[xrow * a.D + d];
+  const int b = bg / a.G;
+  const int64_t xrow = a.x_per_component ? bg : b;
+  const float gbb = gs * (a.gb ? a.gb[b] : 1.f);
+  const bool normal = a.gen_dist <= DMV_GEN_NORMAL_EPS;
+  const int P = normal ? 2 * a.D : a.D;
+  for (int s = blockIdx.y; s < a.S; s += gridDim.y) {
+    const int64_t n = (int64_t)s * BG + bg;
     const float wm = a.wgt ? a.wgt[n] : 1.f;
-    const float coef = gs * ((a.M[xrow * a.D + d] ? wm * a.base_m : 0.f) + (a.wgt_f ? a.wgt_f[n] : wm) * a.base_f);
+    const float wf = a.wgt_f ? a.wgt_f[n] : wm;
     const float* dec = a.dec + n * a.ld_dec;
-    float gr;
-    if (normal) {
-      const float raw = dec[a.D + d];
-      const float s = dmv_softplus(raw) + (a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f);
-      const float df = x - dec[d];
-      if (c < a.D) gr = df / (s * s);
-      else gr = (df * df / (s * s * s) - 1.f / s) * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
-    } else {
-      const float v = a.gen_dist == DMV_GEN_BERN ? x : (x + 1.f) * 0.5f;
-      gr = v - dmv_sigmoid(dec[d]);
+    float* out = a.d_dec + n * a.ld_ddec;
+    for (int c = threadIdx.x; c < (int)a.ld_ddec; c += blockDim.x) {
+      if (c >= P) { out[c] = 0.f; continue; }
+      const int d = c < a.D ? c : c - a.D;
+      const float x = a.X[xrow * a.D + d];
+      const float coef = gbb * ((a.M[xrow * a.D + d] ? wm * a.base_m : 0.f) + wf * a.base_f);
+      float gr;
+      if (normal) {
+        const float raw = dec[a.D + d];
+        const float sg = dmv_softplus(raw) + (a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f);
+        const float df = x - dec[d];
+        if (c < a.D) gr = df / (sg * sg);
+        else gr = (df * df / (sg * sg * sg) - 1.f / sg) * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
+      } else {
+        const float v = a.gen_dist == DMV_GEN_BERN ? x : (x + 1.f) * 0.5f;
+        gr = v - dmv_sigmoid(dec[d]);
+      }
+      out[c] = coef * gr;
     }
-    a.d_dec[i] = coef * gr;
+  }
+}
+
+// Gaussian decoders with D % 4 == 0 and 16-byte aligned rows: thread q < D/4 of a row takes dimensions 4q .. 4q+3,
+// reads their means, raw scales, data (16 bytes each) and mask bytes once and writes both gradient quads; the
+// remaining threads of the row zero the padding columns.  Same arithmetic as the generic form.
+__global__ void k_obj_bwd_dec_normal4(BwdDecArgs a) {
+  const int BG = a.B * a.G;
+  const int bg = blockIdx.x * blockDim.y + threadIdx.y;
+  if (bg >= BG) return;
+  const float gs = a.gscale ? a.gscale[0] : 1.f;
+  const int b = bg / a.G;
+  const int64_t xrow = a.x_per_component ? bg : b;
+  const float gbb = gs * (a.gb ? a.gb[b] : 1.f);
+  const int D4 = a.D >> 2, W4 = (int)(a.ld_ddec >> 2);
+  const float eps = a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f;
+  for (int s = blockIdx.y; s < a.S; s += gridDim.y) {
+    const int64_t n = (int64_t)s * BG + bg;
+    const float wm = a.wgt ? a.wgt[n] : 1.f;
+    const float wf = a.wgt_f ? a.wgt_f[n] : wm;
+    const float* dec = a.dec + n * a.ld_dec;
+    f32x4* out = (f32x4*)(a.d_dec + n * a.ld_ddec);
+    for (int q = threadIdx.x; q < W4; q += blockDim.x) {
+      if (q < D4) {
+        const f32x4 mu = *(const f32x4*)(dec + 4 * q);
+        const f32x4 rw = *(const f32x4*)(dec + a.D + 4 * q);
+        const f32x4 x4 = *(const f32x4*)(a.X + xrow * a.D + 4 * q);
+        const uint32_t m4 = *(const uint32_t*)(a.M + xrow * a.D + 4 * q);
+        f32x4 gmu, grw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float coef = gbb * ((((m4 >> (8 * e)) & 0xffu) ? wm * a.base_m : 0.f) + wf * a.base_f);
+          const float sg = dmv_softplus(rw[e]) + eps;
+          const float df = x4[e] - mu[e];
+          gmu[e] = coef * (df / (sg * sg));
+          grw[e] = coef * ((df * df / (sg * sg * sg) - 1.f / sg) * (rw[e] > 20.f ? 1.f : dmv_sigmoid(rw[e])));
+        }
+        out[q] = gmu;
+        out[q + D4] = grw;
+      } else if (q + D4 < W4) {
+        out[q + D4] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
   }
 }
 
 // Bernoulli decoders with wide, aligned rows (D % 4 == 0, ld_ddec == ld_dec rows of whole float4): blockIdx.y
-// walks the rows, threads walk a row's float4 columns -- no per-element division, 16-byte accesses
+// walks the (b, g) pairs, threads walk a row's float4 columns -- no per-element division, 16-byte accesses
 __global__ void k_obj_bwd_dec_bern4(BwdDecArgs a) {
   const float gs = a.gscale ? a.gscale[0] : 1.f;
   const int D4 = a.D >> 2, W4 = (int)(a.ld_ddec >> 2);
-  for (int64_t n = blockIdx.y; n < a.N; n += gridDim.y) {
-    const int g = (int)(n % a.G);
-    const int64_t b = (n / a.G) % a.B;
-    const int64_t xrow = a.x_per_component ? (b * a.G + g) : b;
-    const float w = gs * (a.wgt ? a.wgt[n] : 1.f);
-    const float wf = a.wgt_f ? gs * a.wgt_f[n] : w;
-    const float* dec = a.dec + n * a.ld_dec;
+  const int BG = a.B * a.G;
+  for (int bg = blockIdx.y; bg < BG; bg += gridDim.y) {
+    const int b = bg / a.G;
+    const int64_t xrow = a.x_per_component ? bg : b;
+    const float gbb = gs * (a.gb ? a.gb[b] : 1.f);
     const float* X = a.X + xrow * a.D;
     const uint8_t* M = a.M + xrow * a.D;
-    f32x4* out = (f32x4*)(a.d_dec + n * a.ld_ddec);
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < W4; q += gridDim.x * blockDim.x) {
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
-      if (q < D4) {
-        const f32x4 l4 = *(const f32x4*)(dec + 4 * q);
-        const f32x4 x4 = *(const f32x4*)(X + 4 * q);
-        const uint32_t m4 = *(const uint32_t*)(M + 4 * q);
+    for (int s = 0; s < a.S; ++s) {
+      const int64_t n = (int64_t)s * BG + bg;
+      const float w = gbb * (a.wgt ? a.wgt[n] : 1.f);
+      const float wf = a.wgt_f ? gbb * a.wgt_f[n] : w;
+      const float* dec = a.dec + n * a.ld_dec;
+      f32x4* out = (f32x4*)(a.d_dec + n * a.ld_ddec);
+      for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < W4; q += gridDim.x * blockDim.x) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (q < D4) {
+          const f32x4 l4 = *(const f32x4*)(dec + 4 * q);
+          const f32x4 x4 = *(const f32x4*)(X + 4 * q);
+          const uint32_t m4 = *(const uint32_t*)(M + 4 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = a.gen_dist == DMV_GEN_BERN ? x4[e] : (x4[e] + 1.f) * 0.5f;
-          const float coef = (((m4 >> (8 * e)) & 0xffu) ? w * a.base_m : 0.f) + wf * a.base_f;
-          o[e] = coef * (v - dmv_sigmoid(l4[e]));
+          for (int e = 0; e < 4; ++e) {
+            const float v = a.gen_dist == DMV_GEN_BERN ? x4[e] : (x4[e] + 1.f) * 0.5f;
+            const float coef = (((m4 >> (8 * e)) & 0xffu) ? w * a.base_m : 0.f) + wf * a.base_f;
+            o[e] = coef * (v - dmv_sigmoid(l4[e]));
+          }
         }
+        out[q] = o;
       }
-      out[q] = o;
     }
   }
 }
@@ -467,19 +493,32 @@ struct BwdLatArgs {
   const float* comp_lp;       // [N][G] when base_qmix != 0
   const float* qmix;          // terms[4]
   const float* dlogit;        // nullable [B][G]
-  const float* gscale;        // nullable
+  const float* gb;            // nullable [B]: upstream gradient per datapoint, multiplied into every row weight and
+                              // into dlogit (not into dZ, which carries it already, nor into the KL term)
+  const float* gscale;        // nullable device scalar: multiplies what gb multiplies, and the KL term
   float* d_enc;               // same addressing as enc
+  // entries of d_enc that no (b, g, j) owns are zeroed here: zf_nseg segments of zf_len floats per datapoint, the
+  // first zf_used of each hold gradients
+  int zf_nseg, zf_len, zf_used;
 };
 
 __global__ void k_obj_bwd_latent(BwdLatArgs a) {
   const int per_b = a.G * (a.Zd + 1);
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)a.B * per_b) return;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // B * per_b < 2^31 (checked by the caller)
+  if (idx >= a.B * per_b) return;
   const int64_t b = idx / per_b;
-  const int rem = (int)(idx - b * per_b);
+  const int rem = idx - (int)b * per_b;
   const int gp = rem / (a.Zd + 1);
   const int j = rem - gp * (a.Zd + 1);
   const float gs = a.gscale ? a.gscale[0] : 1.f;
+  const float gbb = gs * (a.gb ? a.gb[b] : 1.f);
+  {
+    const int pad = a.zf_len - a.zf_used;
+    for (int e = rem; e < a.zf_nseg * pad; e += per_b) {
+      const int seg = e / pad;
+      a.d_enc[b * a.q.sb + (int64_t)seg * a.zf_len + a.zf_used + (e - seg * pad)] = 0.f;
+    }
+  }
   const bool strat = a.mix_kind == DMV_Q_STRATIFIED;
   const bool has_mix = a.base_qmix != 0.f;
 
@@ -498,18 +537,18 @@ __global__ void k_obj_bwd_latent(BwdLatArgs a) {
   if (j == a.Zd) {
     // ---- mixture logit (b, gp)
     if (!strat) return;
-    float acc = a.dlogit ? a.base_w * a.dlogit[b * a.G + gp] : 0.f;
+    float acc = a.dlogit ? a.base_w * gbb * a.dlogit[b * a.G + gp] : 0.f;
     if (has_mix && a.mix_live) {
       const float pi = expf(logpi(gp));
       for (int s = 0; s < a.S; ++s)
         for (int g = 0; g < a.G; ++g) {
           const int64_t n = ((int64_t)s * a.B + b) * a.G + g;
-          const float cw = a.base_qmix * (a.wgt_qmix ? a.wgt_qmix[n] : a.wgt ? a.wgt[n] : 1.f);
+          const float cw = a.base_qmix * gbb * (a.wgt_qmix ? a.wgt_qmix[n] : a.wgt ? a.wgt[n] : 1.f);
           const float r = expf(logpi(gp) + a.comp_lp[n * a.G + gp] - a.qmix[n]);
           acc += cw * (r - pi);
         }
     }
-    a.d_enc[b * a.q.sb + a.q.logit_off + gp] = gs * acc;
+    a.d_enc[b * a.q.sb + a.q.logit_off + gp] = acc;
     return;
   }
 
@@ -521,8 +560,8 @@ __global__ void k_obj_bwd_latent(BwdLatArgs a) {
     // (1) reparameterised path: only samples drawn from component gp depend on (mu, sigma)_{gp}
     {
       const int64_t n = ((int64_t)s * a.B + b) * a.G + gp;
-      const float w = a.wgt ? a.wgt[n] : 1.f;
-      const float wo = a.wgt_qown ? a.wgt_qown[n] : w;
+      const float w = gbb * (a.wgt ? a.wgt[n] : 1.f);
+      const float wo = a.wgt_qown ? gbb * a.wgt_qown[n] : w;
       const float z = a.Z[n * a.ldz + j];
       float dz = a.dZ ? a.dZ[n * a.ld_dz + j] : 0.f;
       dz += a.base_prior * w * (-z);
@@ -534,7 +573,7 @@ __global__ void k_obj_bwd_latent(BwdLatArgs a) {
           const float mc = q_mu(a.enc, a.q, b, c, j), sc = q_sigma(a.enc, a.q, b, c, j);
           t += r * (-(z - mc) / (sc * sc));
         }
-        dz += a.base_qmix * (a.wgt_qmix ? a.wgt_qmix[n] : w) * t;
+        dz += a.base_qmix * (a.wgt_qmix ? gbb * a.wgt_qmix[n] : w) * t;
       }
       if (a.use_zscale && a.zscale) dz *= a.zscale[n];
       acc_mu += dz;
@@ -550,7 +589,7 @@ __global__ void k_obj_bwd_latent(BwdLatArgs a) {
     if (has_mix && a.mix_live) {
       for (int g = 0; g < a.G; ++g) {
         const int64_t n = ((int64_t)s * a.B + b) * a.G + g;
-        const float w = a.wgt_qmix ? a.wgt_qmix[n] : a.wgt ? a.wgt[n] : 1.f;
+        const float w = gbb * (a.wgt_qmix ? a.wgt_qmix[n] : a.wgt ? a.wgt[n] : 1.f);
         const float z = a.Z[n * a.ldz + j];
         const float r = expf(logpi(gp) + a.comp_lp[n * a.G + gp] - a.qmix[n]);
         const float df = z - mu;
@@ -560,12 +599,12 @@ __global__ void k_obj_bwd_latent(BwdLatArgs a) {
     }
   }
   if (a.kl_coef != 0.f) {
-    const float kc = a.kl_coef * (a.kl_wgt ? a.kl_wgt[b * a.G + gp] : 1.f);
+    const float kc = a.kl_coef * gs * (a.kl_wgt ? a.kl_wgt[b * a.G + gp] : 1.f);
     acc_mu += kc * mu;
     acc_sg += kc * (sg - 1.f / sg);
   }
-  a.d_enc[b * a.q.sb + gp * a.q.sg + j] = gs * acc_mu;
-  a.d_enc[b * a.q.sb + gp * a.q.sg + a.q.raw_off + j] = gs * acc_sg * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
+  a.d_enc[b * a.q.sb + gp * a.q.sg + j] = acc_mu;
+  a.d_enc[b * a.q.sb + gp * a.q.sg + a.q.raw_off + j] = acc_sg * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -909,30 +948,42 @@ static inline unsigned grid_for(int64_t work, int block, unsigned cap = 8192) {
 // four consecutive latent dimensions per thread (Zd, ldz, offset multiples of 4, 16-byte aligned rows): one Philox call
 // and one 16-byte access per array; same values as the scalar kernel
 __global__ void k_latent_sample4(SampleArgs a) {
-  const int64_t total4 = (a.N * a.ldz) >> 2;
+  const int BG = a.B * a.G;
+  const int bg = blockIdx.x * blockDim.y + threadIdx.y;
+  if (bg >= BG) return;
+  const int64_t b = bg / a.G;
   const uint64_t off = a.offset + (a.offset_base ? a.offset_base[0] : 0ull);
   const int ld4 = (int)(a.ldz >> 2);
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = q / ld4;
-    const int j = (int)(q - n * ld4) << 2;
-    const int64_t i = q << 2;
-    f32x4 z = {0.f, 0.f, 0.f, 0.f}, e = {0.f, 0.f, 0.f, 0.f};
-    if (j < a.Zd) {
-      int g = (int)(n % a.G);
-      const int64_t b = (n / a.G) % a.B;
-      if (a.comp_idx) g = (int)a.comp_idx[n];
-      if (a.eps) {
-        e = *(const f32x4*)(a.eps + i);
-      } else {
-        const dmv_f4 r = dmv_philox_normal4(a.seed, (off + (uint64_t)i) >> 2);
-        e = f32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
-      }
+  for (int s = blockIdx.y; s < a.S; s += gridDim.y) {
+    const int64_t n = (int64_t)s * BG + bg;
+    const int g = a.comp_idx ? (int)a.comp_idx[n] : bg - (int)b * a.G;
+    for (int q = threadIdx.x; q < ld4; q += blockDim.x) {
+      const int j = q << 2;
+      const int64_t i = n * a.ldz + j;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f}, e = {0.f, 0.f, 0.f, 0.f};
+      if (j < a.Zd) {
+        if (a.eps) {
+          e = *(const f32x4*)(a.eps + i);
+        } else {
+          const dmv_f4 r = dmv_philox_normal4(a.seed, (off + (uint64_t)i) >> 2);
+          e = f32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
+        }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) z[k] = q_mu(a.enc, a.q, b, g, j + k) + q_sigma(a.enc, a.q, b, g, j + k) * e[k];
+        for (int k = 0; k < 4; ++k) z[k] = q_mu(a.enc, a.q, b, g, j + k) + q_sigma(a.enc, a.q, b, g, j + k) * e[k];
+      }
+      *(f32x4*)(a.Z + i) = z;
+      if (a.eps_out) *(f32x4*)(a.eps_out + i) = e;
     }
-    *(f32x4*)(a.Z + i) = z;
-    if (a.eps_out) *(f32x4*)(a.eps_out + i) = e;
   }
+}
+
+// threads along a row (power of two up to 64, at least `want`), rows per workgroup, grid of a row kernel
+static inline void row_geometry(int want, int BG, int S, dim3& grid, dim3& block) {
+  int bx = 1;
+  while (bx < want && bx < 64) bx <<= 1;
+  const int by = 256 / bx;
+  block = dim3((unsigned)bx, (unsigned)by);
+  grid = dim3((unsigned)((BG + by - 1) / by), (unsigned)(S > 65535 ? 65535 : S));   // the kernels stride over s
 }
 
 extern "C" int dmv_latent_sample(const DmvObjCfg* cfg, const float* enc, const float* eps, uint64_t seed,
@@ -947,10 +998,17 @@ extern "C" int dmv_latent_sample(const DmvObjCfg* cfg, const float* enc, const f
   a.q = qaddr(cfg); a.enc = enc; a.eps = eps; a.eps_out = eps_out; a.comp_idx = comp_idx;
   a.ldz = ldz; a.Z = Z; a.seed = seed; a.offset = offset; a.offset_base = offset_base;
   const uintptr_t al = (uintptr_t)Z | (uintptr_t)eps | (uintptr_t)eps_out;
-  if ((cfg->Zd & 3) == 0 && (ldz & 3) == 0 && (offset & 3) == 0 && (al & 15) == 0)
-    hipLaunchKernelGGL(k_latent_sample4, dim3(grid_for(a.N * ldz / 4, 256)), dim3(256), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(k_latent_sample, dim3(grid_for(a.N * ldz, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  const int S = cfg->nz * cfg->I;
+  if ((int64_t)cfg->B * cfg->G > 0x7fffffff) return DMV_E_UNSUPPORTED;
+  a.S = S;
+  dim3 grid, block;
+  if ((cfg->Zd & 3) == 0 && (ldz & 3) == 0 && (offset & 3) == 0 && (al & 15) == 0) {
+    row_geometry((int)(ldz >> 2), cfg->B * cfg->G, S, grid, block);
+    hipLaunchKernelGGL(k_latent_sample4, grid, block, 0, (hipStream_t)stream, a);
+  } else {
+    row_geometry((int)ldz, cfg->B * cfg->G, S, grid, block);
+    hipLaunchKernelGGL(k_latent_sample, grid, block, 0, (hipStream_t)stream, a);
+  }
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
@@ -1063,49 +1121,57 @@ extern "C" int dmv_kl_std_normal(const DmvObjCfg* cfg, const float* enc, float* 
 }
 
 static int backward_dec(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec, const float* X, const uint8_t* M,
-                        const float* wgt, const float* wgt_f, const float* gscale, float base_m, float base_f,
-                        float* d_dec, int64_t ld_ddec, void* stream) {
+                        const float* wgt, const float* wgt_f, const float* gb, const float* gscale, float base_m,
+                        float base_f, float* d_dec, int64_t ld_ddec, void* stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (!dec || !X || !M || !d_dec) return DMV_E_BADARG;
-  const int P = cfg->gen_dist <= DMV_GEN_NORMAL_EPS ? 2 * cfg->D : cfg->D;
+  const bool normal = cfg->gen_dist <= DMV_GEN_NORMAL_EPS;
+  const int P = normal ? 2 * cfg->D : cfg->D;
   if (ld_dec < P || ld_ddec < P) return DMV_E_BADARG;
+  if ((int64_t)cfg->B * cfg->G > 0x7fffffff || ld_ddec > 0x7fffffff) return DMV_E_UNSUPPORTED;
   BwdDecArgs a;
-  a.N = nrows(cfg); a.B = cfg->B; a.G = cfg->G; a.D = cfg->D;
+  a.N = nrows(cfg); a.B = cfg->B; a.G = cfg->G; a.D = cfg->D; a.S = cfg->nz * cfg->I;
   a.gen_dist = cfg->gen_dist; a.x_per_component = cfg->x_per_component;
-  a.dec = dec; a.ld_dec = ld_dec; a.X = X; a.M = M; a.wgt = wgt; a.wgt_f = wgt_f; a.gscale = gscale;
+  a.dec = dec; a.ld_dec = ld_dec; a.X = X; a.M = M; a.wgt = wgt; a.wgt_f = wgt_f; a.gb = gb; a.gscale = gscale;
   a.base_m = base_m; a.base_f = base_f; a.d_dec = d_dec; a.ld_ddec = ld_ddec;
-  const bool vec4 = cfg->gen_dist >= DMV_GEN_BERN && cfg->D >= 64 && (cfg->D & 3) == 0 && (ld_dec & 3) == 0 && (ld_ddec & 3) == 0 &&
-                    ((((uintptr_t)dec | (uintptr_t)X | (uintptr_t)d_dec) & 15) == 0) && (((uintptr_t)M & 3) == 0);
-  if (vec4) {
+  const bool aligned = (cfg->D & 3) == 0 && (ld_dec & 3) == 0 && (ld_ddec & 3) == 0 &&
+                       ((((uintptr_t)dec | (uintptr_t)X | (uintptr_t)d_dec) & 15) == 0) && (((uintptr_t)M & 3) == 0);
+  const int BG = cfg->B * cfg->G;
+  dim3 grid, block;
+  if (!normal && aligned && cfg->D >= 64) {
     const int W4 = (int)(ld_ddec / 4), bx = W4 > 64 ? 256 : 64;
-    dim3 grid((unsigned)((W4 + bx - 1) / bx), (unsigned)(a.N > 65535 ? 65535 : a.N));
+    grid = dim3((unsigned)((W4 + bx - 1) / bx), (unsigned)(BG > 65535 ? 65535 : BG));
     hipLaunchKernelGGL(k_obj_bwd_dec_bern4, grid, dim3(bx), 0, (hipStream_t)stream, a);
+  } else if (normal && aligned) {
+    row_geometry((int)(ld_ddec >> 2), BG, a.S, grid, block);
+    hipLaunchKernelGGL(k_obj_bwd_dec_normal4, grid, block, 0, (hipStream_t)stream, a);
   } else {
-    hipLaunchKernelGGL(k_obj_bwd_dec, dim3(grid_for(a.N * ld_ddec, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    row_geometry((int)ld_ddec, BG, a.S, grid, block);
+    hipLaunchKernelGGL(k_obj_bwd_dec, grid, block, 0, (hipStream_t)stream, a);
   }
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
 
 extern "C" int dmv_obj_backward_dec(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec, const float* X,
-                                    const uint8_t* M, const float* wgt, const float* gscale, float base_m, float base_f,
-                                    float* d_dec, int64_t ld_ddec, void* stream) {
-  return backward_dec(cfg, dec, ld_dec, X, M, wgt, nullptr, gscale, base_m, base_f, d_dec, ld_ddec, stream);
+                                    const uint8_t* M, const float* wgt, const float* gb, const float* gscale, float base_m,
+                                    float base_f, float* d_dec, int64_t ld_ddec, void* stream) {
+  return backward_dec(cfg, dec, ld_dec, X, M, wgt, nullptr, gb, gscale, base_m, base_f, d_dec, ld_ddec, stream);
 }
 
 extern "C" int dmv_obj_backward_dec_terms(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec, const float* X,
                                           const uint8_t* M, const float* g_masked, const float* g_full, float* d_dec,
                                           int64_t ld_ddec, void* stream) {
   if (!g_masked || !g_full) return DMV_E_BADARG;
-  return backward_dec(cfg, dec, ld_dec, X, M, g_masked, g_full, nullptr, 1.f, 1.f, d_dec, ld_ddec, stream);
+  return backward_dec(cfg, dec, ld_dec, X, M, g_masked, g_full, nullptr, nullptr, 1.f, 1.f, d_dec, ld_ddec, stream);
 }
 
 static int backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const float* enc, const float* Z,
                            const float* eps, int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
-                           const float* wgt_qown, const float* wgt_qmix, const float* zscale, const float* comp_lp,
-                           const float* qmix, const float* dlogit, const float* kl_wgt, const float* gscale, float* d_enc,
-                           void* stream) {
+                           const float* wgt_qown, const float* wgt_qmix, const float* gb, const float* zscale,
+                           const float* comp_lp, const float* qmix, const float* dlogit, const float* kl_wgt,
+                           const float* gscale, float* d_enc, void* stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (!p || !enc || !Z || !eps || !d_enc || ldz < cfg->Zd) return DMV_E_BADARG;
@@ -1119,8 +1185,17 @@ static int backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const fl
   a.enc = enc; a.Z = Z; a.eps = eps; a.ldz = ldz; a.dZ = dZ; a.ld_dz = ld_dz;
   a.wgt = wgt; a.wgt_qown = wgt_qown; a.wgt_qmix = wgt_qmix;
   a.zscale = zscale; a.comp_lp = comp_lp; a.qmix = qmix; a.dlogit = dlogit; a.kl_wgt = kl_wgt; a.gscale = gscale;
-  a.d_enc = d_enc;
+  a.d_enc = d_enc; a.gb = gb;
   const int64_t work = (int64_t)cfg->B * cfg->G * (cfg->Zd + 1);
+  if (work > 0x7fffffff || cfg->enc_sb > 0x7fffffff) return DMV_E_UNSUPPORTED;
+  // which entries of a datapoint's slice of d_enc carry gradients
+  if (cfg->enc_sg >= cfg->raw_off + cfg->Zd) {      // one [mu | raw sigma | padding] block per component (imputations)
+    a.zf_nseg = cfg->G; a.zf_len = (int)cfg->enc_sg; a.zf_used = (int)cfg->raw_off + cfg->Zd;
+  } else {                                          // one block per datapoint: [mu.. | raw.. | (logits) | padding]
+    a.zf_nseg = 1; a.zf_len = (int)cfg->enc_sb;
+    a.zf_used = p->mix_kind == DMV_Q_STRATIFIED ? (int)cfg->logit_off + cfg->G : (int)cfg->raw_off + cfg->G * cfg->Zd;
+  }
+  if (a.zf_used > a.zf_len) return DMV_E_BADARG;
   hipLaunchKernelGGL(k_obj_bwd_latent, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
@@ -1128,10 +1203,10 @@ static int backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const fl
 
 extern "C" int dmv_obj_backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const float* enc, const float* Z,
                                        const float* eps, int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
-                                       const float* zscale, const float* comp_lp, const float* qmix,
+                                       const float* gb, const float* zscale, const float* comp_lp, const float* qmix,
                                        const float* dlogit, const float* kl_wgt, const float* gscale, float* d_enc,
                                        void* stream) {
-  return backward_latent(cfg, p, enc, Z, eps, ldz, dZ, ld_dz, wgt, nullptr, nullptr, zscale, comp_lp, qmix, dlogit, kl_wgt,
+  return backward_latent(cfg, p, enc, Z, eps, ldz, dZ, ld_dz, wgt, nullptr, nullptr, gb, zscale, comp_lp, qmix, dlogit, kl_wgt,
                          gscale, d_enc, stream);
 }
 
@@ -1145,7 +1220,7 @@ extern "C" int dmv_obj_backward_latent_terms(const DmvObjCfg* cfg, int32_t mix_k
   DmvLatentBwd p;
   p.base_prior = 1.f; p.base_qown = 1.f; p.base_qmix = 1.f; p.base_w = 0.f; p.kl_coef = 0.f;
   p.own_live = q_live; p.mix_live = q_live; p.use_zscale = zscale ? 1 : 0; p.mix_kind = mix_kind;
-  return backward_latent(cfg, &p, enc, Z, eps, ldz, dZ, ld_dz, g_prior, g_qown, g_qmix, zscale, comp_lp, qmix, nullptr,
+  return backward_latent(cfg, &p, enc, Z, eps, ldz, dZ, ld_dz, g_prior, g_qown, g_qmix, nullptr, zscale, comp_lp, qmix, nullptr,
                          nullptr, nullptr, d_enc, stream);
 }
 

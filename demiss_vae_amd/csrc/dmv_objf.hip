@@ -1,0 +1,391 @@
+// The masked objective in one launch: per-sample terms, bound (logsumexp over the importance / component axes),
+// softmax weights for the backward and the mixture-logit gradient, for a block of datapoints at a time
+// (vgiwae/shared/iwae.py:9-132, vgiwae/models/iwae.py:70-123, models/multiple_iwae.py:124-199,
+// models/mvbvae.py:83-137).  HBM-bound.
+//
+// Work decomposition.  Sample rows are n = s*B*G + b*G + g (s = z*I + i).  A workgroup owns DPB consecutive
+// datapoints, i.e. Q = DPB*G consecutive (b, g) pairs; for every s their rows are consecutive in memory, so a wave
+// reads consecutive rows.  A group of R lanes walks one (b, g) pair through all S samples: the dimensions of a row are
+// spread over the R lanes (consecutive lanes read consecutive floats) and summed with DPP reductions; lane 0 of the
+// group leaves the row's log-weight in LDS.  After a barrier the logsumexp over (i, g) of each datapoint runs out of
+// LDS on a sub-wave group of T lanes, the normalised weights replace the log-weights in LDS, and a last sweep
+// writes them to HBM with consecutive threads on consecutive rows.  Nothing but the decoder outputs, the latent
+// samples and the [B]-sized inputs is read, and nothing is read twice; no 64-bit division anywhere.
+#include "dmv_common.h"
+#include "dmv_objmath.h"
+
+namespace {
+
+struct FwdArgs {
+  int B, G, S, nz, I, D, Zd;
+  int gen_dist, xpc, q_kind, mix_C;
+  int kind;        // DMV_BOUND_LSE / _WEIGHTED / _PER_COMPONENT, or -1: terms only
+  int q_term;      // 3: own, 4: mixture (which log q enters the log-weight)
+  int use_logpi, dreg;
+  int DPB, T;      // datapoints per workgroup; lanes per datapoint in the logsumexp stage
+  int vec4;
+  QAddr q;
+  const float* __restrict__ dec; int64_t ld_dec;
+  const float* __restrict__ X; const uint8_t* __restrict__ M;
+  const float* __restrict__ Z; int64_t ldz;
+  const float* __restrict__ enc;
+  float* __restrict__ terms;    // nullable [5][N]
+  float* __restrict__ comp_lp;  // nullable [N][mix_C]
+  float* __restrict__ log_w;    // nullable [N]
+  float* __restrict__ bound;    // [B] (LSE / WEIGHTED)
+  float* __restrict__ wgt;      // nullable [N]
+  float* __restrict__ zscale;   // nullable [N]
+  float* __restrict__ dlogit;   // nullable [B][G]
+  float cA[5], cB[5];           // PER_COMPONENT: objA = mean_z sum_t cA[t] terms[t], objB likewise (nullable)
+  float* __restrict__ objA; float* __restrict__ objB;
+};
+
+// the five terms of one sample row, summed over the R lanes of the group (every lane returns the totals)
+template <int R>
+__device__ __forceinline__ void row_terms(const FwdArgs& a, int r, int64_t n, int64_t b, int g, const float* __restrict__ X,
+                                          const uint8_t* __restrict__ M, float& gm, float& gf, float& pr, float& qo, float& qm) {
+  const float* __restrict__ dec = a.dec + n * a.ld_dec;
+  gm = 0.f; gf = 0.f;
+  if (a.vec4) {
+    // wide rows (Bernoulli images): 16 bytes of logits / data and 4 mask bytes per lane and iteration
+    for (int q = r; q < (a.D >> 2); q += R) {
+      const f32x4 l4 = *(const f32x4*)(dec + 4 * q);
+      const f32x4 x4 = *(const f32x4*)(X + 4 * q);
+      const uint32_t m4 = *(const uint32_t*)(M + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lp = log_bern(a.gen_dist == DMV_GEN_BERN ? x4[e] : (x4[e] + 1.f) * 0.5f, l4[e]);
+        gf += lp;
+        gm += lp * (((m4 >> (8 * e)) & 0xffu) ? 1.f : 0.f);
+      }
+    }
+  } else {
+    for (int d = r; d < a.D; d += R) {
+      float lp;
+      const float x = X[d];
+      if (a.gen_dist <= DMV_GEN_NORMAL_EPS) {
+        const float s = dmv_softplus(dec[a.D + d]) + (a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f);
+        lp = log_normal(x, dec[d], s);
+      } else if (a.gen_dist == DMV_GEN_BERN) {
+        lp = log_bern(x, dec[d]);
+      } else {
+        lp = log_bern((x + 1.f) * 0.5f, dec[d]);
+      }
+      gf += lp;
+      gm += lp * (M[d] ? 1.f : 0.f);     // the product the reference forms (shared/iwae.py:20): a non-finite lp at a
+                                  // missing entry makes the row's log-weight NaN there and here alike
+    }
+  }
+  const float* __restrict__ z = a.Z + n * a.ldz;
+  pr = 0.f; qo = 0.f;
+  const bool own = a.q_kind != DMV_Q_STRATIFIED || a.G > 1;   // rows sampled from the mixture itself have no own component
+  for (int j = r; j < a.Zd; j += R) {
+    const float zj = z[j];
+    pr += -(zj * zj) * 0.5f - LOG_SQRT_2PI;
+    if (own) qo += log_normal(zj, q_mu(a.enc, a.q, b, g, j), q_sigma(a.enc, a.q, b, g, j));
+  }
+  gm = gsum<R>(gm); gf = gsum<R>(gf); pr = gsum<R>(pr); qo = gsum<R>(qo);
+  qm = qo;
+  if (a.q_kind != DMV_Q_OWN) {
+    float mx = -INFINITY, se = 0.f, lse_logit = 0.f;
+    const float* __restrict__ lg = a.enc + b * a.q.sb + a.q.logit_off;
+    if (a.q_kind == DMV_Q_STRATIFIED) {
+      float lm = -INFINITY;
+      for (int c = 0; c < a.mix_C; ++c) lm = fmaxf(lm, lg[c]);
+      float ss = 0.f;
+      for (int c = 0; c < a.mix_C; ++c) ss += expf(lg[c] - lm);
+      lse_logit = lm + logf(ss);
+    }
+    for (int c = 0; c < a.mix_C; ++c) {
+      float lp = 0.f;
+      for (int j = r; j < a.Zd; j += R) lp += log_normal(z[j], q_mu(a.enc, a.q, b, c, j), q_sigma(a.enc, a.q, b, c, j));
+      lp = gsum<R>(lp);
+      if (a.comp_lp && r == 0) a.comp_lp[n * a.mix_C + c] = lp;
+      const float t = lp + (a.q_kind == DMV_Q_STRATIFIED ? lg[c] - lse_logit : 0.f);
+      const float nm = fmaxf(mx, t);
+      se = se * expf(mx - nm) + expf(t - nm);
+      mx = nm;
+    }
+    qm = mx + logf(se) - (a.q_kind == DMV_Q_IMPUTATION ? logf((float)a.mix_C) : 0.f);
+  }
+}
+
+__device__ __forceinline__ float tsum(float v, int T) {
+  for (int o = T >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float tmax(float v, int T) {
+  for (int o = T >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) k_obj_fwd(FwdArgs a) {
+  extern __shared__ float sm[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int NG = nthr / R;
+  const int r = tid % R, grp = tid / R;
+  const int b0 = blockIdx.x * a.DPB;
+  const int nb = min(a.DPB, a.B - b0);
+  const int Qn = nb * a.G, Q = a.DPB * a.G;
+  const int64_t BG = (int64_t)a.B * a.G;
+  const int64_t N = BG * a.S;
+  const int64_t row0 = (int64_t)b0 * a.G;
+  float* lw = sm;                         // [S][Q] log-weights, later the weights (PER_COMPONENT: objA summands)
+  float* aux = sm + (size_t)a.S * Q;      // PER_COMPONENT: [S][Q] objB summands; else [3][Q]: log pi, L_g, dlogit
+  const bool per_comp = a.kind == DMV_BOUND_PER_COMPONENT;
+
+  // ---- phase 1: terms of every row of the block's datapoints
+  for (int q = grp; q < Qn; q += NG) {
+    const int bl = q / a.G, g = q - bl * a.G;
+    const int64_t b = b0 + bl;
+    const int64_t xrow = a.xpc ? row0 + q : b;
+    const float* __restrict__ X = a.X + xrow * a.D;
+    const uint8_t* __restrict__ M = a.M + xrow * a.D;
+    for (int s = blockIdx.y; s < a.S; s += gridDim.y) {     // gridDim.y > 1 only when no bound is formed (terms only)
+      const int64_t n = (int64_t)s * BG + row0 + q;
+      float gm, gf, pr, qo, qm;
+      row_terms<R>(a, r, n, b, g, X, M, gm, gf, pr, qo, qm);
+      if (r == 0) {
+        if (a.terms) {
+          a.terms[n] = gm; a.terms[N + n] = gf; a.terms[2 * N + n] = pr; a.terms[3 * N + n] = qo; a.terms[4 * N + n] = qm;
+        }
+        if (per_comp) {
+          const float t5[5] = {gm, gf, pr, qo, qm};
+          float vA = 0.f, vB = 0.f;
+#pragma unroll
+          for (int t = 0; t < 5; ++t) {
+            if (a.cA[t] != 0.f) vA += a.cA[t] * t5[t];
+            if (a.cB[t] != 0.f) vB += a.cB[t] * t5[t];
+          }
+          lw[s * Q + q] = vA;
+          aux[s * Q + q] = vB;
+        } else if (a.kind >= 0) {
+          const float w = gm + pr - (a.q_term == 3 ? qo : qm);
+          lw[s * Q + q] = w;
+          if (a.log_w) a.log_w[n] = w;
+        }
+      }
+    }
+  }
+  if (a.kind < 0) return;
+
+  // ---- normalised log mixture weights of the block's datapoints
+  const bool need_pi = !per_comp && (a.use_logpi || a.kind == DMV_BOUND_WEIGHTED);
+  float* lpi = aux;
+  if (need_pi) {
+    for (int bl = tid; bl < nb; bl += nthr) {
+      const float* __restrict__ lg = a.enc + (int64_t)(b0 + bl) * a.q.sb + a.q.logit_off;
+      float lm = -INFINITY;
+      for (int c = 0; c < a.G; ++c) lm = fmaxf(lm, lg[c]);
+      float ss = 0.f;
+      for (int c = 0; c < a.G; ++c) ss += expf(lg[c] - lm);
+      const float lse = lm + logf(ss);
+      for (int c = 0; c < a.G; ++c) lpi[bl * a.G + c] = lg[c] - lse;
+    }
+  }
+  __syncthreads();
+
+  const float inv_nz = 1.f / (float)a.nz;
+  const float logI = logf((float)a.I);
+  if (per_comp) {
+    // objectives per (b, g): mean over the outer samples (I == 1)
+    for (int q = tid; q < Qn; q += nthr) {
+      float sA = 0.f, sB = 0.f;
+      for (int s = 0; s < a.S; ++s) { sA += lw[s * Q + q]; sB += aux[s * Q + q]; }
+      if (a.objA) a.objA[row0 + q] = sA / (float)a.nz;
+      if (a.objB) a.objB[row0 + q] = sB / (float)a.nz;
+    }
+    return;
+  }
+
+  const bool need_w = a.wgt || a.zscale || a.dlogit;
+  if (a.kind == DMV_BOUND_LSE) {
+    // logsumexp over (i, g) per datapoint and outer sample, T lanes per datapoint
+    const int T = a.T, lt = tid % T, sub = tid / T, nsub = nthr / T;
+    const int IG = a.I * a.G;
+    for (int bl = sub; bl < nb; bl += nsub) {
+      float bacc = 0.f;
+      for (int z = 0; z < a.nz; ++z) {
+        float mx = -INFINITY;
+        for (int t = lt; t < IG; t += T) {
+          const int i = t / a.G, g = t - i * a.G;
+          mx = fmaxf(mx, lw[(z * a.I + i) * Q + bl * a.G + g] + (a.use_logpi ? lpi[bl * a.G + g] : 0.f));
+        }
+        mx = tmax(mx, T);
+        float se = 0.f;
+        for (int t = lt; t < IG; t += T) {
+          const int i = t / a.G, g = t - i * a.G;
+          se += expf(lw[(z * a.I + i) * Q + bl * a.G + g] + (a.use_logpi ? lpi[bl * a.G + g] : 0.f) - mx);
+        }
+        se = tsum(se, T);
+        const float lse = mx + logf(se);
+        bacc += lse - logI;
+        if (need_w) {
+          for (int t = lt; t < IG; t += T) {
+            const int i = t / a.G, g = t - i * a.G;
+            float* slot = &lw[(z * a.I + i) * Q + bl * a.G + g];
+            *slot = expf(*slot + (a.use_logpi ? lpi[bl * a.G + g] : 0.f) - lse);
+          }
+        }
+      }
+      if (lt == 0) a.bound[b0 + bl] = bacc * inv_nz;
+    }
+  } else {
+    // sum_g pi_g (logsumexp_i log_w - log I): one thread per datapoint (G and I are small here)
+    float* Lg = aux + Q;
+    float* dl = aux + 2 * Q;
+    for (int bl = tid; bl < nb; bl += nthr) {
+      float bacc = 0.f;
+      for (int g = 0; g < a.G; ++g) dl[bl * a.G + g] = 0.f;
+      for (int z = 0; z < a.nz; ++z) {
+        float tot = 0.f;
+        for (int g = 0; g < a.G; ++g) {
+          const float pig = expf(lpi[bl * a.G + g]);
+          float mx = -INFINITY;
+          for (int i = 0; i < a.I; ++i) mx = fmaxf(mx, lw[(z * a.I + i) * Q + bl * a.G + g]);
+          float se = 0.f;
+          for (int i = 0; i < a.I; ++i) se += expf(lw[(z * a.I + i) * Q + bl * a.G + g] - mx);
+          const float lse = mx + logf(se);
+          tot += pig * (lse - logI);
+          Lg[bl * a.G + g] = lse - logI;
+          if (need_w)
+            for (int i = 0; i < a.I; ++i) {
+              float* slot = &lw[(z * a.I + i) * Q + bl * a.G + g];
+              *slot = pig * expf(*slot - lse);
+            }
+        }
+        bacc += tot;
+        for (int g = 0; g < a.G; ++g) dl[bl * a.G + g] += expf(lpi[bl * a.G + g]) * (Lg[bl * a.G + g] - tot) * inv_nz;
+      }
+      a.bound[b0 + bl] = bacc * inv_nz;
+    }
+  }
+  if (!need_w) return;
+  __syncthreads();
+
+  // ---- gradient of sum_b bound_b with respect to the mixture logits through the pi factors
+  if (a.dlogit) {
+    for (int q = tid; q < Qn; q += nthr) {
+      float v = 0.f;
+      if (a.kind == DMV_BOUND_WEIGHTED) {
+        v = aux[2 * Q + q];
+      } else if (a.use_logpi) {
+        // d/d logit_c of sum_n p_n log pi_{g(n)} = (sum_{n: g(n) = c} p_n) - pi_c, per outer sample
+        float acc = 0.f;
+        for (int s = 0; s < a.S; ++s) acc += lw[s * Q + q];
+        v = (acc - (float)a.nz * expf(lpi[q])) * inv_nz;
+      }
+      a.dlogit[row0 + q] = v;
+    }
+  }
+  // ---- weights of the backward, consecutive threads on consecutive rows
+  for (int s = 0; s < a.S; ++s)
+    for (int q = tid; q < Qn; q += nthr) {
+      const int64_t n = (int64_t)s * BG + row0 + q;
+      const float p = lw[s * Q + q];
+      if (a.wgt) a.wgt[n] = p * inv_nz;
+      if (a.zscale) a.zscale[n] = (a.dreg && a.kind == DMV_BOUND_LSE) ? p : 1.f;
+    }
+}
+
+// means of one or two arrays in one single-workgroup launch
+__global__ void k_mean2(const float* __restrict__ v1, const float* __restrict__ v2, int64_t n, float scale,
+                        float* __restrict__ o1, float* __restrict__ o2) {
+  __shared__ float sh[2][4];
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { if (v1) s1 += v1[i]; if (v2) s2 += v2[i]; }
+  s1 = gsum<64>(s1); s2 = gsum<64>(s2);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (o1) o1[0] = (sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) * scale;
+    if (o2) o2[0] = (sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) * scale;
+  }
+}
+
+int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+}  // namespace
+
+extern "C" int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const float* dec, int64_t ld_dec, const float* X,
+                               const uint8_t* M, const float* Z, int64_t ldz, const float* enc, void* stream) {
+  if (!cfg || !f) return DMV_E_BADARG;
+  if (cfg->B < 1 || cfg->G < 1 || cfg->nz < 1 || cfg->I < 1 || cfg->D < 1 || cfg->Zd < 1) return DMV_E_BADARG;
+  if (cfg->G > 64) return DMV_E_UNSUPPORTED;
+  if (cfg->gen_dist < DMV_GEN_NORMAL || cfg->gen_dist > DMV_GEN_BERN_M1P1) return DMV_E_UNSUPPORTED;
+  if (!dec || !X || !M || !Z || !enc) return DMV_E_BADARG;
+  if (f->q_kind < DMV_Q_OWN || f->q_kind > DMV_Q_IMPUTATION) return DMV_E_UNSUPPORTED;
+  if (f->q_kind != DMV_Q_OWN && (f->mix_C < 1 || f->mix_C > 64)) return DMV_E_UNSUPPORTED;
+  const int P = cfg->gen_dist <= DMV_GEN_NORMAL_EPS ? 2 * cfg->D : cfg->D;
+  if (ld_dec < P || ldz < cfg->Zd) return DMV_E_BADARG;
+  const int kind = f->kind;
+  if (kind < -1 || kind > DMV_BOUND_PER_COMPONENT) return DMV_E_UNSUPPORTED;
+  if ((kind == DMV_BOUND_LSE || kind == DMV_BOUND_WEIGHTED) && !f->bound) return DMV_E_BADARG;
+  if (kind == DMV_BOUND_PER_COMPONENT && (cfg->I != 1 || (!f->objA && !f->objB))) return DMV_E_BADARG;
+  if (kind == -1 && !f->terms) return DMV_E_BADARG;
+
+  FwdArgs a;
+  a.B = cfg->B; a.G = cfg->G; a.nz = cfg->nz; a.I = cfg->I; a.S = cfg->nz * cfg->I; a.D = cfg->D; a.Zd = cfg->Zd;
+  a.gen_dist = cfg->gen_dist; a.xpc = cfg->x_per_component; a.q_kind = f->q_kind; a.mix_C = f->mix_C;
+  a.kind = kind; a.q_term = f->q_kind == DMV_Q_OWN ? 3 : 4; a.use_logpi = f->use_logpi; a.dreg = f->dreg;
+  a.q.sb = cfg->enc_sb; a.q.sg = cfg->enc_sg; a.q.raw_off = cfg->raw_off; a.q.logit_off = cfg->logit_off;
+  a.q.eps = cfg->q_eps ? DMV_EPSILON : 0.f;
+  a.dec = dec; a.ld_dec = ld_dec; a.X = X; a.M = M; a.Z = Z; a.ldz = ldz; a.enc = enc;
+  a.terms = f->terms; a.comp_lp = f->comp_lp; a.log_w = f->log_w; a.bound = f->bound; a.wgt = f->wgt;
+  a.zscale = f->zscale; a.dlogit = f->dlogit; a.objA = f->objA; a.objB = f->objB;
+  for (int t = 0; t < 5; ++t) { a.cA[t] = f->coefA[t]; a.cB[t] = f->coefB[t]; }
+  a.vec4 = cfg->gen_dist >= DMV_GEN_BERN && (cfg->D & 3) == 0 && (ld_dec & 3) == 0 &&
+           ((((uintptr_t)dec | (uintptr_t)X) & 15) == 0) && (((uintptr_t)M & 3) == 0);
+
+  // lanes per row by the longer of the two row kinds; workgroup size by how many datapoints there are
+  const int span = cfg->D > cfg->Zd ? cfg->D : cfg->Zd;
+  const int R = span <= 8 ? 1 : span <= 32 ? 8 : span <= 96 ? 16 : 64;
+  int nthr = 256;
+  const int64_t pairs = (int64_t)cfg->B * cfg->G;
+  if (pairs * R < 256 * 256) nthr = 64;            // small batches: more, smaller workgroups
+  const int NG = nthr / R;
+  int DPB = NG / cfg->G;
+  if (DPB < 1) DPB = 1;
+  // LDS: S*Q log-weights (+ S*Q for the second objective, or 3*Q of mixture bookkeeping)
+  const size_t lds_max = 60 * 1024;
+  auto lds_bytes = [&](int dpb) {
+    const size_t Q = (size_t)dpb * cfg->G;
+    return sizeof(float) * ((size_t)a.S * Q * (kind == DMV_BOUND_PER_COMPONENT ? 2 : 1) + 3 * Q);
+  };
+  while (DPB > 1 && kind >= 0 && lds_bytes(DPB) > lds_max) DPB >>= 1;
+  if (kind >= 0 && lds_bytes(DPB) > lds_max) return DMV_E_UNSUPPORTED;   // nz*I*G beyond ~15 000: stream with dmv_lse_update
+  a.DPB = DPB;
+  int T = pow2_ceil(cfg->I * cfg->G);
+  if (T > 64) T = 64;
+  if (T > nthr) T = nthr;
+  a.T = T;
+  dim3 grid((unsigned)((cfg->B + DPB - 1) / DPB));
+  size_t lds = lds_bytes(DPB);
+  if (kind < 0) {
+    // terms only: nothing couples the samples of a datapoint, so few datapoints with many samples (the K-sample
+    // log-likelihood) spread over the grid's second dimension
+    lds = 0;
+    const int64_t want = 2048 / grid.x;
+    grid.y = (unsigned)(want < 1 ? 1 : want > a.S ? a.S : want > 65535 ? 65535 : want);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (R) {
+    case 1: hipLaunchKernelGGL(k_obj_fwd<1>, grid, dim3(nthr), lds, st, a); break;
+    case 8: hipLaunchKernelGGL(k_obj_fwd<8>, grid, dim3(nthr), lds, st, a); break;
+    case 16: hipLaunchKernelGGL(k_obj_fwd<16>, grid, dim3(nthr), lds, st, a); break;
+    default: hipLaunchKernelGGL(k_obj_fwd<64>, grid, dim3(nthr), lds, st, a); break;
+  }
+  DMV_HIP_CHECK_LAUNCH();
+  if (f->mean_out || f->meanA_out || f->meanB_out) {
+    if (kind == DMV_BOUND_PER_COMPONENT) {
+      hipLaunchKernelGGL(k_mean2, dim3(1), dim3(256), 0, st, (const float*)f->objA, (const float*)f->objB, pairs,
+                         1.f / (float)pairs, f->meanA_out, f->meanB_out);
+    } else if (kind >= 0) {
+      hipLaunchKernelGGL(k_mean2, dim3(1), dim3(256), 0, st, (const float*)f->bound, (const float*)nullptr, (int64_t)cfg->B,
+                         1.f / (float)cfg->B, f->mean_out, (float*)nullptr);
+    }
+    DMV_HIP_CHECK_LAUNCH();
+  }
+  return DMV_OK;
+}

@@ -95,7 +95,7 @@ class _Sample(torch.autograd.Function):
         d_enc = torch.zeros_like(c.enc_out)
         p = _latent_params(w=0.0, use_zscale=c.plan.DREG)
         L.check(lib.dmv_obj_backward_latent(C.byref(c.cfg), C.byref(p), L.ptr(c.enc_out), L.ptr(c.Z), L.ptr(c.eps), c.Z.shape[1],
-                                            L.ptr(dZ), dZ.shape[1], None, L.ptr(c.zscale), None, None, None, None, None,
+                                            L.ptr(dZ), dZ.shape[1], None, None, L.ptr(c.zscale), None, None, None, None, None,
                                             L.ptr(d_enc), st))
         return None, d_enc, None, None
 
@@ -153,7 +153,7 @@ class _Objective(torch.autograd.Function):
             nonlocal d_dec
             out = torch.empty_like(c.dec_out)
             L.check(lib.dmv_obj_backward_dec(C.byref(c.cfg), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
-                                             L.ptr(wt), None, base_m, base_f, L.ptr(out), out.shape[1], st))
+                                             L.ptr(wt), None, None, base_m, base_f, L.ptr(out), out.shape[1], st))
             d_dec = out if d_dec is None else d_dec + out
 
         def enc_part(p, wt, zscale, dlogit, kl_wgt):
@@ -162,7 +162,7 @@ class _Objective(torch.autograd.Function):
             need_mix = p.base_qmix != 0.0
             L.check(lib.dmv_obj_backward_latent(
                 C.byref(c.cfg), C.byref(p), L.ptr(c.enc_out), L.ptr(c.Z), L.ptr(c.eps), c.Z.shape[1], None, 0, L.ptr(wt),
-                L.ptr(zscale), L.ptr(c.comp_lp) if need_mix else None, L.ptr(c.terms[4]) if need_mix else None,
+                None, L.ptr(zscale), L.ptr(c.comp_lp) if need_mix else None, L.ptr(c.terms[4]) if need_mix else None,
                 L.ptr(dlogit), L.ptr(kl_wgt), None, L.ptr(out), st))
             d_enc = out if d_enc is None else d_enc + out
 

@@ -227,14 +227,14 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
         cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, Kp, 1, I, D, Zd
         cfg.gen_dist, cfg.q_eps, cfg.x_per_component = L.GEN[dims.gen_dist], dims.q_eps, 1
         cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = Kp * ldE, ldE, Zd, 0
-        terms = torch.empty((5, N), dtype=torch.float32, device=dev)
-        L.check(lib.dmv_obj_terms(C.byref(cfg), L.Q_IMPUTATION, Kp, L.ptr(dec_out), dec_out.shape[1], L.ptr(Xe), L.ptr(Me),
-                                  L.ptr(Z), Zd, L.ptr(enc_out), L.ptr(terms), None, st))
-        # log_w = terms[0] + terms[2] - terms[4], rows (i b k): the bound kernel writes it as a by-product
+        # log_w = sum_d M log p(x_d|z) + log p(z) - log q_mix(z), rows (i b k): a by-product of the fused objective forward
         log_w = torch.empty(N, dtype=torch.float32, device=dev)
         per_b = torch.empty(B, dtype=torch.float32, device=dev)
-        L.check(lib.dmv_obj_bound(C.byref(cfg), L.BOUND_LSE, L.Q_IMPUTATION, 0, 0, None, L.ptr(terms), L.ptr(log_w), L.ptr(per_b),
-                                  None, None, None, None, st))
+        f = L.DmvObjFwd()
+        f.q_kind, f.mix_C, f.kind = L.Q_IMPUTATION, Kp, L.BOUND_LSE
+        f.log_w, f.bound = L.addr(log_w), L.addr(per_b)
+        L.check(lib.dmv_obj_forward(C.byref(cfg), C.byref(f), L.ptr(dec_out), dec_out.shape[1], L.ptr(Xe), L.ptr(Me),
+                                    L.ptr(Z), Zd, L.ptr(enc_out), st))
         logits = log_w.reshape(I, B, Kp).permute(1, 0, 2).reshape(B, I * Kp).contiguous()   # 'i b k -> b (i k)'
         if idx is not None:
             draw = idx[t].to(dev, torch.int64).t().contiguous()                 # [B, K+r]
@@ -341,9 +341,11 @@ def estimate_loglik(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, nu
                                               L.ptr(comp), L.ptr(Z), None, st))
             dec_out, _ = mlp_forward(dec, Z, Zd, N, save=False)
             terms = torch.empty((5, N), dtype=torch.float32, device=dev)
-            q_kind = L.Q_STRATIFIED if mixture else L.Q_OWN
-            L.check(lib.dmv_obj_terms(C.byref(cfg), q_kind, dims.C if mixture else 1, L.ptr(dec_out), dec_out.shape[1],
-                                      L.ptr(Xc), L.ptr(Mu), L.ptr(Z), Zd, L.ptr(enc_out), L.ptr(terms), None, st))
+            f = L.DmvObjFwd()
+            f.q_kind, f.mix_C, f.kind = (L.Q_STRATIFIED, dims.C, L.TERMS_ONLY) if mixture else (L.Q_OWN, 1, L.TERMS_ONLY)
+            f.terms = L.addr(terms)
+            L.check(lib.dmv_obj_forward(C.byref(cfg), C.byref(f), L.ptr(dec_out), dec_out.shape[1], L.ptr(Xc), L.ptr(Mu),
+                                        L.ptr(Z), Zd, L.ptr(enc_out), st))
             L.check(lib.dmv_lse_update(B, Kc, L.ptr(terms), 4 if mixture else 3, L.ptr(run_max), L.ptr(run_sum), st))
         return run_max, run_sum
 

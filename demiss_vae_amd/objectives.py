@@ -135,25 +135,66 @@ def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, 
     # ---- decoder
     dec_out, dec_saved = mlp_forward(dec, Z, Zd, N, save=training, drop_keep=dec_keep)
 
-    # ---- per-sample terms
     if demiss:
         q_kind, mix_C = L.Q_IMPUTATION, K
     elif dims.q_is_mixture or dims.q_is_reparam:
         q_kind, mix_C = L.Q_STRATIFIED, dims.C
     else:
         q_kind, mix_C = L.Q_OWN, 1
-    terms = torch.empty((5, N), dtype=torch.float32, device=dev)
-    need_comp = training and q_kind != L.Q_OWN and plan.kind in ("miwae", "cvi", "terms")
-    comp_lp = torch.empty((N, mix_C), dtype=torch.float32, device=dev) if need_comp else None
-    L.check(lib.dmv_obj_terms(C.byref(cfg), q_kind, mix_C, L.ptr(dec_out), dec_out.shape[1], L.ptr(Xc), L.ptr(Mu),
-                              L.ptr(Z), Zd, L.ptr(enc_out), L.ptr(terms), L.ptr(comp_lp), st))
-
     c.cfg, c.B, c.G, c.N, c.demiss, c.q_kind, c.mix_C = cfg, B, G, N, demiss, q_kind, mix_C
     c.Xc, c.Mu, c.enc_out, c.enc_saved, c.Z, c.eps, c.dec_out, c.dec_saved = Xc, Mu, enc_out, enc_saved, Z, eps_used, dec_out, dec_saved
-    c.terms, c.comp_lp, c.enc_rows = terms, comp_lp, enc_rows
+    c.terms, c.comp_lp, c.enc_rows = None, None, enc_rows
     c.enc_keep, c.dec_keep = enc_keep, dec_keep
     c.reparam = dims.q_is_reparam
+    c.wgt = c.zscale = c.dlogit = None
     return c
+
+
+def _objective_forward(c, plan: _Plan, training: bool, *, kind, use_logpi=False, coefA=None, coefB=None, want_terms=False,
+                       want_means=False):
+    """One launch of dmv_obj_forward over the pipeline's decoder outputs: per-sample terms, bound / objectives and the
+    buffers the backward reads (softmax weights, DREG scales, mixture-logit gradient, component log-densities).
+    Returns (bound [B], mean) for the bound kinds, (objA, objB, meanA, meanB) for the per-component kind, terms for -1."""
+    lib, st = L.lib(), L.stream_ptr()
+    dev = c.dec_out.device
+    B, G, N = c.B, c.G, c.N
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    f = L.DmvObjFwd()
+    f.q_kind, f.mix_C, f.kind, f.use_logpi, f.dreg = c.q_kind, c.mix_C, kind, int(use_logpi), int(plan.DREG)
+    # the mixture enters the loss (not stop-gradient) in these plans: their backward needs the component densities
+    need_comp = training and c.q_kind != L.Q_OWN and plan.kind in ("miwae", "cvi", "terms") and not c.reparam
+    if want_terms or need_comp:
+        c.terms = new(5, N)
+        f.terms = L.addr(c.terms)
+    if need_comp:
+        c.comp_lp = new(N, c.mix_C)
+        f.comp_lp = L.addr(c.comp_lp)
+    out = None
+    if kind in (L.BOUND_LSE, L.BOUND_WEIGHTED):
+        per_b, mean = new(B), new()
+        f.bound, f.mean_out = L.addr(per_b), L.addr(mean)
+        if training:
+            c.wgt = new(N)
+            f.wgt = L.addr(c.wgt)
+            if plan.DREG:
+                c.zscale = new(N)
+                f.zscale = L.addr(c.zscale)
+            if c.q_kind == L.Q_STRATIFIED and not c.reparam:
+                c.dlogit = new(B, G)
+                f.dlogit = L.addr(c.dlogit)
+        out = (per_b, mean)
+    elif kind == L.BOUND_PER_COMPONENT:
+        objA = new(B, G)
+        objB = new(B, G) if coefB is not None else None
+        mA = new() if want_means else None
+        mB = new() if (want_means and coefB is not None) else None
+        f.coefA = (C.c_float * 5)(*coefA)
+        f.coefB = (C.c_float * 5)(*(coefB if coefB is not None else (0, 0, 0, 0, 0)))
+        f.objA, f.objB, f.meanA_out, f.meanB_out = L.addr(objA), L.addr(objB), L.addr(mA), L.addr(mB)
+        out = (objA, objB, mA, mB)
+    L.check(lib.dmv_obj_forward(C.byref(c.cfg), C.byref(f), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
+                                L.ptr(c.Z), c.Z.shape[1], L.ptr(c.enc_out), st))
+    return out if out is not None else c.terms
 
 
 def reparam_components(dims: ModelDims, cfg, enc_out, comp_idx, eps):
@@ -203,18 +244,19 @@ def _combine(c, coef):
 
 def _kl(c):
     lib, st = L.lib(), L.stream_ptr()
-    kl = torch.empty((c.B, c.G), dtype=torch.float32, device=c.terms.device)
+    kl = torch.empty((c.B, c.G), dtype=torch.float32, device=c.enc_out.device)
     L.check(lib.dmv_kl_std_normal(C.byref(c.cfg), L.ptr(c.enc_out), L.ptr(kl), st))
     return kl
 
 
-def _dec_side(c, dec: PackedNet, wgt_total, base_m, base_f, need_dx, need_param_grads, overlap=None):
-    """overlap: a list; when given (and the batch is small) the decoder's weight-gradient GEMMs go to the side stream
+def _dec_side(c, dec: PackedNet, wgt, base_m, base_f, need_dx, need_param_grads, overlap=None, gb=None, gscale=None):
+    """Decoder-side gradient and the decoder's backward pass.  Row weights = gscale * gb[b] * wgt[n] (each optional).
+    overlap: a list; when given (and the batch is small) the decoder's weight-gradient GEMMs go to the side stream
     while the caller carries on upstream, and the list receives what must stay alive until the caller has joined"""
     lib, st = L.lib(), L.stream_ptr()
     d_dec = torch.empty_like(c.dec_out)
     L.check(lib.dmv_obj_backward_dec(C.byref(c.cfg), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
-                                     L.ptr(wgt_total), None, base_m, base_f, L.ptr(d_dec), d_dec.shape[1], st))
+                                     L.ptr(wgt), L.ptr(gb), L.ptr(gscale), base_m, base_f, L.ptr(d_dec), d_dec.shape[1], st))
     side = side_stream(d_dec.device) if (overlap is not None and need_dx and need_param_grads and overlap_pays(c.N)) else None
     if side is not None:
         overlap.append(side)
@@ -229,15 +271,15 @@ def _join(overlap):
         overlap.clear()
 
 
-def _enc_side(c, enc: PackedNet, p: L.DmvLatentBwd, dZ, wgt_total, zscale, dlogit_total, kl_wgt):
+def _enc_side(c, enc: PackedNet, p: L.DmvLatentBwd, dZ, wgt, zscale, dlogit, kl_wgt, gb=None, gscale=None):
     lib, st = L.lib(), L.stream_ptr()
-    d_enc = torch.zeros_like(c.enc_out)
+    d_enc = torch.empty_like(c.enc_out)          # the kernel writes every entry, padding included
     need_mix = p.base_qmix != 0.0
     L.check(lib.dmv_obj_backward_latent(
         C.byref(c.cfg), C.byref(p), L.ptr(c.enc_out), L.ptr(c.Z), L.ptr(c.eps), c.Z.shape[1],
-        L.ptr(dZ), dZ.shape[1] if dZ is not None else 0, L.ptr(wgt_total), L.ptr(zscale),
+        L.ptr(dZ), dZ.shape[1] if dZ is not None else 0, L.ptr(wgt), L.ptr(gb), L.ptr(zscale),
         L.ptr(c.comp_lp) if need_mix else None, L.ptr(c.terms[4]) if need_mix else None,
-        L.ptr(dlogit_total), L.ptr(kl_wgt), None, L.ptr(d_enc), st))
+        L.ptr(dlogit), L.ptr(kl_wgt), L.ptr(gscale), L.ptr(d_enc), st))
     _, grads = mlp_backward(enc, c.enc_saved, d_enc, c.enc_rows, need_dx=False, need_param_grads=True,
                             drop_keep=c.enc_keep)
     return grads
@@ -270,7 +312,8 @@ def _latent_params(**kw):
 
 
 class _FusedObjective(torch.autograd.Function):
-    """outputs: (per-datapoint bound [B],) or (generator objective [B,K], encoder objective [B,K])."""
+    """outputs: bound kinds (iwae, miwae, elbo_analytic): (batch mean, per-datapoint bound [B]); DeMissVAE kinds: the
+    objective(s) [B, K], or their means over (b, k) with plan.reduce_mean."""
 
     @staticmethod
     def forward(ctx, dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx, *params):
@@ -283,25 +326,31 @@ class _FusedObjective(torch.autograd.Function):
         ctx.c, ctx.dims, ctx.plan, ctx.enc, ctx.dec = c, dims, plan, enc, dec
         ctx.set_materialize_grads(False)
         k = plan.kind
+        pc = L.BOUND_PER_COMPONENT
         if k in ("iwae", "miwae"):
-            return (_bound(c, plan, training),)
+            mixture = c.q_kind == L.Q_STRATIFIED and not c.reparam
+            per_b, mean = _objective_forward(c, plan, training, kind=L.BOUND_WEIGHTED if plan.looser else L.BOUND_LSE,
+                                             use_logpi=mixture and not plan.looser)
+            return mean, per_b
         if k == "elbo_analytic":
-            return (_combine(c, (1, 0, 0, 0, 0)).reshape(c.B) - _kl(c).reshape(c.B),)
+            gen = _objective_forward(c, plan, training, kind=pc, coefA=(1, 0, 0, 0, 0))[0]
+            per_b = gen.reshape(c.B) - _kl(c).reshape(c.B)
+            return per_b.mean(), per_b
         if k == "cvi":
-            return (_combine(c, (1, 0, 1, 0, -1)),)
+            return (_objective_forward(c, plan, training, kind=pc, coefA=(1, 0, 1, 0, -1))[0],)
         if k == "mvb":
             if plan.kl_analytic:
-                return (_combine(c, (0, 1, 0, 0, 0)) - _kl(c),)
-            return (_combine(c, (0, 1, 1, -1, 0)),)
+                return (_objective_forward(c, plan, training, kind=pc, coefA=(0, 1, 0, 0, 0))[0] - _kl(c),)
+            return (_objective_forward(c, plan, training, kind=pc, coefA=(0, 1, 1, -1, 0))[0],)
         if k == "mvb2":
-            gen_obj = _combine(c, (1, 0, 1, 0, -1))
             if plan.kl_analytic:
-                enc_obj = _combine(c, (0, 1, 0, 0, 0)) - _kl(c)
-            else:
-                enc_obj = _combine(c, (0, 1, 1, -1, 0))
-            if plan.reduce_mean:
-                return gen_obj.mean(), enc_obj.mean()
-            return gen_obj, enc_obj
+                gen_obj, enc_obj, mg, _ = _objective_forward(c, plan, training, kind=pc, coefA=(1, 0, 1, 0, -1),
+                                                             coefB=(0, 1, 0, 0, 0), want_means=plan.reduce_mean)
+                enc_obj = enc_obj - _kl(c)
+                return (mg, enc_obj.mean()) if plan.reduce_mean else (gen_obj, enc_obj)
+            gen_obj, enc_obj, mg, me = _objective_forward(c, plan, training, kind=pc, coefA=(1, 0, 1, 0, -1),
+                                                          coefB=(0, 1, 1, -1, 0), want_means=plan.reduce_mean)
+            return (mg, me) if plan.reduce_mean else (gen_obj, enc_obj)
         raise NotImplementedError(k)
 
     @staticmethod
@@ -317,37 +366,42 @@ class _FusedObjective(torch.autograd.Function):
 
         def per_sample(g_bg):
             """[B] or [B,G] upstream gradient -> per-sample weights [N] (rows (s, b, g)), divided by nz."""
-            if plan.reduce_mean:        # scalar gradient of a mean over (b, g): the same weight for every sample row
-                return g_bg.float().reshape(1).expand(S * B * G) * (1.0 / (nz * B * G))
             g = g_bg.reshape(1, B, -1).float()
             return (g / nz).expand(S, B, G).contiguous().reshape(-1)
 
-        if k in ("iwae", "miwae") and gouts[0] is not None:
-            g_b = gouts[0].float().contiguous()
-            wt = (c.wgt.reshape(S, B, G) * g_b.reshape(1, B, 1)).reshape(-1).contiguous()
+        def upstream(g_mean, g_per_b):
+            """Upstream gradient of the per-datapoint bounds as the kernels take it: (gb [B] or None, gscale 0-d or
+            None, factor).  The usual loss is the batch mean: a device scalar and the host factor 1/B, no tensor math."""
+            if g_per_b is None:
+                return None, g_mean.float(), 1.0 / B
+            gb = g_per_b.float().reshape(B)
+            if g_mean is not None:
+                gb = gb + g_mean.float() / B
+            return gb.contiguous(), None, 1.0
+
+        if k in ("iwae", "miwae") and (gouts[0] is not None or gouts[1] is not None):
+            gb, gs, f = upstream(*gouts)
             pending = []
-            dZ, g_dec_params = _dec_side(c, dec, wt, 1.0, 0.0, True, True, overlap=pending)
+            dZ, g_dec_params = _dec_side(c, dec, c.wgt, f, 0.0, True, True, overlap=pending, gb=gb, gscale=gs)
             if c.reparam:
-                d_enc = _implicit_d_enc(c, dZ, wt, 1.0, -1.0)
+                wt = c.wgt * (gs * f) if gb is None else (c.wgt.reshape(S, B) * gb.reshape(1, B)).reshape(-1)
+                d_enc = _implicit_d_enc(c, dZ, wt.contiguous(), 1.0, -1.0)
                 _, g_enc_params = mlp_backward(enc, c.enc_saved, d_enc, c.enc_rows, need_dx=False, need_param_grads=True,
                                                drop_keep=c.enc_keep)
                 _join(pending)
                 return (None,) * 10 + tuple(g_enc_params) + tuple(g_dec_params)
-            mixture = c.q_kind == L.Q_STRATIFIED
-            dl = (c.dlogit * g_b.reshape(B, 1)).contiguous() if mixture else None
-            if mixture:
-                p = _latent_params(prior=1.0, qmix=-1.0, mix_live=not plan.STL, mix_kind=L.Q_STRATIFIED)
+            if c.q_kind == L.Q_STRATIFIED:
+                p = _latent_params(prior=f, qmix=-f, w=f, mix_live=not plan.STL, mix_kind=L.Q_STRATIFIED)
             else:
-                p = _latent_params(prior=1.0, qown=-1.0, own_live=not (plan.STL or plan.DREG), use_zscale=plan.DREG)
-            g_enc_params = _enc_side(c, enc, p, dZ, wt, c.zscale, dl, None)
+                p = _latent_params(prior=f, qown=-f, w=f, own_live=not (plan.STL or plan.DREG), use_zscale=plan.DREG)
+            g_enc_params = _enc_side(c, enc, p, dZ, c.wgt, c.zscale, c.dlogit, None, gb=gb, gscale=gs)
             _join(pending)
-        elif k == "elbo_analytic" and gouts[0] is not None:
-            g_b = gouts[0].float().contiguous()
-            wt = per_sample(g_b)
+        elif k == "elbo_analytic" and (gouts[0] is not None or gouts[1] is not None):
+            gb, gs, f = upstream(*gouts)
             pending = []
-            dZ, g_dec_params = _dec_side(c, dec, wt, 1.0, 0.0, True, True, overlap=pending)
-            p = _latent_params(kl=-1.0)
-            g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, g_b.reshape(B, 1).contiguous())
+            dZ, g_dec_params = _dec_side(c, dec, None, f / nz, 0.0, True, True, overlap=pending, gb=gb, gscale=gs)
+            p = _latent_params(kl=-f)
+            g_enc_params = _enc_side(c, enc, p, dZ, None, None, None, gb.reshape(B, 1) if gb is not None else None, gscale=gs)
             _join(pending)
         elif k == "cvi" and gouts[0] is not None:
             wt = per_sample(gouts[0])
@@ -371,19 +425,31 @@ class _FusedObjective(torch.autograd.Function):
             # vgiwae/shared/mvb2_manual_optimisation.py:6-8: the generator objective updates the decoder
             # only, the encoder objective the encoder only (through the decoder's input gradient).
             g_gen, g_enc = gouts
-            if g_gen is not None:
-                _, g_dec_params = _dec_side(c, dec, per_sample(g_gen), 1.0, 0.0, False, True)
-            if g_enc is not None:
-                wt = per_sample(g_enc)
-                dZ, _ = _dec_side(c, dec, wt, 0.0, 1.0, True, False)
-                if plan.kl_analytic:
-                    p = _latent_params(kl=-1.0)
-                    kl_w = g_enc.float().reshape(1, 1).expand(B, G) * (1.0 / (B * G)) if plan.reduce_mean \
-                        else g_enc.float().contiguous()
-                    g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, kl_w)
-                else:
-                    p = _latent_params(prior=1.0, qown=-1.0, own_live=not plan.STL)
-                    g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, None)
+            if plan.reduce_mean:
+                # scalar gradients of means over (b, k): every sample row weighs 1 / (nz B K), times a device scalar
+                f = 1.0 / (nz * B * G)
+                if g_gen is not None:
+                    _, g_dec_params = _dec_side(c, dec, None, f, 0.0, False, True, gscale=g_gen.float())
+                if g_enc is not None:
+                    gs = g_enc.float()
+                    dZ, _ = _dec_side(c, dec, None, 0.0, f, True, False, gscale=gs)
+                    if plan.kl_analytic:
+                        p = _latent_params(kl=-1.0 / (B * G))
+                    else:
+                        p = _latent_params(prior=f, qown=-f, own_live=not plan.STL)
+                    g_enc_params = _enc_side(c, enc, p, dZ, None, None, None, None, gscale=gs)
+            else:
+                if g_gen is not None:
+                    _, g_dec_params = _dec_side(c, dec, per_sample(g_gen), 1.0, 0.0, False, True)
+                if g_enc is not None:
+                    wt = per_sample(g_enc)
+                    dZ, _ = _dec_side(c, dec, wt, 0.0, 1.0, True, False)
+                    if plan.kl_analytic:
+                        p = _latent_params(kl=-1.0)
+                        g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, g_enc.float().contiguous())
+                    else:
+                        p = _latent_params(prior=1.0, qown=-1.0, own_live=not plan.STL)
+                        g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, None)
         return (None,) * 10 + tuple(g_enc_params) + tuple(g_dec_params)
 
 
@@ -398,6 +464,7 @@ class _DemissTerms(torch.autograd.Function):
         training = grad and any(ctx.needs_input_grad[13:])
         plan = _Plan("terms", nz, I)
         c = _forward_core(dims, plan, enc, dec, Xt, M, eps, enc_keep, dec_keep, training)
+        _objective_forward(c, plan, training, kind=L.TERMS_ONLY, want_terms=True)
         ctx.c, ctx.enc, ctx.dec, ctx.q_live, ctx.split = c, enc, dec, q_live, split
         ctx.set_materialize_grads(False)
         shape = (5, nz, I, c.B, c.G)
@@ -419,7 +486,7 @@ class _DemissTerms(torch.autograd.Function):
             return d_dec
 
         def encoder_grads(g, dZ):
-            d_enc = torch.zeros_like(c.enc_out)
+            d_enc = torch.empty_like(c.enc_out)
             L.check(lib.dmv_obj_backward_latent_terms(
                 C.byref(c.cfg), L.Q_IMPUTATION, int(ctx.q_live), L.ptr(c.enc_out), L.ptr(c.Z), L.ptr(c.eps), c.Z.shape[1],
                 L.ptr(dZ), dZ.shape[1], L.ptr(g[2]), L.ptr(g[3]), L.ptr(g[4]), None, L.ptr(c.comp_lp),
@@ -468,8 +535,7 @@ def estimate_iwelbo(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, nu
     assert not (STL and DREG), "Cannot use STL and DREG gradients at the same time."
     assert not dims.q_is_mixture
     plan = _Plan("iwae", num_latent_samples, num_importance_samples, STL=STL, DREG=DREG)
-    (per_b,) = _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx)
-    return per_b.mean(), per_b
+    return _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx)
 
 
 def estimate_elbo(dims, enc, dec, X, M, *, num_latent_samples=1, kl_analytic=True, STL=False, eps=None,
@@ -482,8 +548,7 @@ def estimate_elbo(dims, enc, dec, X, M, *, num_latent_samples=1, kl_analytic=Tru
         plan = _Plan("elbo_analytic", num_latent_samples, 1)
     else:
         plan = _Plan("iwae", num_latent_samples, 1, STL=STL)   # logsumexp over a single sample = identity
-    (per_b,) = _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx)
-    return per_b.mean(), per_b
+    return _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx)
 
 
 def estimate_multiple_iwelbo(dims, enc, dec, X, M, *, num_latent_samples=1, num_importance_samples_for_each_component=1,
@@ -491,8 +556,7 @@ def estimate_multiple_iwelbo(dims, enc, dec, X, M, *, num_latent_samples=1, num_
     """MissSIWAE bound (stratified mixture encoder).  eps [nz, I, B, C, Zd]."""
     assert dims.q_is_mixture
     plan = _Plan("miwae", num_latent_samples, num_importance_samples_for_each_component, STL=STL, looser=looser)
-    (per_b,) = _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep)
-    return per_b.mean(), per_b
+    return _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep)
 
 
 def estimate_multiple_elbo(dims, enc, dec, X, M, *, num_latent_samples=1, STL=False, eps=None, enc_keep=None,
@@ -500,8 +564,7 @@ def estimate_multiple_elbo(dims, enc, dec, X, M, *, num_latent_samples=1, STL=Fa
     """MissSVAE stratified ELBO = sum_c pi_c * ratio_c.  eps [nz, B, C, Zd]."""
     assert dims.q_is_mixture
     plan = _Plan("miwae", num_latent_samples, 1, STL=STL, looser=True)
-    (per_b,) = _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep)
-    return per_b.mean(), per_b
+    return _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep)
 
 
 def mvb2_objectives(dims, enc, dec, Xt, M, *, num_latent_samples=1, STL=False, kl_analytic=False, eps=None,

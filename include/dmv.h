@@ -162,6 +162,29 @@ int dmv_obj_terms(const DmvObjCfg* cfg, int32_t q_kind, int32_t mix_C, const flo
                   const float* X, const uint8_t* M, const float* Z, int64_t ldz, const float* enc,
                   float* terms, float* comp_lp, void* stream);
 
+/* The objective forward in ONE launch: the per-sample terms of dmv_obj_terms, the bound of dmv_obj_bound (or the
+ * per-(b,g) objectives of dmv_obj_combine) and the weights the backward needs, for a block of datapoints at a time, with
+ * the logsumexp over the importance / component axes done in LDS (vgiwae/shared/iwae.py:9-132, models/iwae.py:70-123,
+ * models/multiple_iwae.py:124-199, models/multiple_vae.py:109-160, models/mvbvae.py:83-137).  Inputs as dmv_obj_terms;
+ * every output pointer is optional except the one the chosen kind defines:
+ *   kind DMV_BOUND_LSE / _WEIGHTED: bound [B] (+ mean_out scalar), log_w [N], wgt [N], zscale [N], dlogit [B][G]
+ *        (written in full, zeros where the bound has no pi factor), with the meaning they have in dmv_obj_bound;
+ *   kind DMV_BOUND_PER_COMPONENT (I == 1): objA / objB [B][G] = mean_z sum_t coefA/B[t] * terms[t] (+ meanA/B_out scalars);
+ *   kind -1: terms only.
+ *   terms [5][N] and comp_lp [N][mix_C] are written when given.
+ * Limit: nz * I * G floats per datapoint must fit the workgroup's 60 KB of LDS (about 15 000); beyond it the call
+ * returns DMV_E_UNSUPPORTED and the caller streams with dmv_obj_terms + dmv_lse_update. */
+typedef struct DmvObjFwd {
+  int32_t q_kind, mix_C;
+  int32_t kind, use_logpi, dreg;
+  float coefA[5], coefB[5];
+  float *terms, *comp_lp, *log_w;
+  float *bound, *mean_out, *wgt, *zscale, *dlogit;
+  float *objA, *objB, *meanA_out, *meanB_out;
+} DmvObjFwd;
+int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const float* dec, int64_t ld_dec, const float* X,
+                    const uint8_t* M, const float* Z, int64_t ldz, const float* enc, void* stream);
+
 /* Bounds from the terms: log_w = terms[0] + terms[2] - terms[q] (q = 3 for DMV_Q_OWN else 4), combined
  * per datapoint by `kind` (DMV_BOUND_LSE / DMV_BOUND_WEIGHTED); use_logpi adds log pi_g inside the
  * logsumexp (models/multiple_iwae.py:127).  One wavefront per datapoint.
@@ -181,11 +204,11 @@ int dmv_obj_combine(const DmvObjCfg* cfg, const float* coef5 /* host */, const f
 /* kl[b*G+g] = sum_j KL(N(mu,sigma) || N(0,1))  (models/vae.py:404-406, models/mvbvae.py:119-122) */
 int dmv_kl_std_normal(const DmvObjCfg* cfg, const float* enc, float* kl, void* stream);
 
-/* Decoder-side backward: d_dec[n][c] = gscale * wgt[n] * (base_m * M_d + base_f) * d log p(x_d|z)/d dec[n][c]
- * for every column c < ld_ddec (zeros past the parameter count).  wgt == NULL means 1, gscale (device
- * scalar, nullable) is the upstream gradient of the scalar loss. */
+/* Decoder-side backward: d_dec[n][c] = gscale * gb[b(n)] * wgt[n] * (base_m * M_d + base_f) * d log p(x_d|z)/d dec[n][c]
+ * for every column c < ld_ddec (zeros past the parameter count).  wgt == NULL means 1; gb (nullable, [B]) is the
+ * upstream gradient of each datapoint's bound; gscale (device scalar, nullable) that of a scalar loss. */
 int dmv_obj_backward_dec(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec, const float* X, const uint8_t* M,
-                         const float* wgt, const float* gscale, float base_m, float base_f,
+                         const float* wgt, const float* gb, const float* gscale, float base_m, float base_f,
                          float* d_dec, int64_t ld_ddec, void* stream);
 
 /* Latent-side backward: gradient of
@@ -194,7 +217,11 @@ int dmv_obj_backward_dec(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec,
  *          + kl_coef * sum_{b,g} kl_wgt[b][g] * KL          (kl_wgt == NULL means 1)
  * with respect to the encoder output, through z = mu + sigma*eps (times zscale[n] when use_zscale)
  * and, when own_live / mix_live, through q's own parameters (no "sticking the landing").
- * d_enc uses the same addressing as enc and must be zero-filled by the caller. */
+ * gb (nullable, [B]): upstream gradient of each datapoint's bound; it multiplies wgt[n] and dlogit[b][.] of that
+ * datapoint (dZ carries it already when the decoder-side call was given the same gb; the KL term has kl_wgt).
+ * gscale (nullable device scalar): upstream gradient of a scalar loss; multiplies what gb multiplies and the KL term,
+ * not dZ (give the decoder-side call the same gscale).
+ * d_enc uses the same addressing as enc; every entry of it is written (padding entries as zeros). */
 typedef struct DmvLatentBwd {
   float base_prior, base_qown, base_qmix, base_w, kl_coef;
   int32_t own_live, mix_live, use_zscale;
@@ -202,8 +229,8 @@ typedef struct DmvLatentBwd {
 } DmvLatentBwd;
 int dmv_obj_backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const float* enc, const float* Z,
                             const float* eps, int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
-                            const float* zscale, const float* comp_lp, const float* qmix, const float* dlogit,
-                            const float* kl_wgt, const float* gscale, float* d_enc, void* stream);
+                            const float* gb, const float* zscale, const float* comp_lp, const float* qmix,
+                            const float* dlogit, const float* kl_wgt, const float* gscale, float* d_enc, void* stream);
 
 /* Backward from per-term cotangents, for objectives composed by the caller out of the five terms of dmv_obj_terms
  * (the importance-weighted DeMissVAE family, vgiwae/models/mvbiwae.py:97-565, combines them in a dozen ways).

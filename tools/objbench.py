@@ -45,7 +45,7 @@ def terms_fn():
 
 
 def bwd_fn():
-    L.check(lib.dmv_obj_backward_dec(C.byref(cfg), L.ptr(dec), D, L.ptr(X), L.ptr(M), L.ptr(wgt), None, 1.0, 0.0,
+    L.check(lib.dmv_obj_backward_dec(C.byref(cfg), L.ptr(dec), D, L.ptr(X), L.ptr(M), L.ptr(wgt), None, None, 1.0, 0.0,
                                      L.ptr(ddec), D, st))
 
 
