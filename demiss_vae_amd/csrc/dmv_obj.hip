@@ -33,16 +33,20 @@ __global__ void k_latent_sample(SampleArgs a) {
   const int bg = blockIdx.x * blockDim.y + threadIdx.y;
   if (bg >= BG) return;
   const int64_t b = bg / a.G;
+  const int g0 = bg - (int)b * a.G;
   const uint64_t off = a.offset + (a.offset_base ? a.offset_base[0] : 0ull);
-  for (int s = blockIdx.y; s < a.S; s += gridDim.y) {
-    const int64_t n = (int64_t)s * BG + bg;
-    const int g = a.comp_idx ? (int)a.comp_idx[n] : bg - (int)b * a.G;
-    for (int j = threadIdx.x; j < (int)a.ldz; j += blockDim.x) {
+  for (int j = threadIdx.x; j < (int)a.ldz; j += blockDim.x) {
+    // without per-row components the parameters of (b, g, j) serve every sample s: one softplus for all of them
+    float mu = 0.f, sg = 0.f;
+    if (j < a.Zd && !a.comp_idx) { mu = q_mu(a.enc, a.q, b, g0, j); sg = q_sigma(a.enc, a.q, b, g0, j); }
+    for (int s = blockIdx.y; s < a.S; s += gridDim.y) {
+      const int64_t n = (int64_t)s * BG + bg;
       const int64_t i = n * a.ldz + j;
       if (j >= a.Zd) { a.Z[i] = 0.f; if (a.eps_out) a.eps_out[i] = 0.f; continue; }
+      if (a.comp_idx) { const int g = (int)a.comp_idx[n]; mu = q_mu(a.enc, a.q, b, g, j); sg = q_sigma(a.enc, a.q, b, g, j); }
       const float e = a.eps ? a.eps[i] : dmv_philox_normal(a.seed, off + (uint64_t)i);
       if (a.eps_out) a.eps_out[i] = e;
-      a.Z[i] = q_mu(a.enc, a.q, b, g, j) + q_sigma(a.enc, a.q, b, g, j) * e;
+      a.Z[i] = mu + sg * e;
     }
   }
 }
@@ -387,10 +391,11 @@ __global__ void k_obj_bwd_dec(BwdDecArgs a) {
   }
 }
 
-// Gaussian decoders with D % 4 == 0 and 16-byte aligned rows: thread q < D/4 of a row takes dimensions 4q .. 4q+3,
-// reads their means, raw scales, data (16 bytes each) and mask bytes once and writes both gradient quads; the
-// remaining threads of the row zero the padding columns.  Same arithmetic as the generic form.
-__global__ void k_obj_bwd_dec_normal4(BwdDecArgs a) {
+// Gaussian decoders: thread (row, d) reads the mean, the raw scale, the datum and the mask byte of dimension d once and
+// writes both of its gradients (columns d and D + d); the padding columns [2D, pitch) are zeroed by the same threads.
+// These rows are short (the kernel is bound by its arithmetic, not by HBM), so every lane gets one dimension's worth of
+// transcendentals instead of a few lanes getting four; reciprocals instead of divisions.
+__global__ void k_obj_bwd_dec_normal(BwdDecArgs a) {
   const int BG = a.B * a.G;
   const int bg = blockIdx.x * blockDim.y + threadIdx.y;
   if (bg >= BG) return;
@@ -398,35 +403,25 @@ __global__ void k_obj_bwd_dec_normal4(BwdDecArgs a) {
   const int b = bg / a.G;
   const int64_t xrow = a.x_per_component ? bg : b;
   const float gbb = gs * (a.gb ? a.gb[b] : 1.f);
-  const int D4 = a.D >> 2, W4 = (int)(a.ld_ddec >> 2);
   const float eps = a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f;
+  const int ld = (int)a.ld_ddec;
   for (int s = blockIdx.y; s < a.S; s += gridDim.y) {
     const int64_t n = (int64_t)s * BG + bg;
-    const float wm = a.wgt ? a.wgt[n] : 1.f;
-    const float wf = a.wgt_f ? a.wgt_f[n] : wm;
+    const float wm = gbb * (a.wgt ? a.wgt[n] : 1.f);
+    const float wf = a.wgt_f ? gbb * a.wgt_f[n] : wm;
     const float* dec = a.dec + n * a.ld_dec;
-    f32x4* out = (f32x4*)(a.d_dec + n * a.ld_ddec);
-    for (int q = threadIdx.x; q < W4; q += blockDim.x) {
-      if (q < D4) {
-        const f32x4 mu = *(const f32x4*)(dec + 4 * q);
-        const f32x4 rw = *(const f32x4*)(dec + a.D + 4 * q);
-        const f32x4 x4 = *(const f32x4*)(a.X + xrow * a.D + 4 * q);
-        const uint32_t m4 = *(const uint32_t*)(a.M + xrow * a.D + 4 * q);
-        f32x4 gmu, grw;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float coef = gbb * ((((m4 >> (8 * e)) & 0xffu) ? wm * a.base_m : 0.f) + wf * a.base_f);
-          const float sg = dmv_softplus(rw[e]) + eps;
-          const float df = x4[e] - mu[e];
-          gmu[e] = coef * (df / (sg * sg));
-          grw[e] = coef * ((df * df / (sg * sg * sg) - 1.f / sg) * (rw[e] > 20.f ? 1.f : dmv_sigmoid(rw[e])));
-        }
-        out[q] = gmu;
-        out[q + D4] = grw;
-      } else if (q + D4 < W4) {
-        out[q + D4] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+    float* out = a.d_dec + n * a.ld_ddec;
+    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
+      const float mu = dec[d], raw = dec[a.D + d];
+      const float x = a.X[xrow * a.D + d];
+      const float coef = (a.M[xrow * a.D + d] ? wm * a.base_m : 0.f) + wf * a.base_f;
+      const float sg = dmv_softplus(raw) + eps;
+      const float rs = __builtin_amdgcn_rcpf(sg);
+      const float u = (x - mu) * rs;                       // (x - mu) / sigma
+      out[d] = coef * (u * rs);                            // (x - mu) / sigma^2
+      out[a.D + d] = coef * ((u * u - 1.f) * rs * (raw > 20.f ? 1.f : dmv_sigmoid(raw)));   // ((x-mu)^2/sigma^3 - 1/sigma) sigma'(raw)
     }
+    for (int c = 2 * a.D + threadIdx.x; c < ld; c += blockDim.x) out[c] = 0.f;
   }
 }
 
@@ -952,16 +947,26 @@ __global__ void k_latent_sample4(SampleArgs a) {
   const int bg = blockIdx.x * blockDim.y + threadIdx.y;
   if (bg >= BG) return;
   const int64_t b = bg / a.G;
+  const int g0 = bg - (int)b * a.G;
   const uint64_t off = a.offset + (a.offset_base ? a.offset_base[0] : 0ull);
   const int ld4 = (int)(a.ldz >> 2);
-  for (int s = blockIdx.y; s < a.S; s += gridDim.y) {
-    const int64_t n = (int64_t)s * BG + bg;
-    const int g = a.comp_idx ? (int)a.comp_idx[n] : bg - (int)b * a.G;
-    for (int q = threadIdx.x; q < ld4; q += blockDim.x) {
-      const int j = q << 2;
+  for (int q = threadIdx.x; q < ld4; q += blockDim.x) {
+    const int j = q << 2;
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (j < a.Zd && !a.comp_idx) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { mu[k] = q_mu(a.enc, a.q, b, g0, j + k); sg[k] = q_sigma(a.enc, a.q, b, g0, j + k); }
+    }
+    for (int s = blockIdx.y; s < a.S; s += gridDim.y) {
+      const int64_t n = (int64_t)s * BG + bg;
       const int64_t i = n * a.ldz + j;
       f32x4 z = {0.f, 0.f, 0.f, 0.f}, e = {0.f, 0.f, 0.f, 0.f};
       if (j < a.Zd) {
+        if (a.comp_idx) {
+          const int g = (int)a.comp_idx[n];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { mu[k] = q_mu(a.enc, a.q, b, g, j + k); sg[k] = q_sigma(a.enc, a.q, b, g, j + k); }
+        }
         if (a.eps) {
           e = *(const f32x4*)(a.eps + i);
         } else {
@@ -969,7 +974,7 @@ __global__ void k_latent_sample4(SampleArgs a) {
           e = f32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) z[k] = q_mu(a.enc, a.q, b, g, j + k) + q_sigma(a.enc, a.q, b, g, j + k) * e[k];
+        for (int k = 0; k < 4; ++k) z[k] = mu[k] + sg[k] * e[k];
       }
       *(f32x4*)(a.Z + i) = z;
       if (a.eps_out) *(f32x4*)(a.eps_out + i) = e;
@@ -1002,11 +1007,16 @@ extern "C" int dmv_latent_sample(const DmvObjCfg* cfg, const float* enc, const f
   if ((int64_t)cfg->B * cfg->G > 0x7fffffff) return DMV_E_UNSUPPORTED;
   a.S = S;
   dim3 grid, block;
+  // a thread walks the samples of its (b, g, position): the grid's second dimension only has to bring the number of
+  // workgroups to a few thousand when there are few datapoints and many samples
+  auto slices = [&](unsigned gx) { const int64_t want = (4096 + gx - 1) / gx; return (unsigned)(want > S ? S : want); };
   if ((cfg->Zd & 3) == 0 && (ldz & 3) == 0 && (offset & 3) == 0 && (al & 15) == 0) {
     row_geometry((int)(ldz >> 2), cfg->B * cfg->G, S, grid, block);
+    grid.y = slices(grid.x);
     hipLaunchKernelGGL(k_latent_sample4, grid, block, 0, (hipStream_t)stream, a);
   } else {
     row_geometry((int)ldz, cfg->B * cfg->G, S, grid, block);
+    grid.y = slices(grid.x);
     hipLaunchKernelGGL(k_latent_sample, grid, block, 0, (hipStream_t)stream, a);
   }
   DMV_HIP_CHECK_LAUNCH();
@@ -1143,9 +1153,9 @@ static int backward_dec(const DmvObjCfg* cfg, const float* dec, int64_t ld_dec, 
     const int W4 = (int)(ld_ddec / 4), bx = W4 > 64 ? 256 : 64;
     grid = dim3((unsigned)((W4 + bx - 1) / bx), (unsigned)(BG > 65535 ? 65535 : BG));
     hipLaunchKernelGGL(k_obj_bwd_dec_bern4, grid, dim3(bx), 0, (hipStream_t)stream, a);
-  } else if (normal && aligned) {
-    row_geometry((int)(ld_ddec >> 2), BG, a.S, grid, block);
-    hipLaunchKernelGGL(k_obj_bwd_dec_normal4, grid, block, 0, (hipStream_t)stream, a);
+  } else if (normal) {
+    row_geometry(cfg->D, BG, a.S, grid, block);
+    hipLaunchKernelGGL(k_obj_bwd_dec_normal, grid, block, 0, (hipStream_t)stream, a);
   } else {
     row_geometry((int)ld_ddec, BG, a.S, grid, block);
     hipLaunchKernelGGL(k_obj_bwd_dec, grid, block, 0, (hipStream_t)stream, a);

@@ -24,6 +24,7 @@ struct FwdArgs {
   int use_logpi, dreg;
   int DPB, T;      // datapoints per workgroup; lanes per datapoint in the logsumexp stage
   int vec4;
+  int nC;          // components per datapoint in the LDS table of q's parameters (0: no table, q evaluated from enc)
   QAddr q;
   const float* __restrict__ dec; int64_t ld_dec;
   const float* __restrict__ X; const uint8_t* __restrict__ M;
@@ -40,10 +41,28 @@ struct FwdArgs {
   float* __restrict__ objA; float* __restrict__ objB;
 };
 
-// the five terms of one sample row, summed over the R lanes of the group (every lane returns the totals)
+// log N(x; mu, sigma) with the division replaced by a reciprocal (1 ulp): -((x - mu) / sigma)^2 / 2 - log sigma - c
+__device__ __forceinline__ float log_normal_r(float x, float mu, float sigma) {
+  const float d = (x - mu) * __builtin_amdgcn_rcpf(sigma);
+  return -0.5f * d * d - dmv_log(sigma) - LOG_SQRT_2PI;
+}
+
+// One entry of the LDS table of q's parameters: log N(z; mu, sigma) = -(z - mu)^2 * inv2s2 - lnorm.  The softplus, the
+// logarithm and the reciprocal are paid once per (datapoint, component, dimension) of the workgroup instead of once
+// per sample row that evaluates the component.
+struct __attribute__((aligned(16))) QEntry { float mu, inv2s2, lnorm, pad; };
+
+__device__ __forceinline__ float q_logp(const QEntry& e, float z) {
+  const float d = z - e.mu;
+  return -(d * d) * e.inv2s2 - e.lnorm;
+}
+
+// the five terms of one sample row, summed over the R lanes of the group (every lane returns the totals).
+// qt: the workgroup's table [DPB][nC][Zd] (null: evaluate q from the encoder output), bl: datapoint within the workgroup
 template <int R>
-__device__ __forceinline__ void row_terms(const FwdArgs& a, int r, int64_t n, int64_t b, int g, const float* __restrict__ X,
-                                          const uint8_t* __restrict__ M, float& gm, float& gf, float& pr, float& qo, float& qm) {
+__device__ __forceinline__ void row_terms(const FwdArgs& a, int r, int64_t n, int64_t b, int bl, int g, const QEntry* qt,
+                                          const float* __restrict__ X, const uint8_t* __restrict__ M, float& gm, float& gf,
+                                          float& pr, float& qo, float& qm) {
   const float* __restrict__ dec = a.dec + n * a.ld_dec;
   gm = 0.f; gf = 0.f;
   if (a.vec4) {
@@ -65,7 +84,7 @@ __device__ __forceinline__ void row_terms(const FwdArgs& a, int r, int64_t n, in
       const float x = X[d];
       if (a.gen_dist <= DMV_GEN_NORMAL_EPS) {
         const float s = dmv_softplus(dec[a.D + d]) + (a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f);
-        lp = log_normal(x, dec[d], s);
+        lp = log_normal_r(x, dec[d], s);
       } else if (a.gen_dist == DMV_GEN_BERN) {
         lp = log_bern(x, dec[d]);
       } else {
@@ -73,16 +92,17 @@ __device__ __forceinline__ void row_terms(const FwdArgs& a, int r, int64_t n, in
       }
       gf += lp;
       gm += lp * (M[d] ? 1.f : 0.f);     // the product the reference forms (shared/iwae.py:20): a non-finite lp at a
-                                  // missing entry makes the row's log-weight NaN there and here alike
+                                         // missing entry makes the row's log-weight NaN there and here alike
     }
   }
   const float* __restrict__ z = a.Z + n * a.ldz;
   pr = 0.f; qo = 0.f;
   const bool own = a.q_kind != DMV_Q_STRATIFIED || a.G > 1;   // rows sampled from the mixture itself have no own component
+  const QEntry* qb = qt ? qt + (size_t)bl * a.nC * a.Zd : nullptr;
   for (int j = r; j < a.Zd; j += R) {
     const float zj = z[j];
     pr += -(zj * zj) * 0.5f - LOG_SQRT_2PI;
-    if (own) qo += log_normal(zj, q_mu(a.enc, a.q, b, g, j), q_sigma(a.enc, a.q, b, g, j));
+    if (own) qo += qb ? q_logp(qb[g * a.Zd + j], zj) : log_normal_r(zj, q_mu(a.enc, a.q, b, g, j), q_sigma(a.enc, a.q, b, g, j));
   }
   gm = gsum<R>(gm); gf = gsum<R>(gf); pr = gsum<R>(pr); qo = gsum<R>(qo);
   qm = qo;
@@ -93,22 +113,29 @@ __device__ __forceinline__ void row_terms(const FwdArgs& a, int r, int64_t n, in
       float lm = -INFINITY;
       for (int c = 0; c < a.mix_C; ++c) lm = fmaxf(lm, lg[c]);
       float ss = 0.f;
-      for (int c = 0; c < a.mix_C; ++c) ss += expf(lg[c] - lm);
-      lse_logit = lm + logf(ss);
+      for (int c = 0; c < a.mix_C; ++c) ss += dmv_exp(lg[c] - lm);
+      lse_logit = lm + dmv_log(ss);
     }
     for (int c = 0; c < a.mix_C; ++c) {
       float lp = 0.f;
-      for (int j = r; j < a.Zd; j += R) lp += log_normal(z[j], q_mu(a.enc, a.q, b, c, j), q_sigma(a.enc, a.q, b, c, j));
+      if (qb) {
+        for (int j = r; j < a.Zd; j += R) lp += q_logp(qb[c * a.Zd + j], z[j]);
+      } else {
+        for (int j = r; j < a.Zd; j += R) lp += log_normal_r(z[j], q_mu(a.enc, a.q, b, c, j), q_sigma(a.enc, a.q, b, c, j));
+      }
       lp = gsum<R>(lp);
       if (a.comp_lp && r == 0) a.comp_lp[n * a.mix_C + c] = lp;
       const float t = lp + (a.q_kind == DMV_Q_STRATIFIED ? lg[c] - lse_logit : 0.f);
       const float nm = fmaxf(mx, t);
-      se = se * expf(mx - nm) + expf(t - nm);
+      se = se * dmv_exp(mx - nm) + dmv_exp(t - nm);
       mx = nm;
     }
-    qm = mx + logf(se) - (a.q_kind == DMV_Q_IMPUTATION ? logf((float)a.mix_C) : 0.f);
+    qm = mx + dmv_log(se) - (a.q_kind == DMV_Q_IMPUTATION ? dmv_log((float)a.mix_C) : 0.f);
   }
 }
+
+__device__ __forceinline__ void bound_phases(const FwdArgs& a, float* lw, float* aux, int tid, int nthr, int b0, int nb, int Qn,
+                                             int Q, int64_t BG, int64_t row0);
 
 __device__ __forceinline__ float tsum(float v, int T) {
   for (int o = T >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -131,9 +158,22 @@ __global__ void __launch_bounds__(256) k_obj_fwd(FwdArgs a) {
   const int64_t BG = (int64_t)a.B * a.G;
   const int64_t N = BG * a.S;
   const int64_t row0 = (int64_t)b0 * a.G;
-  float* lw = sm;                         // [S][Q] log-weights, later the weights (PER_COMPONENT: objA summands)
-  float* aux = sm + (size_t)a.S * Q;      // PER_COMPONENT: [S][Q] objB summands; else [3][Q]: log pi, L_g, dlogit
   const bool per_comp = a.kind == DMV_BOUND_PER_COMPONENT;
+  // LDS: the q table first (16-byte entries), then the log-weights and the mixture bookkeeping
+  QEntry* qt = a.nC ? (QEntry*)sm : nullptr;
+  float* lw = sm + (size_t)4 * a.DPB * a.nC * a.Zd;   // [S][Q] log-weights, later the weights (PER_COMPONENT: objA summands)
+  float* aux = lw + (a.kind < 0 ? 0 : (size_t)a.S * Q);   // PER_COMPONENT: [S][Q] objB summands; else [3][Q]: log pi, L_g, dlogit
+  if (qt) {
+    const int per_dp = a.nC * a.Zd;
+    for (int e = tid; e < nb * per_dp; e += nthr) {
+      const int bl = e / per_dp, rem = e - bl * per_dp;
+      const int c = rem / a.Zd, j = rem - c * a.Zd;
+      const float sg = q_sigma(a.enc, a.q, b0 + bl, c, j);
+      const float rs = __builtin_amdgcn_rcpf(sg);
+      qt[e] = QEntry{q_mu(a.enc, a.q, b0 + bl, c, j), 0.5f * rs * rs, dmv_log(sg) + LOG_SQRT_2PI, 0.f};
+    }
+    __syncthreads();
+  }
 
   // ---- phase 1: terms of every row of the block's datapoints
   for (int q = grp; q < Qn; q += NG) {
@@ -145,7 +185,7 @@ __global__ void __launch_bounds__(256) k_obj_fwd(FwdArgs a) {
     for (int s = blockIdx.y; s < a.S; s += gridDim.y) {     // gridDim.y > 1 only when no bound is formed (terms only)
       const int64_t n = (int64_t)s * BG + row0 + q;
       float gm, gf, pr, qo, qm;
-      row_terms<R>(a, r, n, b, g, X, M, gm, gf, pr, qo, qm);
+      row_terms<R>(a, r, n, b, bl, g, qt, X, M, gm, gf, pr, qo, qm);
       if (r == 0) {
         if (a.terms) {
           a.terms[n] = gm; a.terms[N + n] = gf; a.terms[2 * N + n] = pr; a.terms[3 * N + n] = qo; a.terms[4 * N + n] = qm;
@@ -169,7 +209,14 @@ __global__ void __launch_bounds__(256) k_obj_fwd(FwdArgs a) {
     }
   }
   if (a.kind < 0) return;
+  bound_phases(a, lw, aux, tid, nthr, b0, nb, Qn, Q, BG, row0);
+}
 
+// Everything after the log-weights of a workgroup's rows are in LDS: bounds by logsumexp over (i, g), weights of the
+// backward, mixture-logit gradients, per-component objectives.  lw [S][Q], aux as laid out by the kernels.
+__device__ __forceinline__ void bound_phases(const FwdArgs& a, float* lw, float* aux, int tid, int nthr, int b0, int nb, int Qn,
+                                             int Q, int64_t BG, int64_t row0) {
+  const bool per_comp = a.kind == DMV_BOUND_PER_COMPONENT;
   // ---- normalised log mixture weights of the block's datapoints
   const bool need_pi = !per_comp && (a.use_logpi || a.kind == DMV_BOUND_WEIGHTED);
   float* lpi = aux;
@@ -289,6 +336,133 @@ __global__ void __launch_bounds__(256) k_obj_fwd(FwdArgs a) {
     }
 }
 
+// Short, 16-byte aligned rows of a Gaussian decoder (D and Zd multiples of 4: the UCI-gas shapes of the headline
+// configuration): one THREAD per sample row, D4 = D / 4 and Z4 = Zd / 4 known at compile time.  With a group of lanes per
+// row most instructions of a wave are address arithmetic, reductions and loop control around a handful of useful
+// operations per lane, and the kernel is bound by instruction issue; one lane per row spends its instructions on the
+// row, and because the loops unroll completely every load of the row (2 D4 + Z4 of 16 bytes, plus data and mask) is
+// issued before the first is used.  The logsumexp stage is the same as in the general kernel.
+template <int D4, int Z4>
+__global__ void __launch_bounds__(256) k_obj_fwd_rows4(FwdArgs a) {
+  extern __shared__ float sm[];
+  constexpr int D = 4 * D4, Zd = 4 * Z4;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int b0 = blockIdx.x * a.DPB;
+  const int nb = min(a.DPB, a.B - b0);
+  const int Qn = nb * a.G, Q = a.DPB * a.G;
+  const int64_t BG = (int64_t)a.B * a.G;
+  const int64_t N = BG * a.S;
+  const int64_t row0 = (int64_t)b0 * a.G;
+  const bool per_comp = a.kind == DMV_BOUND_PER_COMPONENT;
+  // a datapoint's table entries are followed by one unused entry: 64 lanes on 64 datapoints then read 16-byte entries at
+  // a stride that is not a multiple of the bank width
+  const int qstride = a.nC * Zd + 1;
+  QEntry* qt = (QEntry*)sm;
+  float* lw = sm + (size_t)4 * a.DPB * qstride;
+  float* aux = lw + (a.kind < 0 ? 0 : (size_t)a.S * Q);
+
+  // this thread's row: loads first
+  const int t = tid;
+  const bool live = t < a.S * Qn;
+  const int s = live ? t / Qn : 0, q = live ? t - s * Qn : 0;
+  const int bl = q / a.G, g = q - bl * a.G;
+  const int64_t b = b0 + bl;
+  const int64_t n = (int64_t)s * BG + row0 + q;
+  const int64_t xrow = a.xpc ? row0 + q : b;
+  f32x4 dm[D4], dr[D4], xx[D4], zz[Z4];
+  uint32_t mm[D4];
+  {
+    const f32x4* dp = (const f32x4*)(a.dec + n * a.ld_dec);
+    const f32x4* xp = (const f32x4*)(a.X + xrow * D);
+    const uint32_t* mp = (const uint32_t*)(a.M + xrow * D);
+    const f32x4* zp = (const f32x4*)(a.Z + n * a.ldz);
+#pragma unroll
+    for (int k = 0; k < D4; ++k) { dm[k] = dp[k]; dr[k] = dp[D4 + k]; xx[k] = xp[k]; mm[k] = mp[k]; }
+#pragma unroll
+    for (int k = 0; k < Z4; ++k) zz[k] = zp[k];
+  }
+  {
+    const int per_dp = a.nC * Zd;
+    for (int e = tid; e < nb * per_dp; e += nthr) {
+      const int el = e / per_dp, rem = e - el * per_dp;
+      const int c = rem / Zd, j = rem - c * Zd;
+      const float sg = q_sigma(a.enc, a.q, b0 + el, c, j);
+      const float rs = __builtin_amdgcn_rcpf(sg);
+      qt[el * qstride + rem] = QEntry{q_mu(a.enc, a.q, b0 + el, c, j), 0.5f * rs * rs, dmv_log(sg) + LOG_SQRT_2PI, 0.f};
+    }
+  }
+  __syncthreads();
+
+  if (live) {
+    const float geps = a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f;
+    const bool own = a.q_kind != DMV_Q_STRATIFIED || a.G > 1;
+    float gm = 0.f, gf = 0.f;
+#pragma unroll
+    for (int k = 0; k < D4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lp = log_normal_r(xx[k][e], dm[k][e], dmv_softplus(dr[k][e]) + geps);
+        gf += lp;
+        gm += lp * (((mm[k] >> (8 * e)) & 0xffu) ? 1.f : 0.f);
+      }
+    const QEntry* qb = qt + (size_t)bl * qstride;
+    float pr = 0.f, qo = 0.f;
+#pragma unroll
+    for (int k = 0; k < Z4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float zj = zz[k][e];
+        pr += -(zj * zj) * 0.5f - LOG_SQRT_2PI;
+        if (own) qo += q_logp(qb[g * Zd + 4 * k + e], zj);
+      }
+    float qm = qo;
+    if (a.q_kind != DMV_Q_OWN) {
+      float mx = -INFINITY, se = 0.f, lse_logit = 0.f;
+      const float* __restrict__ lg = a.enc + b * a.q.sb + a.q.logit_off;
+      if (a.q_kind == DMV_Q_STRATIFIED) {
+        float lm = -INFINITY;
+        for (int c = 0; c < a.mix_C; ++c) lm = fmaxf(lm, lg[c]);
+        float ss = 0.f;
+        for (int c = 0; c < a.mix_C; ++c) ss += dmv_exp(lg[c] - lm);
+        lse_logit = lm + dmv_log(ss);
+      }
+      for (int c = 0; c < a.mix_C; ++c) {
+        float lp = 0.f;
+#pragma unroll
+        for (int k = 0; k < Z4; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lp += q_logp(qb[c * Zd + 4 * k + e], zz[k][e]);
+        if (a.comp_lp) a.comp_lp[n * a.mix_C + c] = lp;
+        const float tt = lp + (a.q_kind == DMV_Q_STRATIFIED ? lg[c] - lse_logit : 0.f);
+        const float nm = fmaxf(mx, tt);
+        se = se * dmv_exp(mx - nm) + dmv_exp(tt - nm);
+        mx = nm;
+      }
+      qm = mx + dmv_log(se) - (a.q_kind == DMV_Q_IMPUTATION ? dmv_log((float)a.mix_C) : 0.f);
+    }
+    if (a.terms) {
+      a.terms[n] = gm; a.terms[N + n] = gf; a.terms[2 * N + n] = pr; a.terms[3 * N + n] = qo; a.terms[4 * N + n] = qm;
+    }
+    if (per_comp) {
+      const float t5[5] = {gm, gf, pr, qo, qm};
+      float vA = 0.f, vB = 0.f;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        if (a.cA[k] != 0.f) vA += a.cA[k] * t5[k];
+        if (a.cB[k] != 0.f) vB += a.cB[k] * t5[k];
+      }
+      lw[s * Q + q] = vA;
+      aux[s * Q + q] = vB;
+    } else if (a.kind >= 0) {
+      const float w = gm + pr - (a.q_term == 3 ? qo : qm);
+      lw[s * Q + q] = w;
+      if (a.log_w) a.log_w[n] = w;
+    }
+  }
+  if (a.kind < 0) return;
+  bound_phases(a, lw, aux, tid, nthr, b0, nb, Qn, Q, BG, row0);
+}
+
 // means of one or two arrays in one single-workgroup launch
 __global__ void k_mean2(const float* __restrict__ v1, const float* __restrict__ v2, int64_t n, float scale,
                         float* __restrict__ o1, float* __restrict__ o2) {
@@ -338,38 +512,100 @@ extern "C" int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const f
   a.vec4 = cfg->gen_dist >= DMV_GEN_BERN && (cfg->D & 3) == 0 && (ld_dec & 3) == 0 &&
            ((((uintptr_t)dec | (uintptr_t)X) & 15) == 0) && (((uintptr_t)M & 3) == 0);
 
+  const int nC_full = f->q_kind == DMV_Q_OWN ? cfg->G : f->mix_C;
+  const size_t lds_max = 60 * 1024;
+  const int64_t pairs = (int64_t)cfg->B * cfg->G;
+  hipStream_t st = (hipStream_t)stream;
+  auto means = [&]() -> int {
+    if (f->mean_out || f->meanA_out || f->meanB_out) {
+      if (kind == DMV_BOUND_PER_COMPONENT) {
+        hipLaunchKernelGGL(k_mean2, dim3(1), dim3(256), 0, st, (const float*)f->objA, (const float*)f->objB, pairs,
+                           1.f / (float)pairs, f->meanA_out, f->meanB_out);
+      } else if (kind >= 0) {
+        hipLaunchKernelGGL(k_mean2, dim3(1), dim3(256), 0, st, (const float*)f->bound, (const float*)nullptr, (int64_t)cfg->B,
+                           1.f / (float)cfg->B, f->mean_out, (float*)nullptr);
+      }
+      DMV_HIP_CHECK_LAUNCH();
+    }
+    return DMV_OK;
+  };
+
+  // ---- short aligned Gaussian rows: one thread per row (every sample of a workgroup's datapoints in one pass)
+  const int SG = a.S * cfg->G;
+  const bool aligned4 = cfg->gen_dist <= DMV_GEN_NORMAL_EPS && (cfg->D & 3) == 0 && (cfg->Zd & 3) == 0 && (ld_dec & 3) == 0 &&
+                        (ldz & 3) == 0 && ((((uintptr_t)dec | (uintptr_t)X | (uintptr_t)Z) & 15) == 0) && (((uintptr_t)M & 3) == 0);
+  const int D4 = cfg->D >> 2, Z4 = cfg->Zd >> 2;
+  if (aligned4 && SG <= 256 && (D4 == 1 || D4 == 2 || D4 == 4) && (Z4 == 1 || Z4 == 2 || Z4 == 4 || Z4 == 8)) {
+    auto rows_lds = [&](int dpb) {
+      const size_t Q = (size_t)dpb * cfg->G;
+      const size_t bound_part = kind < 0 ? 0 : (size_t)a.S * Q + (kind == DMV_BOUND_PER_COMPONENT ? (size_t)a.S * Q : 3 * Q);
+      return sizeof(float) * (bound_part + (size_t)4 * dpb * (nC_full * cfg->Zd + 1));
+    };
+    int nthr = pairs * a.S >= 256 * 512 ? 256 : 64;       // small batches: more, smaller workgroups
+    int DPB = nthr / SG;
+    if (DPB < 1) { nthr = 256; DPB = 256 / SG; }
+    while (DPB > 1 && rows_lds(DPB) > lds_max) --DPB;
+    if (rows_lds(DPB) <= lds_max) {
+      a.DPB = DPB; a.nC = nC_full;
+      int T = pow2_ceil(cfg->I * cfg->G);
+      if (T > 64) T = 64;
+      if (T > nthr) T = nthr;
+      a.T = T;
+      const dim3 grid((unsigned)((cfg->B + DPB - 1) / DPB)), block(nthr);
+      const size_t lds = rows_lds(DPB);
+#define DMV_ROWS4(d4, z4) \
+  if (D4 == d4 && Z4 == z4) hipLaunchKernelGGL((k_obj_fwd_rows4<d4, z4>), grid, block, lds, st, a)
+      DMV_ROWS4(1, 1); DMV_ROWS4(1, 2); DMV_ROWS4(1, 4); DMV_ROWS4(1, 8);
+      DMV_ROWS4(2, 1); DMV_ROWS4(2, 2); DMV_ROWS4(2, 4); DMV_ROWS4(2, 8);
+      DMV_ROWS4(4, 1); DMV_ROWS4(4, 2); DMV_ROWS4(4, 4); DMV_ROWS4(4, 8);
+#undef DMV_ROWS4
+      DMV_HIP_CHECK_LAUNCH();
+      return means();
+    }
+  }
+
   // lanes per row by the longer of the two row kinds; workgroup size by how many datapoints there are
   const int span = cfg->D > cfg->Zd ? cfg->D : cfg->Zd;
   const int R = span <= 8 ? 1 : span <= 32 ? 8 : span <= 96 ? 16 : 64;
   int nthr = 256;
-  const int64_t pairs = (int64_t)cfg->B * cfg->G;
   if (pairs * R < 256 * 256) nthr = 64;            // small batches: more, smaller workgroups
   const int NG = nthr / R;
   int DPB = NG / cfg->G;
   if (DPB < 1) DPB = 1;
-  // LDS: S*Q log-weights (+ S*Q for the second objective, or 3*Q of mixture bookkeeping)
-  const size_t lds_max = 60 * 1024;
-  auto lds_bytes = [&](int dpb) {
+  {
+    // keep every group busy in every round: if the (b, g) pairs of a workgroup do not fill whole rounds of NG groups
+    // (less than 90 % of them), take the smallest count of datapoints that does
+    const int Q0 = DPB * cfg->G, rounds = (Q0 + NG - 1) / NG;
+    if (Q0 * 10 < rounds * NG * 9) {
+      int x = NG, y = cfg->G;
+      while (y) { const int t = x % y; x = y; y = t; }
+      if (NG / x <= 64) DPB = NG / x;
+    }
+  }
+  // LDS: the q table (16 bytes per (datapoint, component, dimension)), S*Q log-weights (twice for the two objectives of
+  // the per-component kind) and 3*Q floats of mixture bookkeeping
+  auto lds_bytes = [&](int dpb, int nC) {
     const size_t Q = (size_t)dpb * cfg->G;
-    return sizeof(float) * ((size_t)a.S * Q * (kind == DMV_BOUND_PER_COMPONENT ? 2 : 1) + 3 * Q);
+    const size_t bound_part = kind < 0 ? 0 : (size_t)a.S * Q * (kind == DMV_BOUND_PER_COMPONENT ? 2 : 1) + 3 * Q;
+    return sizeof(float) * (bound_part + (size_t)4 * dpb * nC * cfg->Zd);
   };
-  while (DPB > 1 && kind >= 0 && lds_bytes(DPB) > lds_max) DPB >>= 1;
-  if (kind >= 0 && lds_bytes(DPB) > lds_max) return DMV_E_UNSUPPORTED;   // nz*I*G beyond ~15 000: stream with dmv_lse_update
-  a.DPB = DPB;
+  int nC = nC_full;
+  while (DPB > 1 && lds_bytes(DPB, nC) > lds_max) DPB >>= 1;
+  if (lds_bytes(DPB, nC) > lds_max) nC = 0;                       // too many components for a table: evaluate q directly
+  if (lds_bytes(DPB, nC) > lds_max) return DMV_E_UNSUPPORTED;     // nz*I*G beyond ~15 000: stream with dmv_lse_update
+  a.DPB = DPB; a.nC = nC;
   int T = pow2_ceil(cfg->I * cfg->G);
   if (T > 64) T = 64;
   if (T > nthr) T = nthr;
   a.T = T;
   dim3 grid((unsigned)((cfg->B + DPB - 1) / DPB));
-  size_t lds = lds_bytes(DPB);
+  const size_t lds = lds_bytes(DPB, nC);
   if (kind < 0) {
     // terms only: nothing couples the samples of a datapoint, so few datapoints with many samples (the K-sample
     // log-likelihood) spread over the grid's second dimension
-    lds = 0;
     const int64_t want = 2048 / grid.x;
     grid.y = (unsigned)(want < 1 ? 1 : want > a.S ? a.S : want > 65535 ? 65535 : want);
   }
-  hipStream_t st = (hipStream_t)stream;
   switch (R) {
     case 1: hipLaunchKernelGGL(k_obj_fwd<1>, grid, dim3(nthr), lds, st, a); break;
     case 8: hipLaunchKernelGGL(k_obj_fwd<8>, grid, dim3(nthr), lds, st, a); break;
@@ -377,15 +613,5 @@ extern "C" int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const f
     default: hipLaunchKernelGGL(k_obj_fwd<64>, grid, dim3(nthr), lds, st, a); break;
   }
   DMV_HIP_CHECK_LAUNCH();
-  if (f->mean_out || f->meanA_out || f->meanB_out) {
-    if (kind == DMV_BOUND_PER_COMPONENT) {
-      hipLaunchKernelGGL(k_mean2, dim3(1), dim3(256), 0, st, (const float*)f->objA, (const float*)f->objB, pairs,
-                         1.f / (float)pairs, f->meanA_out, f->meanB_out);
-    } else if (kind >= 0) {
-      hipLaunchKernelGGL(k_mean2, dim3(1), dim3(256), 0, st, (const float*)f->bound, (const float*)nullptr, (int64_t)cfg->B,
-                         1.f / (float)cfg->B, f->mean_out, (float*)nullptr);
-    }
-    DMV_HIP_CHECK_LAUNCH();
-  }
-  return DMV_OK;
+  return means();
 }

@@ -34,9 +34,11 @@ struct dmv_f4 { float v[4]; };
 // standard normals for elements 4 q .. 4 q + 3 of stream `seed`
 __device__ inline dmv_f4 dmv_philox_normal4(uint64_t seed, uint64_t q) {
   const dmv_u4 r = dmv_philox4x32_10(seed, q, 0x6e6f726dull /* "norm" */);
-  const float r0 = sqrtf(-2.f * __logf(dmv_u01(r.x))), r1 = sqrtf(-2.f * __logf(dmv_u01(r.z)));
-  const float a0 = 2.f * dmv_u01(r.y), a1 = 2.f * dmv_u01(r.w);
-  return dmv_f4{{r0 * cospif(a0), r0 * sinpif(a0), r1 * cospif(a1), r1 * sinpif(a1)}};
+  // Box-Muller; the angle goes to the hardware sine / cosine, which take their argument in revolutions
+  const float r0 = __builtin_amdgcn_sqrtf(-2.f * __logf(dmv_u01(r.x))), r1 = __builtin_amdgcn_sqrtf(-2.f * __logf(dmv_u01(r.z)));
+  const float a0 = dmv_u01(r.y), a1 = dmv_u01(r.w);
+  return dmv_f4{{r0 * __builtin_amdgcn_cosf(a0), r0 * __builtin_amdgcn_sinf(a0), r1 * __builtin_amdgcn_cosf(a1),
+                 r1 * __builtin_amdgcn_sinf(a1)}};
 }
 __device__ inline float dmv_philox_normal(uint64_t seed, uint64_t idx) {
   return dmv_philox_normal4(seed, idx >> 2).v[idx & 3];
