@@ -32,8 +32,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X fp32 matrix peak (dense)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32768, help="datapoints per GPU per step")
     ap.add_argument("--with-conv", action="store_true",
                     help="also time the image DeMissVAE step with convolutional trunks (MIOpen warm-up takes a while)")
@@ -51,19 +51,14 @@ def mlp_flops_per_row(spec):
 
 
 def make_gas(device, B, seed=20220118):
+    """UCI-gas MissIWAE shapes (configs/uci_gas/compare/mis50/iwae_i5_encm_stl.yaml) with synthetic data and
+    nn.Linear-style random weights; product-side generators only (the oracle is used by the CPU baseline alone)."""
     import demiss_vae_amd as dmv
-    from oracle.recipes import NetSpec, make_params, make_batch
-    enc_s, dec_s = NetSpec(16, 32, 2, 256), NetSpec(16, 16, 2, 256)
-    ep, dp = make_params(enc_s, seed), make_params(dec_s, seed + 1)
-
-    def packed(spec, params):
-        ws = [params[n + ".weight"].to(device).requires_grad_(True) for n in spec.layer_names()]
-        bs = [params[n + ".bias"].to(device).requires_grad_(True) for n in spec.layer_names()]
-        return dmv.PackedNet(dmv.NetDims(spec.in_dim, spec.out_dim, spec.nb, spec.hidden), ws, bs)
-
-    enc, dec = packed(enc_s, ep), packed(dec_s, dp)
+    from demiss_vae_amd import synth
+    enc_s, dec_s = synth.NetShape(16, 32, 2, 256), synth.NetShape(16, 16, 2, 256)
+    enc, dec = synth.packed_net(enc_s, seed, device), synth.packed_net(dec_s, seed + 1, device)
     dims = dmv.ModelDims(D=8, Zd=16, gen_dist="normal_with_eps", q_dist="normal_with_eps", encoder_use_mis_mask=True)
-    X, M = make_batch(seed + 2, B, 8)
+    X, M = synth.batch(seed + 2, B, 8)
     return dims, enc, dec, enc_s, dec_s, X.to(device), M.to(device)
 
 
@@ -93,21 +88,30 @@ def event_time(fn, reps):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+PROFILE_MD = "profiles/r2_decoder_kernels.md"   # written by tools/prof.sh + tools/summarize_prof.py from `bench.py --kernels-only`
+
+
 def profiled_traffic(rows, kernel):
-    """HBM bytes per launch of the named kernel at this size, from the committed rocprofv3 PMC passes of
-    `bench.py --kernels-only` (FETCH_SIZE / WRITE_SIZE in runs of their own, gfx950 unit correction applied by
-    tools/summarize_prof.py); counters cannot be collected from inside this process, so null without the summary."""
+    """HBM bytes per launch of the named kernel, from the committed rocprofv3 PMC passes of `bench.py --kernels-only`
+    (FETCH_SIZE / WRITE_SIZE in runs of their own, gfx950 unit correction applied by tools/summarize_prof.py).  Counters
+    cannot be collected from inside this process, so the record is null unless the committed summary is of this very
+    workload: the same row count (stated in its title) and a section for the kernel that is timed here."""
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_decoder_kernels.md")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PROFILE_MD)
     try:
-        if rows != 163840:
-            return {"traffic": None}
         text = open(path).read()
-        head = {"k_mlp_fwd": "### void k_mlp_fwd", "k_mlp_bwd": "### void k_mlp_bwd"}.get(kernel, "### k_mlp_wgrad")
-        sec = text[text.index(head):]
+        if f"{rows} rows" not in text.splitlines()[0]:
+            return {"traffic": None}
+        pat = {"k_mlp_fwd": r"^### .*k_mlp_fwd<", "k_mlp_bwd": r"^### .*k_mlp_bwd<"}.get(kernel, r"^### .*k_mlp_wgrad")
+        m0 = re.search(pat, text, re.M)
+        sec = text[m0.start():]
+        sec = sec[:sec.index("\n### ", 4)] if "\n### " in sec[4:] else sec
         m = re.search(r"HBM read bytes[^=]*=[^=]*= ([\d.,]+) MB; written = ([\d.,]+) MB", sec)
+        trace = re.search(r"^\| [^|]*" + {"k_mlp_fwd": "k_mlp_fwd<", "k_mlp_bwd": "k_mlp_bwd<"}.get(kernel, "k_mlp_wgrad") +
+                          r"[^|]*\| \d+ \| ([\d.]+) \|", text, re.M)
         return {"traffic": sum(float(m.group(i).replace(",", "")) for i in (1, 2)) * 1e6, "traffic_unit": "bytes per launch",
-                "traffic_source": "profiles/r1_decoder_kernels.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 163840 rows)"}
+                "traffic_source": f"{PROFILE_MD} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {rows} rows)",
+                "profile_avg_us": float(trace.group(1)) if trace else None}
     except Exception:
         return {"traffic": None}
 
@@ -231,12 +235,15 @@ def main():
 
     import demiss_vae_amd as dmv
     from demiss_vae_amd import rng
-    from demiss_vae_amd.parallel import all_reduce, allreduce_grads
+    from demiss_vae_amd.parallel import all_reduce, allreduce_grads, overlap_grad_exchange
     rng.set_seed(20220118 + rank)
 
     B, K = args.batch, 5
     dims, enc, dec, enc_s, dec_s, X, M = make_gas(device, B, seed=20220118 + 1000 * rank)
     params = enc.params() + dec.params()
+    # as the trainer sets the networks up: gradients in one permanent buffer per network; under torch.distributed the
+    # decoder's exchange starts under the encoder's backward pass
+    overlap_grad_exchange((enc, dec), force=dist)
     if args.kernels_only:
         print(json.dumps({"roofline": kernel_roofline(dec, dec_s, B * K, device)}), file=out_stream, flush=True)
         return
@@ -252,8 +259,10 @@ def main():
             td.barrier()
 
     def fwd_bwd():
-        bound, _ = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=1, num_importance_samples=K, STL=True)
-        (-bound).backward()
+        # the loss (minus the bound) comes out of the library with the bound, as in the model classes' training_step
+        _, _, loss = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=1, num_importance_samples=K, STL=True,
+                                         with_loss=True)
+        loss.backward()
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -317,8 +326,9 @@ def main():
 
             def step512():
                 opt2.zero_grad(set_to_none=True)
-                b, _ = dmv.estimate_iwelbo(dims2, enc2, dec2, X2, M2, num_latent_samples=1, num_importance_samples=K, STL=True)
-                (-b).backward()
+                _, _, loss = dmv.estimate_iwelbo(dims2, enc2, dec2, X2, M2, num_latent_samples=1, num_importance_samples=K,
+                                                 STL=True, with_loss=True)
+                loss.backward()
                 opt2.clip_on_next_step(5.0)
                 opt2.step()
 

@@ -43,7 +43,8 @@ class DmvObjFwd(C.Structure):
                 ("coefA", C.c_float * 5), ("coefB", C.c_float * 5),
                 ("terms", C.c_void_p), ("comp_lp", C.c_void_p), ("log_w", C.c_void_p),
                 ("bound", C.c_void_p), ("mean_out", C.c_void_p), ("wgt", C.c_void_p), ("zscale", C.c_void_p), ("dlogit", C.c_void_p),
-                ("objA", C.c_void_p), ("objB", C.c_void_p), ("meanA_out", C.c_void_p), ("meanB_out", C.c_void_p)]
+                ("objA", C.c_void_p), ("objB", C.c_void_p), ("meanA_out", C.c_void_p), ("meanB_out", C.c_void_p),
+                ("neg_mean_out", C.c_void_p)]
 
 
 class DmvAdamGroup(C.Structure):

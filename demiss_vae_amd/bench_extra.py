@@ -9,6 +9,8 @@ from .mlp import make_keep_masks
 from . import imputation as imp
 from . import parallel as P
 from .optim import Adam
+from . import synth
+from .synth import NetShape as NetSpec, batch as make_batch
 
 
 def _sync_time(fn, steps, warmup):
@@ -23,18 +25,14 @@ def _sync_time(fn, steps, warmup):
 
 
 def _packed(device, spec, seed, requires_grad, dropout=0.0):
-    from oracle.recipes import make_params
-    p = make_params(spec, seed)
-    ws = [p[n + ".weight"].to(device).requires_grad_(requires_grad) for n in spec.layer_names()]
-    bs = [p[n + ".bias"].to(device).requires_grad_(requires_grad) for n in spec.layer_names()]
-    return PackedNet(NetDims(spec.in_dim, spec.out_dim, spec.nb, spec.hidden, dropout=dropout), ws, bs)
+    import dataclasses
+    return synth.packed_net(dataclasses.replace(spec, dropout=dropout), seed, device, requires_grad)
 
 
 def missiwae_step(device, name, B, D, Zd, enc_shape, dec_shape, C=5, dropout=0.0):
     """MissSIWAE training step (stratified mixture of C Gaussians as the encoder, one importance sample per
     component, tight bound): configs/uci_hepmass/mis50/miwae_stratified_k5_i1_encm_stl.yaml and the miniboone
     counterpart (dropout 0.5 in both networks).  Fresh dropout masks every step, Adam included."""
-    from oracle.recipes import NetSpec, make_batch
     enc_s, dec_s = NetSpec(*enc_shape), NetSpec(*dec_shape)
     enc, dec = _packed(device, enc_s, 1, True, dropout), _packed(device, dec_s, 2, True, dropout)
     dims = ModelDims(D=D, Zd=Zd, q_dist="stratified_with_eps", C=C, encoder_use_mis_mask=True)
@@ -45,10 +43,10 @@ def missiwae_step(device, name, B, D, Zd, enc_shape, dec_shape, C=5, dropout=0.0
     def step():
         ek = make_keep_masks(enc.dims, B, device)
         dk = make_keep_masks(dec.dims, B * C, device)
-        bound, _ = estimate_multiple_iwelbo(dims, enc, dec, X, M, num_importance_samples_for_each_component=1, STL=True,
-                                            enc_keep=ek, dec_keep=dk)
+        _, _, loss = estimate_multiple_iwelbo(dims, enc, dec, X, M, num_importance_samples_for_each_component=1, STL=True,
+                                              enc_keep=ek, dec_keep=dk, with_loss=True)
         opt.zero_grad(set_to_none=True)
-        (-bound).backward()
+        loss.backward()
         opt.step()
 
     t = _sync_time(step, 20, 5)
@@ -65,7 +63,6 @@ def iwae_step(device, B, I=5, *, name="UCI-gas", D=8, Zd=16, enc_shape=(16, 32, 
               gen_dist="normal_with_eps", mask_concat=True, graph=False):
     """MissIWAE training step, Adam included; by default on UCI-gas shapes
     (configs/uci_gas/compare/mis50/iwae_i5_encm_stl.yaml)."""
-    from oracle.recipes import NetSpec, make_batch
     enc_s, dec_s = NetSpec(*enc_shape), NetSpec(*dec_shape)
     enc, dec = _packed(device, enc_s, 1, True), _packed(device, dec_s, 2, True)
     dims = ModelDims(D=D, Zd=Zd, gen_dist=gen_dist, encoder_use_mis_mask=mask_concat)
@@ -76,9 +73,9 @@ def iwae_step(device, B, I=5, *, name="UCI-gas", D=8, Zd=16, enc_shape=(16, 32, 
     opt = Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True)
 
     def step():
-        bound, _ = estimate_iwelbo(dims, enc, dec, X, M, num_importance_samples=I, STL=True)
+        _, _, loss = estimate_iwelbo(dims, enc, dec, X, M, num_importance_samples=I, STL=True, with_loss=True)
         opt.zero_grad(set_to_none=True)
-        (-bound).backward()
+        loss.backward()
         opt.step()
 
     if graph:       # the whole step recorded once and replayed (library noise stays fresh through its device counter)
@@ -100,7 +97,6 @@ def demiss_toy_step(device, B=4096, K=5):
     """toy_mog2_large DeMissVAE (configs/toy_mog2_large/compare/mis50/mvb2vae_lairdmisr0_k5_stl_mlp.yaml shapes:
     D=5, Zd=2, encoder (5,4,3,200), decoder (2,10,3,200), K=5 imputations, LAIR I=1 r=0 T=1, mvb2 + STL):
     gather from the device buffer -> LAIR update with write-back -> two objectives -> two backward calls -> Adam."""
-    from oracle.recipes import NetSpec, make_batch
     enc_s, dec_s = NetSpec(5, 4, 3, 200), NetSpec(2, 10, 3, 200)
     enc, dec = _packed(device, enc_s, 1, True), _packed(device, dec_s, 2, True)
     dims = ModelDims(D=5, Zd=2, gen_dist="normal", q_dist="normal", encoder_use_mis_mask=False)
@@ -134,7 +130,6 @@ def loglik_eval_rate(device, B=50, K=50000, batches=4, name="gas", D=8, Zd=16, e
     """Refit test step (UCI-gas shapes by default): B=50 test points x K=50 000 importance samples per batch; C > 1:
     a stratified-mixture encoder sampled as a plain mixture.  Under data parallelism every rank takes its own
     batches of test points (no exchange until the final mean)."""
-    from oracle.recipes import NetSpec, make_batch
     enc_s, dec_s = NetSpec(*enc_shape), NetSpec(*dec_shape)
     enc, dec = _packed(device, enc_s, 1, False), _packed(device, dec_s, 2, False)
     dims = ModelDims(D=D, Zd=Zd, encoder_use_mis_mask=True, q_dist="stratified_with_eps" if C > 1 else "normal_with_eps", C=C)

@@ -551,6 +551,57 @@ __global__ void k_obj_bwd_latent(BwdLatArgs a) {
   const float raw = a.enc[b * a.q.sb + gp * a.q.sg + a.q.raw_off + j];
   const float sg = dmv_softplus(raw) + a.q.eps;
   float acc_mu = 0.f, acc_sg = 0.f;
+  if (!has_mix) {
+    // Own-Gaussian q (no mixture term): the operands of eight samples are requested before the first is used, so a
+    // thread waits for memory once per eight samples instead of once per sample (small batches are bound by that
+    // latency chain, not by bandwidth).  Same operations in the same order as the general loop below.
+    // every load below is unconditional (a clamped sample index, and a valid stand-in address where an optional array
+    // is absent) so that the compiler issues all of them before the first wait; the selects come afterwards
+    const float* dZp = a.dZ ? a.dZ : a.Z;
+    const int64_t ld_dzp = a.dZ ? a.ld_dz : a.ldz;
+    const float* wp = a.wgt ? a.wgt : a.Z;
+    const float* wop = a.wgt_qown ? a.wgt_qown : wp;
+    const bool zs_on = a.use_zscale && a.zscale;
+    const float* zsp = zs_on ? a.zscale : a.Z;
+    for (int s0 = 0; s0 < a.S; s0 += 8) {
+      float zv[8], dzv[8], ev[8], wv[8], wov[8], zsv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int sk = min(s0 + k, a.S - 1);
+        const int64_t n = ((int64_t)sk * a.B + b) * a.G + gp;
+        zv[k] = a.Z[n * a.ldz + j];
+        dzv[k] = dZp[n * ld_dzp + j];
+        ev[k] = a.eps[n * a.ldz + j];
+        wv[k] = wp[n];
+        wov[k] = wop[n];
+        zsv[k] = zsp[n];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool ok = s0 + k < a.S;
+        if (!a.dZ) dzv[k] = 0.f;
+        if (!a.wgt) wv[k] = 1.f;
+        if (!a.wgt_qown) wov[k] = wv[k];
+        if (!zs_on) zsv[k] = 1.f;
+        if (!ok) { zv[k] = 0.f; dzv[k] = 0.f; ev[k] = 0.f; wv[k] = 0.f; wov[k] = 0.f; zsv[k] = 1.f; }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float w = gbb * wv[k], wo = gbb * wov[k], z = zv[k];
+        float dz = dzv[k];
+        dz += a.base_prior * w * (-z);
+        if (a.base_qown != 0.f) dz += a.base_qown * wo * (-(z - mu) / (sg * sg));
+        dz *= zsv[k];
+        acc_mu += dz;
+        acc_sg += dz * ev[k];
+        if (a.own_live && a.base_qown != 0.f) {
+          const float df = z - mu;
+          acc_mu += a.base_qown * wo * (df / (sg * sg));
+          acc_sg += a.base_qown * wo * (df * df / (sg * sg * sg) - 1.f / sg);
+        }
+      }
+    }
+  } else
   for (int s = 0; s < a.S; ++s) {
     // (1) reparameterised path: only samples drawn from component gp depend on (mu, sigma)_{gp}
     {
@@ -811,7 +862,7 @@ __global__ void k_grid_marginal(GridArgs a) {
       if (normal) { const float df = x - w[3 * d]; lp = w[3 * d + 2] - df * df * w[3 * d + 1]; }
       else { const float v = a.gen_dist == DMV_GEN_BERN ? x : (x + 1.f) * 0.5f; lp = w[3 * d + 2] + v * w[3 * d]; }
       lf += lp;
-      lo += M[d] ? lp : 0.f;
+      lo += lp * (M[d] ? 1.f : 0.f);
     }
     float nm = fmaxf(mo, lo);
     if (nm > -INFINITY) { so = so * expf(mo - nm) + expf(lo - nm); mo = nm; }

@@ -463,18 +463,41 @@ __global__ void __launch_bounds__(256) k_obj_fwd_rows4(FwdArgs a) {
   bound_phases(a, lw, aux, tid, nthr, b0, nb, Qn, Q, BG, row0);
 }
 
-// means of one or two arrays in one single-workgroup launch
-__global__ void k_mean2(const float* __restrict__ v1, const float* __restrict__ v2, int64_t n, float scale,
-                        float* __restrict__ o1, float* __restrict__ o2) {
-  __shared__ float sh[2][4];
-  float s1 = 0.f, s2 = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { if (v1) s1 += v1[i]; if (v2) s2 += v2[i]; }
-  s1 = gsum<64>(s1); s2 = gsum<64>(s2);
+// means of one or two arrays in one single-workgroup launch (fixed summation order: reproducible bit for bit).
+// 1024 threads, 16-byte loads, four of them in flight per thread: a [B] array of a few hundred KB takes a few us.
+__device__ __forceinline__ float sum_strided(const float* __restrict__ v, int64_t n) {
+  float s = 0.f;
+  if (!v) return s;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  if ((((uintptr_t)v) & 15) == 0) {
+    const f32x4* v4 = (const f32x4*)v;
+    const int64_t n4 = n >> 2;
+    int64_t i = tid;
+    for (; i + 3 * (int64_t)nt < n4; i += 4 * (int64_t)nt) {
+      const f32x4 a = v4[i], b = v4[i + nt], c = v4[i + 2 * nt], d = v4[i + 3 * nt];
+      s += ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3])) + ((c[0] + c[1]) + (c[2] + c[3])) +
+           ((d[0] + d[1]) + (d[2] + d[3]));
+    }
+    for (; i < n4; i += nt) { const f32x4 a = v4[i]; s += (a[0] + a[1]) + (a[2] + a[3]); }
+    for (int64_t k = (n4 << 2) + tid; k < n; k += nt) s += v[k];
+  } else {
+    for (int64_t i = tid; i < n; i += nt) s += v[i];
+  }
+  return s;
+}
+
+__global__ void __launch_bounds__(1024) k_mean2(const float* __restrict__ v1, const float* __restrict__ v2, int64_t n, float scale,
+                                                float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ o1_neg) {
+  __shared__ float sh[2][16];
+  float s1 = gsum<64>(sum_strided(v1, n)), s2 = gsum<64>(sum_strided(v2, n));
   if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (o1) o1[0] = (sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) * scale;
-    if (o2) o2[0] = (sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) * scale;
+    float t1 = 0.f, t2 = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { t1 += sh[0][w]; t2 += sh[1][w]; }
+    if (o1) o1[0] = t1 * scale;
+    if (o1_neg) o1_neg[0] = -(t1 * scale);
+    if (o2) o2[0] = t2 * scale;
   }
 }
 
@@ -517,13 +540,13 @@ extern "C" int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const f
   const int64_t pairs = (int64_t)cfg->B * cfg->G;
   hipStream_t st = (hipStream_t)stream;
   auto means = [&]() -> int {
-    if (f->mean_out || f->meanA_out || f->meanB_out) {
+    if (f->mean_out || f->meanA_out || f->meanB_out || f->neg_mean_out) {
       if (kind == DMV_BOUND_PER_COMPONENT) {
-        hipLaunchKernelGGL(k_mean2, dim3(1), dim3(256), 0, st, (const float*)f->objA, (const float*)f->objB, pairs,
-                           1.f / (float)pairs, f->meanA_out, f->meanB_out);
+        hipLaunchKernelGGL(k_mean2, dim3(1), dim3(1024), 0, st, (const float*)f->objA, (const float*)f->objB, pairs,
+                           1.f / (float)pairs, f->meanA_out, f->meanB_out, (float*)nullptr);
       } else if (kind >= 0) {
-        hipLaunchKernelGGL(k_mean2, dim3(1), dim3(256), 0, st, (const float*)f->bound, (const float*)nullptr, (int64_t)cfg->B,
-                           1.f / (float)cfg->B, f->mean_out, (float*)nullptr);
+        hipLaunchKernelGGL(k_mean2, dim3(1), dim3(1024), 0, st, (const float*)f->bound, (const float*)nullptr, (int64_t)cfg->B,
+                           1.f / (float)cfg->B, f->mean_out, (float*)nullptr, f->neg_mean_out);
       }
       DMV_HIP_CHECK_LAUNCH();
     }

@@ -7,6 +7,7 @@ parameter's version counter or address moved (load_state_dict, manual in-place e
 row-major buffers; `ResidualMLPFunction` exposes one network call to autograd.
 """
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -25,6 +26,18 @@ def _count_optimizer_step(*_args, **_kwargs):
 
 
 register_optimizer_step_post_hook(_count_optimizer_step)
+
+
+_SLAB_OWNERS = {}       # storage address of a gradient slab -> weak reference to its PackedNet
+
+
+def slab_owner(grad: torch.Tensor):
+    """the PackedNet whose gradient slab `grad` is a view of, or None"""
+    ref = _SLAB_OWNERS.get(grad.untyped_storage().data_ptr())
+    net = ref() if ref is not None else None
+    if net is None or net._slab is None or net._slab.untyped_storage().data_ptr() != grad.untyped_storage().data_ptr():
+        return None
+    return net
 
 
 def pad32(n: int) -> int:
@@ -67,6 +80,53 @@ class PackedNet:
         if n == 0:
             raise RuntimeError(f"unsupported network shape for the HIP kernels: {dims}")
         self._n_packed = n
+        self.flat_grads = False
+        self._slab = None
+        self._slab_offsets = None
+        self.on_grads_ready = None      # callable(net): the slab holds this step's complete gradients (see parallel.py)
+        self.pending_exchange = None
+
+    # ---- parameter gradients in one permanent buffer
+    def use_flat_grads(self, on: bool = True):
+        """Backward passes write this network's parameter gradients into one buffer that is allocated once (each
+        tensor's gradient a view at a fixed, 256-byte aligned offset), so a data-parallel exchange reduces the buffer
+        as it stands: no gather copy per step.  The gradients of a step are overwritten by the next backward pass
+        (after zero_grad(set_to_none=True), as the training loops do): clone what must outlive the step."""
+        self.flat_grads = bool(on)
+        return self
+
+    def grad_slab(self) -> torch.Tensor:
+        if self._slab is None or self._slab.device != self.weights[0].device:
+            offs, at = [], 0
+            for t in self.params():
+                offs.append(at)
+                at += 64 * ((t.numel() + 63) // 64)
+            self._slab = torch.zeros(at, dtype=torch.float32, device=self.weights[0].device)
+            self._slab_offsets = offs
+            _SLAB_OWNERS[self._slab.untyped_storage().data_ptr()] = weakref.ref(self)
+        return self._slab
+
+    def grad_views(self):
+        """Fresh views of the slab, one per parameter in params() order - or None while a parameter's .grad still
+        lives in the slab (a second backward pass before zero_grad: autograd must then add to it, not alias it)."""
+        slab = self.grad_slab()
+        home = slab.untyped_storage().data_ptr()
+        ps = self.params()
+        for t in ps:
+            if t.grad is not None and t.grad.untyped_storage().data_ptr() == home:
+                return None
+        return [slab[o:o + t.numel()].view(t.shape) for o, t in zip(self._slab_offsets, ps)]
+
+    def grads_live_in_slab(self) -> bool:
+        """every parameter's .grad is the slab's view of it (autograd kept the tensors the backward pass returned)"""
+        if self._slab is None:
+            return False
+        home = self._slab.untyped_storage().data_ptr()
+        for o, t in zip(self._slab_offsets, self.params()):
+            g = t.grad
+            if g is None or g.untyped_storage().data_ptr() != home or g.storage_offset() != o or not g.is_contiguous():
+                return False
+        return True
 
     def params(self) -> List[torch.Tensor]:
         out = []
@@ -135,8 +195,13 @@ def overlap_pays(rows: int) -> bool:
 
 def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: int, *, need_dx: bool,
                  need_param_grads: bool, drop_keep: Optional[torch.Tensor] = None,
-                 wgrad_stream: Optional[torch.cuda.Stream] = None, keepalive: Optional[list] = None):
+                 wgrad_stream: Optional[torch.cuda.Stream] = None, keepalive: Optional[list] = None,
+                 complete: bool = False):
     """gy [rows, pad32(out_dim)] -> (dx [rows, pad32(in_dim)] or None, [gW0, gb0, gW1, ...] or None).
+
+    complete: these are the network's whole gradients for this step; with use_flat_grads() and a registered
+    on_grads_ready the hook is called on the stream that carries the weight-gradient kernels (a data-parallel exchange
+    of this network's gradients can start while the caller carries on upstream).
 
     wgrad_stream: run the weight-gradient GEMMs there, after the input-gradient chain on the current stream; the
     caller makes the current stream wait for it before the gradients are used and keeps `keepalive` (filled with the
@@ -147,9 +212,14 @@ def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: in
     dx = torch.empty((rows, pad32(d.in_dim)), dtype=torch.float32, device=dev) if need_dx else None
     gws = gbs = None
     gw_arr = gb_arr = None
+    in_slab = False
     if need_param_grads:
-        gws = [torch.empty_like(w) for w in net.weights]
-        gbs = [torch.empty_like(b) for b in net.biases]
+        views = net.grad_views() if net.flat_grads else None
+        if views is not None:
+            gws, gbs, in_slab = views[0::2], views[1::2], True
+        else:
+            gws = [torch.empty_like(w) for w in net.weights]
+            gbs = [torch.empty_like(b) for b in net.biases]
         gw_arr, gb_arr = L.ptr_array(gws), L.ptr_array(gbs)
     nbytes = L.lib().dmv_mlp_backward_ws_bytes(C.byref(net.c), rows)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
@@ -162,6 +232,10 @@ def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: in
         L.check(lib.dmv_mlp_backward_wgrad(C.byref(net.c), L.ptr(saved), L.ptr(gy), gy.shape[1], rows, gw_arr, gb_arr, 0.0,
                                            L.ptr(ws), nbytes, C.c_void_p(wgrad_stream.cuda_stream)))
         keepalive += [ws, gy, saved]
+        if complete and in_slab and net.on_grads_ready is not None:
+            with torch.cuda.stream(wgrad_stream):
+                net.on_grads_ready(net)
+            complete = False
     elif rows:
         L.check(L.lib().dmv_mlp_backward(C.byref(net.c), L.ptr(net.packed()), L.ptr(saved), L.ptr(drop_keep),
                                          L.ptr(gy), gy.shape[1], rows, L.ptr(dx), dx.shape[1] if need_dx else 0,
@@ -174,6 +248,8 @@ def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: in
         grads = []
         for w, b in zip(gws, gbs):
             grads += [w, b]
+        if complete and in_slab and net.on_grads_ready is not None:
+            net.on_grads_ready(net)
     return dx, grads
 
 

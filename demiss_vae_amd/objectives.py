@@ -154,7 +154,7 @@ def _objective_forward(c, plan: _Plan, training: bool, *, kind, use_logpi=False,
                        want_means=False):
     """One launch of dmv_obj_forward over the pipeline's decoder outputs: per-sample terms, bound / objectives and the
     buffers the backward reads (softmax weights, DREG scales, mixture-logit gradient, component log-densities).
-    Returns (bound [B], mean) for the bound kinds, (objA, objB, meanA, meanB) for the per-component kind, terms for -1."""
+    Returns (bound [B], mean, -mean) for the bound kinds, (objA, objB, meanA, meanB) for the per-component kind, terms for -1."""
     lib, st = L.lib(), L.stream_ptr()
     dev = c.dec_out.device
     B, G, N = c.B, c.G, c.N
@@ -171,8 +171,8 @@ def _objective_forward(c, plan: _Plan, training: bool, *, kind, use_logpi=False,
         f.comp_lp = L.addr(c.comp_lp)
     out = None
     if kind in (L.BOUND_LSE, L.BOUND_WEIGHTED):
-        per_b, mean = new(B), new()
-        f.bound, f.mean_out = L.addr(per_b), L.addr(mean)
+        per_b, mean, neg = new(B), new(), new()
+        f.bound, f.mean_out, f.neg_mean_out = L.addr(per_b), L.addr(mean), L.addr(neg)
         if training:
             c.wgt = new(N)
             f.wgt = L.addr(c.wgt)
@@ -182,7 +182,7 @@ def _objective_forward(c, plan: _Plan, training: bool, *, kind, use_logpi=False,
             if c.q_kind == L.Q_STRATIFIED and not c.reparam:
                 c.dlogit = new(B, G)
                 f.dlogit = L.addr(c.dlogit)
-        out = (per_b, mean)
+        out = (per_b, mean, neg)
     elif kind == L.BOUND_PER_COMPONENT:
         objA = new(B, G)
         objB = new(B, G) if coefB is not None else None
@@ -249,7 +249,8 @@ def _kl(c):
     return kl
 
 
-def _dec_side(c, dec: PackedNet, wgt, base_m, base_f, need_dx, need_param_grads, overlap=None, gb=None, gscale=None):
+def _dec_side(c, dec: PackedNet, wgt, base_m, base_f, need_dx, need_param_grads, overlap=None, gb=None, gscale=None,
+              complete=False):
     """Decoder-side gradient and the decoder's backward pass.  Row weights = gscale * gb[b] * wgt[n] (each optional).
     overlap: a list; when given (and the batch is small) the decoder's weight-gradient GEMMs go to the side stream
     while the caller carries on upstream, and the list receives what must stay alive until the caller has joined"""
@@ -261,7 +262,7 @@ def _dec_side(c, dec: PackedNet, wgt, base_m, base_f, need_dx, need_param_grads,
     if side is not None:
         overlap.append(side)
     return mlp_backward(dec, c.dec_saved, d_dec, c.N, need_dx=need_dx, need_param_grads=need_param_grads,
-                        drop_keep=c.dec_keep, wgrad_stream=side, keepalive=overlap)
+                        drop_keep=c.dec_keep, wgrad_stream=side, keepalive=overlap, complete=complete)
 
 
 def _join(overlap):
@@ -312,8 +313,8 @@ def _latent_params(**kw):
 
 
 class _FusedObjective(torch.autograd.Function):
-    """outputs: bound kinds (iwae, miwae, elbo_analytic): (batch mean, per-datapoint bound [B]); DeMissVAE kinds: the
-    objective(s) [B, K], or their means over (b, k) with plan.reduce_mean."""
+    """outputs: bound kinds (iwae, miwae, elbo_analytic): (batch mean, per-datapoint bound [B], minus the batch mean =
+    the training loss); DeMissVAE kinds: the objective(s) [B, K], or their means over (b, k) with plan.reduce_mean."""
 
     @staticmethod
     def forward(ctx, dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx, *params):
@@ -329,13 +330,14 @@ class _FusedObjective(torch.autograd.Function):
         pc = L.BOUND_PER_COMPONENT
         if k in ("iwae", "miwae"):
             mixture = c.q_kind == L.Q_STRATIFIED and not c.reparam
-            per_b, mean = _objective_forward(c, plan, training, kind=L.BOUND_WEIGHTED if plan.looser else L.BOUND_LSE,
-                                             use_logpi=mixture and not plan.looser)
-            return mean, per_b
+            per_b, mean, neg = _objective_forward(c, plan, training, kind=L.BOUND_WEIGHTED if plan.looser else L.BOUND_LSE,
+                                                  use_logpi=mixture and not plan.looser)
+            return mean, per_b, neg
         if k == "elbo_analytic":
             gen = _objective_forward(c, plan, training, kind=pc, coefA=(1, 0, 0, 0, 0))[0]
             per_b = gen.reshape(c.B) - _kl(c).reshape(c.B)
-            return per_b.mean(), per_b
+            mean = per_b.mean()
+            return mean, per_b, -mean
         if k == "cvi":
             return (_objective_forward(c, plan, training, kind=pc, coefA=(1, 0, 1, 0, -1))[0],)
         if k == "mvb":
@@ -369,20 +371,29 @@ class _FusedObjective(torch.autograd.Function):
             g = g_bg.reshape(1, B, -1).float()
             return (g / nz).expand(S, B, G).contiguous().reshape(-1)
 
-        def upstream(g_mean, g_per_b):
+        def upstream(g_mean, g_per_b, g_neg):
             """Upstream gradient of the per-datapoint bounds as the kernels take it: (gb [B] or None, gscale 0-d or
-            None, factor).  The usual loss is the batch mean: a device scalar and the host factor 1/B, no tensor math."""
-            if g_per_b is None:
+            None, factor).  The usual loss is (minus) the batch mean: a device scalar and the host factor +-1/B, no
+            tensor math."""
+            if g_per_b is None and g_mean is None:
+                return None, g_neg.float(), -1.0 / B
+            if g_per_b is None and g_neg is None:
                 return None, g_mean.float(), 1.0 / B
+            g_tot = None if g_mean is None else g_mean.float()
+            if g_neg is not None:
+                g_tot = -g_neg.float() if g_tot is None else g_tot - g_neg.float()
+            if g_per_b is None:
+                return None, g_tot, 1.0 / B
             gb = g_per_b.float().reshape(B)
-            if g_mean is not None:
-                gb = gb + g_mean.float() / B
+            if g_tot is not None:
+                gb = gb + g_tot / B
             return gb.contiguous(), None, 1.0
 
-        if k in ("iwae", "miwae") and (gouts[0] is not None or gouts[1] is not None):
+        if k in ("iwae", "miwae") and any(g is not None for g in gouts):
             gb, gs, f = upstream(*gouts)
             pending = []
-            dZ, g_dec_params = _dec_side(c, dec, c.wgt, f, 0.0, True, True, overlap=pending, gb=gb, gscale=gs)
+            # (the decoder's gradients are whole here: one backward pass per step for these objectives)
+            dZ, g_dec_params = _dec_side(c, dec, c.wgt, f, 0.0, True, True, overlap=pending, gb=gb, gscale=gs, complete=True)
             if c.reparam:
                 wt = c.wgt * (gs * f) if gb is None else (c.wgt.reshape(S, B) * gb.reshape(1, B)).reshape(-1)
                 d_enc = _implicit_d_enc(c, dZ, wt.contiguous(), 1.0, -1.0)
@@ -396,10 +407,11 @@ class _FusedObjective(torch.autograd.Function):
                 p = _latent_params(prior=f, qown=-f, w=f, own_live=not (plan.STL or plan.DREG), use_zscale=plan.DREG)
             g_enc_params = _enc_side(c, enc, p, dZ, c.wgt, c.zscale, c.dlogit, None, gb=gb, gscale=gs)
             _join(pending)
-        elif k == "elbo_analytic" and (gouts[0] is not None or gouts[1] is not None):
+        elif k == "elbo_analytic" and any(g is not None for g in gouts):
             gb, gs, f = upstream(*gouts)
             pending = []
-            dZ, g_dec_params = _dec_side(c, dec, None, f / nz, 0.0, True, True, overlap=pending, gb=gb, gscale=gs)
+            dZ, g_dec_params = _dec_side(c, dec, None, f / nz, 0.0, True, True, overlap=pending, gb=gb, gscale=gs,
+                                         complete=True)
             p = _latent_params(kl=-f)
             g_enc_params = _enc_side(c, enc, p, dZ, None, None, None, gb.reshape(B, 1) if gb is not None else None, gscale=gs)
             _join(pending)
@@ -528,18 +540,26 @@ def _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx=None):
 
 
 # ------------------------------------------------------------------------------------------ public API
+def _pick(outs, with_loss):
+    """(mean bound, per-datapoint bounds) as the reference's estimators return them; with_loss adds minus the mean, the
+    loss the training steps minimise, formed by the kernel that forms the mean (differentiable like the mean)."""
+    mean, per_b, neg = outs
+    return (mean, per_b, neg) if with_loss else (mean, per_b)
+
+
 def estimate_iwelbo(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_latent_samples=1,
-                    num_importance_samples=1, STL=False, DREG=False, eps=None, enc_keep=None, dec_keep=None, comp_idx=None):
+                    num_importance_samples=1, STL=False, DREG=False, eps=None, enc_keep=None, dec_keep=None, comp_idx=None,
+                    with_loss=False):
     """IWAE bound averaged over the batch, and the per-datapoint bounds.  eps [nz, I, B, Zd]; for a reparametrised
     mixture encoder eps [nz, I, B, C, Zd] and comp_idx [nz, I, B] (drawn on the device when omitted)."""
     assert not (STL and DREG), "Cannot use STL and DREG gradients at the same time."
     assert not dims.q_is_mixture
     plan = _Plan("iwae", num_latent_samples, num_importance_samples, STL=STL, DREG=DREG)
-    return _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx)
+    return _pick(_run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx), with_loss)
 
 
 def estimate_elbo(dims, enc, dec, X, M, *, num_latent_samples=1, kl_analytic=True, STL=False, eps=None,
-                  enc_keep=None, dec_keep=None, comp_idx=None):
+                  enc_keep=None, dec_keep=None, comp_idx=None, with_loss=False):
     """VAE ELBO with analytic or Monte-Carlo KL.  eps [nz, B, Zd] (reparametrised mixture: [nz, B, C, Zd] and
     comp_idx [nz, B])."""
     assert not (STL and kl_analytic), '"Sticking the Landing" cannot be used with analytical KL.'
@@ -548,23 +568,23 @@ def estimate_elbo(dims, enc, dec, X, M, *, num_latent_samples=1, kl_analytic=Tru
         plan = _Plan("elbo_analytic", num_latent_samples, 1)
     else:
         plan = _Plan("iwae", num_latent_samples, 1, STL=STL)   # logsumexp over a single sample = identity
-    return _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx)
+    return _pick(_run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, comp_idx), with_loss)
 
 
 def estimate_multiple_iwelbo(dims, enc, dec, X, M, *, num_latent_samples=1, num_importance_samples_for_each_component=1,
-                             STL=False, looser=False, eps=None, enc_keep=None, dec_keep=None):
+                             STL=False, looser=False, eps=None, enc_keep=None, dec_keep=None, with_loss=False):
     """MissSIWAE bound (stratified mixture encoder).  eps [nz, I, B, C, Zd]."""
     assert dims.q_is_mixture
     plan = _Plan("miwae", num_latent_samples, num_importance_samples_for_each_component, STL=STL, looser=looser)
-    return _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep)
+    return _pick(_run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep), with_loss)
 
 
 def estimate_multiple_elbo(dims, enc, dec, X, M, *, num_latent_samples=1, STL=False, eps=None, enc_keep=None,
-                           dec_keep=None):
+                           dec_keep=None, with_loss=False):
     """MissSVAE stratified ELBO = sum_c pi_c * ratio_c.  eps [nz, B, C, Zd]."""
     assert dims.q_is_mixture
     plan = _Plan("miwae", num_latent_samples, 1, STL=STL, looser=True)
-    return _run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep)
+    return _pick(_run(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep), with_loss)
 
 
 def mvb2_objectives(dims, enc, dec, Xt, M, *, num_latent_samples=1, STL=False, kl_analytic=False, eps=None,

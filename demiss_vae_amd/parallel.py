@@ -2,9 +2,11 @@
 the GPU box, "gloo" in the CPU tests).
 
 Training is pure data parallelism: datapoints are independent and every loss is a mean over the batch,
-so each rank runs the fused step on its own shard and the only exchange is ONE flat all-reduce of all
-parameter gradients per step (UCI models: 2-4 MB, latency-bound, so a single message beats per-tensor
-buckets), done before gradient clipping so the clip norm is that of the averaged gradient.
+so each rank runs the fused step on its own shard and the only exchange is one all-reduce per network of
+its parameter gradients (UCI models: 1-2 MB each, latency-bound, so whole-network messages beat per-tensor
+buckets), done before gradient clipping so the clip norm is that of the averaged gradient.  The gradients
+live permanently in one buffer per network (no gather copy), and the decoder's exchange starts as soon as
+the decoder's backward pass has written them, under the encoder's backward pass.
 
 The K-sample log-likelihood shards either test points (no exchange until the final sum) or importance
 samples of the same points; the latter combines per-rank (max, sum-exp) pairs with a max all-reduce
@@ -39,24 +41,85 @@ def all_reduce(t: torch.Tensor, op=None, group=None):
     return t
 
 
-def allreduce_grads(params: Sequence[torch.Tensor], group=None, force=False):
-    """Average .grad over ranks with one flat all-reduce (equal shard sizes assumed).  force: run the collective even
-    in a world of one rank (rehearsals of the RCCL path on a single GPU)."""
-    if world() == 1 and not (force and dist.is_available() and dist.is_initialized()):
-        return
-    with_grad = [p for p in params if p.grad is not None]
-    if not with_grad:
-        return
-    grads = [p.grad for p in with_grad]
-    flat = _flatten_dense_tensors(grads)
+def _average(flat: torch.Tensor, group=None):
     if dist.get_backend(group) == "nccl":
         all_reduce(flat, dist.ReduceOp.AVG, group)          # RCCL averages inside the reduction
     else:
         all_reduce(flat, dist.ReduceOp.SUM, group)
         flat.div_(dist.get_world_size(group))
+
+
+def overlap_grad_exchange(nets, group=None, force=False):
+    """Start the exchange of a network's gradients the moment its backward pass has written them, while the rest of
+    the backward pass (the encoder's, after the decoder's) is still running: `nets` get use_flat_grads() and a hook
+    that launches an asynchronous all-reduce of their gradient slab; allreduce_grads() at the end of the step waits
+    for it instead of reducing again.  One backward pass per network and step (the hook fires only where an objective
+    marks the gradients complete); steps recorded into a HIP graph and gloo exchanges of device tensors (staged through
+    the host) fall back to the blocking exchange."""
+    for net in nets:
+        net.use_flat_grads(True)
+        net.on_grads_ready = None
+    if not (dist.is_available() and dist.is_initialized()) or (world() == 1 and not force):
+        return
+
+    def launch(net):
+        slab = net.grad_slab()
+        if torch.cuda.is_available() and slab.is_cuda and torch.cuda.is_current_stream_capturing():
+            return
+        nccl = dist.get_backend(group) == "nccl"
+        if slab.is_cuda and not nccl:
+            return
+        if net.pending_exchange is not None:
+            raise RuntimeError("a second backward pass before the gradients of the first were exchanged: "
+                               "overlap_grad_exchange needs one backward pass per step")
+        work = dist.all_reduce(slab, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, group=group, async_op=True)
+        net.pending_exchange = (work, nccl)
+
+    for net in nets:
+        net.on_grads_ready = launch
+
+
+def allreduce_grads(params: Sequence[torch.Tensor], group=None, force=False):
+    """Average .grad over ranks (equal shard sizes assumed).  Gradients that live in their network's permanent slab
+    (PackedNet.use_flat_grads) are reduced where they are, one collective per network, or were already sent off by
+    overlap_grad_exchange and are only waited for; any others go through one flat gather + all-reduce.  force: run the
+    collectives even in a world of one rank (rehearsals of the RCCL path on a single GPU)."""
+    if world() == 1 and not (force and dist.is_available() and dist.is_initialized()):
+        return
+    from .mlp import slab_owner
+    with_grad = [p for p in params if p.grad is not None]
+    if not with_grad:
+        return
+    asked = {id(p) for p in with_grad}
+    nets, loose = {}, []
+    for p in with_grad:
+        net = slab_owner(p.grad)
+        if net is None:
+            loose.append(p)
+        else:
+            nets.setdefault(id(net), (net, []))[1].append(p)
+    for net, ps in nets.values():
+        whole = net.grads_live_in_slab() and all(id(t) in asked for t in net.params())
+        pending, net.pending_exchange = net.pending_exchange, None
+        if pending is not None:
+            work, averaged = pending
+            work.wait()
+            if not whole:
+                raise RuntimeError("gradients left their slab after the overlapped exchange had started")
+            if not averaged:
+                net.grad_slab().div_(dist.get_world_size(group))
+        elif whole:
+            _average(net.grad_slab(), group)
+        else:
+            loose += ps
+    if not loose:
+        return
+    grads = [p.grad for p in loose]
+    flat = _flatten_dense_tensors(grads)
+    _average(flat, group)
     # the averaged gradients stay where they are: every .grad becomes a view of the flat buffer (one gather kernel and
     # the collective per step, no copies back)
-    for p, g in zip(with_grad, _unflatten_dense_tensors(flat, grads)):
+    for p, g in zip(loose, _unflatten_dense_tensors(flat, grads)):
         p.grad = g
 
 

@@ -260,7 +260,24 @@ class _StepRunner:
         if m.automatic_optimization or self.use_graph:
             self._after()
 
+    def _flat_gradients(self):
+        """the fused networks keep their parameter gradients in one permanent buffer each (what the gradient exchange
+        reduces in place); with automatic optimisation (one backward pass a step) the decoder's exchange starts under
+        the encoder's backward pass"""
+        self.flat_ready = True
+        m = self.model
+        inner = getattr(m, "model", m)
+        if not getattr(inner, "fused", False) or not hasattr(m, "engine"):
+            return
+        nets = tuple(m.engine()[1:])
+        for net in nets:
+            net.use_flat_grads(True)
+        if P.world() > 1 and m.automatic_optimization:
+            P.overlap_grad_exchange(nets)
+
     def __call__(self, batch):
+        if not getattr(self, "flat_ready", False):
+            self._flat_gradients()
         if not self.use_graph:
             return self._eager(batch)
         from .graph import GraphedStep

@@ -167,7 +167,8 @@ int dmv_obj_terms(const DmvObjCfg* cfg, int32_t q_kind, int32_t mix_C, const flo
  * the logsumexp over the importance / component axes done in LDS (vgiwae/shared/iwae.py:9-132, models/iwae.py:70-123,
  * models/multiple_iwae.py:124-199, models/multiple_vae.py:109-160, models/mvbvae.py:83-137).  Inputs as dmv_obj_terms;
  * every output pointer is optional except the one the chosen kind defines:
- *   kind DMV_BOUND_LSE / _WEIGHTED: bound [B] (+ mean_out scalar), log_w [N], wgt [N], zscale [N], dlogit [B][G]
+ *   kind DMV_BOUND_LSE / _WEIGHTED: bound [B] (+ mean_out scalar and neg_mean_out = -mean, the training loss of
+ *        models/iwae.py:45), log_w [N], wgt [N], zscale [N], dlogit [B][G]
  *        (written in full, zeros where the bound has no pi factor), with the meaning they have in dmv_obj_bound;
  *   kind DMV_BOUND_PER_COMPONENT (I == 1): objA / objB [B][G] = mean_z sum_t coefA/B[t] * terms[t] (+ meanA/B_out scalars);
  *   kind -1: terms only.
@@ -181,6 +182,7 @@ typedef struct DmvObjFwd {
   float *terms, *comp_lp, *log_w;
   float *bound, *mean_out, *wgt, *zscale, *dlogit;
   float *objA, *objB, *meanA_out, *meanB_out;
+  float *neg_mean_out;
 } DmvObjFwd;
 int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const float* dec, int64_t ld_dec, const float* X,
                     const uint8_t* M, const float* Z, int64_t ldz, const float* enc, void* stream);

@@ -54,6 +54,21 @@ def model_case(g):
     return spec, stored_params(g, "enc", enc, seed), stored_params(g, "dec", dec, seed + 1)
 
 
+def mlp_io(g, spec):
+    """(x, upstream gradient, rows) of an MLP case: stored, or rebuilt from the seed - for long batches the drawn rows
+    less those the generator left out (rows within a margin of a relu kink; `row_ok` holds the kept ones bit-packed)"""
+    seed, rows = int(g["seed"]), int(g["rows"])
+    if "x" in g:
+        return torch.from_numpy(g["x"]), torch.from_numpy(g["gy"]), rows
+    drawn = int(g["rows_drawn"]) if "rows_drawn" in g else rows
+    x, gy = make_noise(seed + 1, drawn, spec.in_dim), make_noise(seed + 2, drawn, spec.out_dim)
+    if "row_ok" in g:
+        ok = torch.from_numpy(np.unpackbits(g["row_ok"])[:drawn].astype(bool))
+        x, gy = x[ok].contiguous(), gy[ok].contiguous()
+    assert x.shape[0] == rows
+    return x, gy, rows
+
+
 def batch_of(g, binary=None):
     seed = int(g["seed"])
     if "X" in g:
@@ -93,6 +108,24 @@ def imputed_batch(g, binary=None):
     Mk = M[:, None, :].expand(B, K, D).contiguous()
     Xt = torch.where(Mk, X[:, None, :].expand(B, K, D), fill.reshape(B, K, D)).contiguous()
     return Xt, Mk
+
+
+def check_tensor(g, key, t, rtol, atol):
+    """Compare a 2-d tensor with what the fixture holds under `key`: the full array, or (long batches) its digest of
+    row sums, column sums and a strided sub-sample.  Sums are compared to the tolerance of their terms times the
+    number of terms' typical growth (sqrt of the count)."""
+    t = t.detach().cpu().to(torch.float64)
+    if key in g:
+        torch.testing.assert_close(t, torch.from_numpy(g[key]).double(), rtol=rtol, atol=atol)
+        return "full"
+    torch.testing.assert_close(t[::7, ::5], torch.from_numpy(g[f"{key}.sub"]).double(), rtol=rtol, atol=atol)
+    scale = float(t.abs().mean())
+    for name, dim in (("rowsum", 1), ("colsum", 0)):
+        ref = torch.from_numpy(g[f"{key}.{name}"]).double()
+        grow = float(t.shape[dim]) ** 0.5
+        torch.testing.assert_close(t.sum(dim), ref, rtol=rtol, atol=(atol + rtol * scale) * grow,
+                                   msg=lambda m: f"{key}.{name}: {m}")
+    return "digest"
 
 
 def check_grads(g, prefix, grads, rtol, atol, floor=2e-5):

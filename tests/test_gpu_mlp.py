@@ -15,16 +15,18 @@ def test_mlp_golden(name):
     import gpu_util as G
     g = gu.load(name)
     spec = gu.net_spec(g["spec"], g["dropout"])
-    seed, rows = int(g["seed"]), int(g["rows"])
+    seed = int(g["seed"])
     params = gu.stored_params(g, "p", spec, seed)
     net = G.packed_net(spec, params)
-    x = (torch.from_numpy(g["x"]) if "x" in g else make_noise(seed + 1, rows, spec.in_dim)).cuda().requires_grad_(True)
-    gy = (torch.from_numpy(g["gy"]) if "gy" in g else make_noise(seed + 2, rows, spec.out_dim)).cuda()
+    x, gy, rows = gu.mlp_io(g, spec)
+    x, gy = x.cuda().requires_grad_(True), gy.cuda()
     keep = G.keep_to_dev(gu.dropout_masks(seed + 3, spec, (rows,)))
     y = dmv.ResidualMLPFunction.apply(net, True, keep, x, *net.params())
     y.backward(gy)
-    torch.testing.assert_close(y.detach().cpu(), torch.from_numpy(g["y"]), rtol=1e-5, atol=2e-6)
-    torch.testing.assert_close(x.grad.cpu(), torch.from_numpy(g["dx"]), rtol=1e-4, atol=2e-6)
+    # long batches (rows above every small-batch kernel family: the one-wave kernels the headline benchmark times)
+    # hold digests of the reference's outputs instead of the full arrays, and leave out rows at a relu kink
+    gu.check_tensor(g, "y", y, 1e-5, 2e-6)
+    gu.check_tensor(g, "dx", x.grad, 1e-4, 2e-6)
     assert gu.check_grads(g, "g", G.grads_of(net, spec), 1e-4, 2e-6) == 2 * (2 * spec.nb + 2)
 
 

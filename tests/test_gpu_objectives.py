@@ -66,10 +66,14 @@ def test_multiple(name):
     X, M = gu.batch_of(g)
     B, I, nz, C = int(g["B"]), int(g["I"]), int(g["nz"]), int(g["C"])
     if name.startswith("miwae"):
+        import gpu_util as G
+        seed = int(g["seed"])
         eps = gu.eps_of(g, nz, I, B, C, spec.Zd)
+        ek = G.keep_to_dev(gu.dropout_masks(seed + 4, spec.enc, (B,)) or None)      # miniboone: dropout 0.5 in both networks
+        dk = G.keep_to_dev(gu.dropout_masks(seed + 5, spec.dec, (nz, I, B, C)) or None)
         bound, _ = dmv.estimate_multiple_iwelbo(dims, enc, dec, X.cuda(), M.cuda(), num_latent_samples=nz,
                                                 num_importance_samples_for_each_component=I, STL=bool(g["STL"]),
-                                                looser=bool(g["looser"]), eps=eps.cuda())
+                                                looser=bool(g["looser"]), eps=eps.cuda(), enc_keep=ek, dec_keep=dk)
     else:
         eps = gu.eps_of(g, nz, B, C, spec.Zd)
         bound, _ = dmv.estimate_multiple_elbo(dims, enc, dec, X.cuda(), M.cuda(), num_latent_samples=nz,
@@ -224,3 +228,47 @@ def test_no_grad_evaluation_saves_nothing_and_accepts_dropout_networks():
     plain_dec = G.packed_net(NetSpec(16, 16, 1, 64), make_params(dec_s, 2))
     b1, _ = dmv.estimate_iwelbo(dims, plain_enc, plain_dec, X, M, num_importance_samples=5, eps=eps)
     torch.testing.assert_close(b0, b1.detach())   # inference with dropout networks = the same networks without dropout
+
+
+def test_gradients_in_permanent_slabs_equal_fresh_ones():
+    """PackedNet.use_flat_grads: the backward pass writes the parameter gradients into one permanent buffer per network
+    and autograd keeps those views as .grad (what the data-parallel exchange reduces in place).  Same values as with
+    fresh tensors; a second backward pass without zero_grad adds to them instead of aliasing the buffer."""
+    import demiss_vae_amd as dmv
+    g = gu.load("iwae_stl_normal_with_eps_mc")
+    spec, enc_p, dec_p = gu.model_case(g)
+    X, M = gu.batch_of(g)
+    B, I, nz = int(g["B"]), int(g["I"]), int(g["nz"])
+    eps = gu.eps_of(g, nz, I, B, spec.Zd).cuda()
+
+    def run(flat, passes=1):
+        dims, enc, dec = _nets(spec, enc_p, dec_p)
+        ready = []
+        if flat:
+            enc.use_flat_grads()
+            dec.use_flat_grads()
+            dec.on_grads_ready = lambda net: ready.append(net)
+        for _ in range(passes):
+            bound, _ = dmv.estimate_iwelbo(dims, enc, dec, X.cuda(), M.cuda(), num_latent_samples=nz, num_importance_samples=I,
+                                           STL=True, eps=eps)
+            (-bound).backward()
+        return enc, dec, ready
+
+    e0, d0, _ = run(False)
+    e1, d1, ready = run(True)
+    assert e1.grads_live_in_slab() and d1.grads_live_in_slab() and ready == [d1]
+    for a, b in zip(e0.params() + d0.params(), e1.params() + d1.params()):
+        assert torch.equal(a.grad, b.grad)
+    _check(g, spec, e1, d1)
+    # the next step (after zero_grad) lands in the same memory
+    where = [p.grad.data_ptr() for p in d1.params()]
+    for p in e1.params() + d1.params():
+        p.grad = None
+    bound, _ = dmv.estimate_iwelbo(_nets(spec, enc_p, dec_p)[0], e1, d1, X.cuda(), M.cuda(), num_latent_samples=nz,
+                                   num_importance_samples=I, STL=True, eps=eps)
+    (-bound).backward()
+    assert [p.grad.data_ptr() for p in d1.params()] == where and d1.grads_live_in_slab()
+    # accumulation over two passes: twice the gradient
+    e2, d2, _ = run(True, passes=2)
+    for a, b in zip(e0.params() + d0.params(), e2.params() + d2.params()):
+        torch.testing.assert_close(b.grad, 2 * a.grad, rtol=1e-6, atol=1e-7)

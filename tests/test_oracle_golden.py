@@ -27,15 +27,15 @@ def _grads(p):
 def test_mlp(name):
     g = gu.load(name)
     spec = gu.net_spec(g["spec"], g["dropout"])
-    seed, rows = int(g["seed"]), int(g["rows"])
+    seed = int(g["seed"])
     params = _as_params(gu.stored_params(g, "p", spec, seed))
-    x = (torch.from_numpy(g["x"]) if "x" in g else make_noise(seed + 1, rows, spec.in_dim)).requires_grad_(True)
-    gy = torch.from_numpy(g["gy"]) if "gy" in g else make_noise(seed + 2, rows, spec.out_dim)
+    x, gy, rows = gu.mlp_io(g, spec)
+    x.requires_grad_(True)
     masks = gu.dropout_masks(seed + 3, spec, (rows,))
     y = core.mlp_forward(params, x, spec, masks)
     y.backward(gy)
-    torch.testing.assert_close(y.detach(), torch.from_numpy(g["y"]), rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(x.grad, torch.from_numpy(g["dx"]), rtol=RT_G, atol=AT_G)
+    gu.check_tensor(g, "y", y, 1e-5, 1e-6)
+    gu.check_tensor(g, "dx", x.grad, RT_G, AT_G)
     assert gu.check_grads(g, "g", _grads(params), RT_G, AT_G) == 2 * (2 * spec.nb + 2)
 
 
@@ -82,9 +82,13 @@ def test_multiple(name):
     enc_p, dec_p = _as_params(enc_p), _as_params(dec_p)
     X, M = gu.batch_of(g)
     B, I, nz, C = int(g["B"]), int(g["I"]), int(g["nz"]), int(g["C"])
+    seed = int(g["seed"])
     if name.startswith("miwae"):
         eps = gu.eps_of(g, nz, I, B, C, spec.Zd)
-        bound, _ = core.estimate_multiple_iwelbo(spec, enc_p, dec_p, X, M, eps, STL=bool(g["STL"]), looser=bool(g["looser"]))
+        em = gu.dropout_masks(seed + 4, spec.enc, (B,)) or None
+        dm = gu.dropout_masks(seed + 5, spec.dec, (nz, I, B, C)) or None
+        bound, _ = core.estimate_multiple_iwelbo(spec, enc_p, dec_p, X, M, eps, STL=bool(g["STL"]), looser=bool(g["looser"]),
+                                                 enc_masks=em, dec_masks=dm)
     else:
         eps = gu.eps_of(g, nz, B, C, spec.Zd)
         bound, _ = core.estimate_multiple_elbo(spec, enc_p, dec_p, X, M, eps, STL=bool(g["STL"]))
@@ -226,7 +230,9 @@ def test_loglik(name):
     seed = int(g["seed"])
     if str(g["kind"]) == "standard":
         eps = gu.eps_of(g, 1, K, B, spec.Zd)
-        val, _ = core.loglik_eval(spec, enc_p, dec_p, X, M, eps)
+        val, per_point = core.loglik_eval(spec, enc_p, dec_p, X, M, eps)
+        if "per_point" in g:
+            torch.testing.assert_close(per_point.double(), torch.from_numpy(g["per_point"]).double(), rtol=1e-4, atol=1e-4)
     else:
         comp = torch.from_numpy(g["comp_idx"])
         if g["eps"].size:

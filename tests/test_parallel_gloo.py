@@ -82,9 +82,37 @@ def _worker(rank, world, port, out):
             self._logged = {"est_loglik/test": per_b.mean(), "points": float(Xb.shape[0])}
 
     runs = {mode: run.test(_Model(), _Data(), log=lambda *_: None, shard=mode) for mode in ("points", "samples")}
+
+    # gradients that live in their network's permanent slab: the overlapped exchange (launched by the hook the backward
+    # pass calls, here by hand), the blocking one of a second network, and loose gradients beside them in one call
+    import demiss_vae_amd as dmv
+    slab_report = {}
+    nets = []
+    for tag, seed in (("overlapped", 6), ("blocking", 7)):
+        ns = NetSpec(6, 5, 1, 32)
+        pr = make_params(ns, seed)
+        ws = [pr[n + ".weight"].clone().requires_grad_(True) for n in ns.layer_names()]
+        bs = [pr[n + ".bias"].clone().requires_grad_(True) for n in ns.layer_names()]
+        nets.append(dmv.PackedNet(dmv.NetDims(6, 5, 1, 32), ws, bs))
+    P.overlap_grad_exchange(nets[:1])
+    nets[1].use_flat_grads(True)
+    for net in nets:
+        for i, (t, v) in enumerate(zip(net.params(), net.grad_views())):
+            v.copy_(torch.full_like(t, float(i + 1)) * (rank + 1) + t.detach())
+            t.grad = v
+        assert net.grads_live_in_slab() and net.grad_views() is None      # a second pass would not alias the slab
+    nets[0].on_grads_ready(nets[0])
+    assert nets[0].pending_exchange is not None and nets[1].pending_exchange is None
+    loose = torch.nn.Parameter(torch.zeros(7))
+    loose.grad = torch.full((7,), float(rank))
+    P.allreduce_grads(nets[0].params() + nets[1].params() + [loose])
+    for tag, net in zip(("overlapped", "blocking"), nets):
+        assert net.pending_exchange is None and net.grads_live_in_slab()
+        slab_report[tag] = [(t.grad - t.detach()).clone() for t in net.params()]
+    slab_report["loose"] = loose.grad.clone()
     if rank == 0:
         torch.save({"grads": [p.grad.clone() for p in params], "ll": ll, "shards": [P.shard_slice(10, r, 3) for r in range(3)],
-                    "runs": runs}, out)
+                    "runs": runs, "slabs": slab_report}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -109,3 +137,8 @@ def test_two_rank_data_parallel_and_lse_combine(tmp_path):
     for mode in ("points", "samples"):
         assert abs(got["runs"][mode]["est_loglik/test"] - per_b.mean().item()) < 1e-5 * abs(per_b.mean().item()), mode
         assert abs(got["runs"][mode]["points"] - (12 * 12 + 12 * 12 + 8 * 8) / 32) < 1e-9
+    # slab-resident gradients: rank r held (i + 1) * (r + 1) in tensor i -> the mean over two ranks is 1.5 * (i + 1)
+    for tag in ("overlapped", "blocking"):
+        for i, g in enumerate(got["slabs"][tag]):
+            torch.testing.assert_close(g, torch.full_like(g, 1.5 * (i + 1)), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(got["slabs"]["loose"], torch.full((7,), 0.5))

@@ -164,13 +164,40 @@ def dropout_masks(seed, spec: NetSpec, rows_shape):
 
 
 # ----------------------------------------------------------------------------- cases
-def case_mlp(out, name, spec: NetSpec, rows, seed, store_params=True):
-    """A2: ResidualFCNetwork forward + backward against a fixed upstream gradient."""
+def relu_kink_margin(spec: NetSpec, params, x):
+    """per row, the smallest |pre-activation| over all hidden layers (float64)"""
+    p = {k: v.double() for k, v in params.items()}
+    a = x.double() @ p["initial_layer.weight"].T + p["initial_layer.bias"]
+    closest = a.abs().min(dim=1).values
+    a = torch.relu(a)
+    for b in range(spec.nb):
+        t = a @ p[f"blocks.{b}.linear_layers.0.weight"].T + p[f"blocks.{b}.linear_layers.0.bias"]
+        closest = torch.minimum(closest, t.abs().min(dim=1).values)
+        u = torch.relu(t) @ p[f"blocks.{b}.linear_layers.1.weight"].T + p[f"blocks.{b}.linear_layers.1.bias"] + a
+        closest = torch.minimum(closest, u.abs().min(dim=1).values)
+        a = torch.relu(u)
+    return closest
+
+
+def case_mlp(out, name, spec: NetSpec, rows, seed, store_params=True, digest_io=False, kink_margin=None):
+    """A2: ResidualFCNetwork forward + backward against a fixed upstream gradient.  digest_io: outputs and input
+    gradients of long batches are stored as row / column sums plus a strided sub-sample.  kink_margin: of the `rows`
+    drawn rows keep those none of whose hidden pre-activations lies within the margin of zero (among tens of
+    thousands of rows a few would otherwise sit within fp32 rounding of a relu kink, where two correct fp32
+    implementations pick different derivatives for the row and the weight gradients inherit the difference); the
+    kept rows are recorded bit-packed so that the readers rebuild exactly this batch."""
     params = make_params(spec, seed)
     net = ref_net(spec, params)
     net.train()
-    x = make_noise(seed + 1, rows, spec.in_dim).requires_grad_(True)
+    x = make_noise(seed + 1, rows, spec.in_dim)
     gy = make_noise(seed + 2, rows, spec.out_dim)
+    extra = {}
+    if kink_margin is not None:
+        assert spec.dropout == 0
+        ok = relu_kink_margin(spec, params, x) > kink_margin
+        extra = dict(rows_drawn=rows, row_ok=np.packbits(ok.numpy().astype(np.uint8)), kink_margin=kink_margin)
+        x, gy, rows = x[ok].contiguous(), gy[ok].contiguous(), int(ok.sum())
+    x.requires_grad_(True)
     noise = Noise()
     masks = dropout_masks(seed + 3, spec, (rows,))
     noise.dropout = [m.clone() for m in masks]
@@ -178,7 +205,13 @@ def case_mlp(out, name, spec: NetSpec, rows, seed, store_params=True):
         y = net(x)
     y.backward(gy)
     arrays = dict(seed=seed, rows=rows, spec=np.array([spec.in_dim, spec.out_dim, spec.nb, spec.hidden]),
-                  dropout=spec.dropout, y=y, dx=x.grad)
+                  dropout=spec.dropout, **extra)
+    if digest_io:
+        for key, t in (("y", y), ("dx", x.grad)):
+            for k, v in digest(t).items():
+                arrays[f"{key}.{k}"] = v
+    else:
+        arrays.update(y=y, dx=x.grad)
     if store_params:
         arrays.update(params_to_dict("p", params))
         arrays.update(x=x, gy=gy)
@@ -284,6 +317,9 @@ def _multiple(out, name, *, cls, D, Zd, C, enc_spec, dec_spec, B, I, nz, seed, S
     model = build_model(cls, enc_spec, dec_spec, enc_p, dec_p, "normal_with_eps", "stratified_with_eps", C=C, **kw)
     X, M = make_batch(seed + 2, B, D)
     noise = Noise()
+    # dropout inside the residual blocks: the encoder's masks are drawn first, then the decoder's (order of the calls)
+    dec_rows = (nz, I, B, C) if cls == "MultipleIWAE" else (nz, B, C)
+    noise.dropout = dropout_masks(seed + 4, enc_spec, (B,)) + dropout_masks(seed + 5, dec_spec, dec_rows)
     if cls == "MultipleIWAE":
         from vgiwae.models.multiple_iwae import estimate_multiple_iwelbo
         eps = make_noise(seed + 3, nz, I, B, C, Zd)
@@ -300,6 +336,7 @@ def _multiple(out, name, *, cls, D, Zd, C, enc_spec, dec_spec, B, I, nz, seed, S
             bound = estimate_multiple_elbo(model, (X, M), kl_analytic=False, var_latent_STL=STL, num_latent_samples=nz)
     (-bound).backward()
     arrays = dict(seed=seed, B=B, I=I, nz=nz, D=D, Zd=Zd, C=C, STL=STL, looser=looser, bound=bound,
+                  enc_dropout=enc_spec.dropout, dec_dropout=dec_spec.dropout,
                   enc_spec=np.array([enc_spec.in_dim, enc_spec.out_dim, enc_spec.nb, enc_spec.hidden]),
                   dec_spec=np.array([dec_spec.in_dim, dec_spec.out_dim, dec_spec.nb, dec_spec.hidden]))
     if store_inputs:
@@ -331,6 +368,11 @@ def cases_multiple(out):
     _multiple(out, "miwae_hepmass_full", cls="MultipleIWAE", D=21, Zd=16, C=5,
               enc_spec=NetSpec(42, 165, 2, 256), dec_spec=NetSpec(16, 42, 2, 256), B=512, I=1, nz=1,
               seed=20220119, STL=True, store_inputs=False)
+    # MiniBooNE shapes at full width: five residual blocks in the encoder, dropout 0.5 in both networks
+    # (configs/uci_miniboone/compare/mis50/miwae_stratified_k5_i1_encm_stl.yaml), yaml batch 1024
+    _multiple(out, "miwae_miniboone_full", cls="MultipleIWAE", D=43, Zd=32, C=5,
+              enc_spec=NetSpec(86, 325, 5, 256, dropout=0.5), dec_spec=NetSpec(32, 86, 2, 256, dropout=0.5), B=1024, I=1, nz=1,
+              seed=20220120, STL=True, store_inputs=False)
 
 
 def _mvb(out, name, *, D, Zd, K, enc_spec, dec_spec, B, nz, seed, objective, STL, kl_analytic=False,
@@ -766,8 +808,8 @@ def cases_samplers(out):
     save(out, "pgibbs_bern_m1_p1", **arrays)
 
     # ---- LAIR: dmis weights, global multinomial resampling
-    for tag, I, r, T, final in (("r0_T1", 1, 0, 1, False), ("r1_T3_final", 2, 1, 3, True)):
-        seed = 5200 if r == 0 else 5300
+    for tag, I, r, T, final in (("r0_T1", 1, 0, 1, False), ("r1_T3_final", 2, 1, 3, True), ("r1_T10_final", 1, 1, 10, True)):
+        seed = 5200 if r == 0 else 5300 if T == 3 else 5400
         q = "normal" if r == 0 else "normal_with_eps"
         enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
         model = _sampler_model(enc_spec, dec_spec, enc_p, dec_p, q, q, False)
@@ -879,6 +921,84 @@ def cases_loglik(out):
             save(out, f"loglik_{kind}_{tag}", **arrays)
 
 
+def cases_loglik_k50000(out):
+    """A15 at the configs' K: RefitEncoderUsingIWAE.test_step with 50 000 importance samples on 8 complete test points
+    (configs/uci_*/compare/refit_encoder_testcomp: num_test_importance_samples 50000).  Noise is rebuilt from the
+    seed; stored are the batch estimate and every point's own estimate (the test step run on that point alone with
+    its slice of the same noise)."""
+    from vgiwae.test.refit_encoder_using_iwae_and_estimate_loglik import RefitEncoderUsingIWAE, RefitEncoderClass
+    D, Zd, B, K, seed = 8, 16, 8, 50000, 7900
+    enc_spec, dec_spec = NetSpec(2 * D, 2 * Zd, 2, 32), NetSpec(Zd, 2 * D, 2, 32)
+    enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+    model = build_model("IWAE", enc_spec, dec_spec, enc_p, dec_p, "normal_with_eps", "normal_with_eps",
+                        encoder_use_mis_mask=True, num_importance_samples=5)
+    model.eval()
+    refit = RefitEncoderUsingIWAE(RefitEncoderClass.standard, num_test_latent_samples=1, num_test_importance_samples=K)
+    refit.set_model(model)
+    X, _ = make_batch(seed + 2, B, D)
+    M = torch.ones(B, D, dtype=torch.bool)
+    eps = make_noise(seed + 3, 1, K, B, Zd)
+    logged = {}
+    refit.log = lambda name, v, **k: logged.__setitem__(name, v)
+
+    def run(Xb, Mb, eb):
+        noise = Noise()
+        noise.normal = [eb.clone()]
+        with injected(noise):
+            refit.test_step((Xb, Mb), 0)
+        return float(logged["est_loglik/test"])
+    est = run(X, M, eps)
+    per_point = np.array([run(X[b:b + 1], M[b:b + 1], eps[:, :, b:b + 1].contiguous()) for b in range(B)], dtype=np.float64)
+    arrays = dict(seed=seed, D=D, Zd=Zd, B=B, K=K, C=1, kind="standard", X=X, M=M, est_loglik=est, per_point=per_point,
+                  eps=np.zeros(0), enc_spec=np.array([2 * D, 2 * Zd, 2, 32]), dec_spec=np.array([Zd, 2 * D, 2, 32]))
+    arrays.update(params_to_dict("enc", enc_p))
+    arrays.update(params_to_dict("dec", dec_p))
+    save(out, "loglik_standard_K50000", **arrays)
+
+
+def cases_datamodule(out, ref):
+    """(f)2: the reference's MissingDataModule itself (vgiwae/data/missing_data_module.py:171-312) on the toy data it
+    ships: split loading, missingness, fully-missing filter, index wrapper and pre-imputation in its own order of
+    generator draws.  Stored per configuration: packed masks, kept indices, and of the (pre-imputed) data a row
+    sub-sample plus float64 column sums."""
+    # version skew: the reference imports corrcoef from numpy.lib.function_base, a module path numpy 2 dropped; the
+    # function itself is numpy's own
+    if "numpy.lib.function_base" not in sys.modules:
+        import types
+        shim = types.ModuleType("numpy.lib.function_base")
+        shim.corrcoef = np.corrcoef
+        sys.modules["numpy.lib.function_base"] = shim
+    from vgiwae.data import MissingDataModule
+    from vgiwae.data.missing_data_module import DATASET, MISSINGNESS, PRE_IMPUTATION
+    cwd = os.getcwd()
+    os.chdir(ref)                # the toy loader resolves <data_root>/toy/<file>.mat
+    try:
+        arrays = {}
+        # ('empirical' pre-imputation cannot be pinned: the reference hands a numpy mask to torch.multinomial,
+        #  missing_data_module.py:150, and raises TypeError on every dataset it ships)
+        configs = (("uniform_oracle", "uniform", 0.5, 0.3, "oracle", False),
+                   ("tophalf_mean", "top_half", 0.5, 0.5, "mean", True),
+                   ("uniform_zero", "uniform", 0.8, 0.5, "zero", False))
+        for tag, miss, mt, mv, pre, pre_val in configs:
+            dm = MissingDataModule(dataset=DATASET.toy_mog2_large, batch_size=64, missingness=MISSINGNESS(miss),
+                                   total_miss_train=mt, total_miss_val=mv, pre_imputation=PRE_IMPUTATION(pre),
+                                   pre_impute_val=pre_val, data_root="./data", setup_seed=20220118, total_miss_test=0.0)
+            dm.setup("fit")
+            dm.setup("test")
+            for split, ds in (("train", dm.train_data), ("val", dm.val_data), ("test", dm.test_data)):
+                items = ds[:]
+                Xs, Ms, idx = np.asarray(items[0]), np.asarray(items[1]), np.asarray(items[-1])
+                arrays[f"{tag}.{split}.n"] = len(ds)
+                arrays[f"{tag}.{split}.mask_bits"] = np.packbits(Ms.astype(np.uint8), axis=None)
+                arrays[f"{tag}.{split}.index"] = idx.astype(np.int64)
+                arrays[f"{tag}.{split}.x_sub"] = Xs[::37].astype(np.float32)
+                arrays[f"{tag}.{split}.x_colsum"] = Xs.astype(np.float64).sum(0)
+        arrays["configs"] = np.array([",".join(str(v) for v in c) for c in configs])
+        save(out, "datamodule", setup_seed=20220118, **arrays)
+    finally:
+        os.chdir(cwd)
+
+
 def cases_masks(out, ref):
     """A0: missingness masks, fully-missing filter and index wrapper (loaded by file path because the
     reference's vgiwae.data package __init__ needs torchvision)."""
@@ -920,6 +1040,10 @@ def cases_masks(out, ref):
         g.manual_seed(20220118)
         ds = quad.QuadrantMissingnessDataset(Plain(img), total_miss=miss, img_dims=[28, 28], rng=g)
         arrays[f"quadrant_{int(miss * 100)}"] = ds.miss_mask
+    top = load("tophalf_missingness_provider.py", "ref_tophalf")
+    for miss in (0.25, 0.5):
+        ds = top.TopHalfMissingnessDataset(Plain(img), total_miss=miss, rng=torch.Generator().manual_seed(20220118))
+        arrays[f"tophalf_{int(miss * 100)}"] = ds.miss_mask
     save(out, "masks", N=N, D=D, seed=20220118, **arrays)
 
 
@@ -985,7 +1109,10 @@ def main():
                         case_mlp(args.out, "mlp_toy_h200", NetSpec(5, 4, 3, 200), 70, 110, store_params=False),
                         case_mlp(args.out, "mlp_gas_h256", NetSpec(16, 16, 2, 256), 100, 120, store_params=False),
                         case_mlp(args.out, "mlp_dropout", NetSpec(16, 32, 2, 32, dropout=0.5), 40, 130),
-                        case_mlp(args.out, "mlp_odd_dims", NetSpec(43, 86, 1, 64), 33, 140, store_params=False)],
+                        case_mlp(args.out, "mlp_odd_dims", NetSpec(43, 86, 1, 64), 33, 140, store_params=False),
+                        # above every small-batch kernel family's row limit: the kernels the headline benchmark times
+                        case_mlp(args.out, "mlp_gas_rows20k", NetSpec(16, 16, 2, 256), 21504, 150, store_params=False,
+                                 digest_io=True, kink_margin=1e-5)],
         "iwae": lambda: cases_iwae(args.out),
         "vae": lambda: cases_vae(args.out),
         "multiple": lambda: cases_multiple(args.out),
@@ -993,6 +1120,8 @@ def main():
         "samplers": lambda: cases_samplers(args.out),
         "buffer": lambda: cases_buffer(args.out),
         "loglik": lambda: cases_loglik(args.out),
+        "loglik50k": lambda: cases_loglik_k50000(args.out),
+        "datamodule": lambda: cases_datamodule(args.out, args.ref),
         "masks": lambda: cases_masks(args.out, args.ref),
         "dmis": lambda: cases_dmis_known_answer(args.out),
         "resnet": lambda: cases_resnet(args.out),

@@ -85,7 +85,16 @@ class LightningModule(nn.Module):
 
 
 class LightningDataModule:
-    pass
+    """hparams attribute dictionary filled from the constructor's arguments, as for LightningModule (plumbing only)"""
+
+    def __init__(self, *args, **kwargs):
+        self.__dict__["_hp"] = _AttrDict()
+
+    @property
+    def hparams(self):
+        return self.__dict__["_hp"]
+
+    save_hyperparameters = LightningModule.save_hyperparameters
 
 
 class Trainer:

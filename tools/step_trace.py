@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""One training step of the UCI-gas MissIWAE model (K = 5, STL, clip + AMSGrad through the library's optimiser) at a
+given batch size, eager or replayed from a HIP graph, for rocprofv3 kernel traces:
+    rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python tools/step_trace.py 512 graph 200
+Prints the wall time per step."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import demiss_vae_amd as dmv  # noqa: E402
+from bench import make_gas  # noqa: E402
+from demiss_vae_amd.optim import Adam  # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else "512"
+mode = sys.argv[2] if len(sys.argv) > 2 else "graph"
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+K = 5
+if what in ("hepmass", "miniboone"):
+    # MissSIWAE (stratified mixture of 5, one sample per component): configs/uci_hepmass, configs/uci_miniboone shapes
+    from demiss_vae_amd import synth
+    from demiss_vae_amd.mlp import make_keep_masks
+    B, D, Zd, es, ds, p = (4096, 21, 16, (42, 165, 2, 256), (16, 42, 2, 256), 0.0) if what == "hepmass" else \
+        (8192, 43, 32, (86, 325, 5, 256), (32, 86, 2, 256), 0.5)
+    enc = synth.packed_net(synth.NetShape(*es, dropout=p), 1, "cuda")
+    dec = synth.packed_net(synth.NetShape(*ds, dropout=p), 2, "cuda")
+    dims = dmv.ModelDims(D=D, Zd=Zd, q_dist="stratified_with_eps", C=5, encoder_use_mis_mask=True)
+    X, M = (t.cuda() for t in synth.batch(3, B, D))
+    opt = Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True)
+
+    def step():
+        ek, dk = make_keep_masks(enc.dims, B, "cuda"), make_keep_masks(dec.dims, B * 5, "cuda")
+        _, _, loss = dmv.estimate_multiple_iwelbo(dims, enc, dec, X, M, num_importance_samples_for_each_component=1, STL=True,
+                                                  enc_keep=ek, dec_keep=dk, with_loss=True)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+else:
+    B = int(what)
+    dims, enc, dec, _, _, X, M = make_gas("cuda", B)
+    opt = Adam([{"params": dec.params(), "amsgrad": True, "lr": 1e-3}, {"params": enc.params(), "amsgrad": True, "lr": 1e-3}])
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        _, _, loss = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=1, num_importance_samples=K, STL=True,
+                                         with_loss=True)
+        loss.backward()
+        opt.clip_on_next_step(5.0)
+        opt.step()
+
+
+fn = dmv.GraphedStep(step, nets=(enc, dec)) if mode == "graph" else step
+for _ in range(20):
+    fn()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    fn()
+torch.cuda.synchronize()
+print(f"B={B} {mode}: {(time.perf_counter() - t0) / steps * 1e3:.4f} ms/step over {steps} steps")

@@ -7,7 +7,7 @@ import torch
 
 import demiss_vae_amd as dmv
 from demiss_vae_amd.pl_compat import STEP_OUTPUT
-from vgiwae.models.vae import VAE, _inner
+from vgiwae.models.vae import VAE, _inner, _bound_and_loss
 
 
 class IWAE(VAE):
@@ -19,15 +19,15 @@ class IWAE(VAE):
         assert not (self.hparams.var_latent_DREG and self.hparams.var_latent_STL), \
             "Cannot use STL and DREG gradients at the same time."
 
-    def _bound(self, batch):
+    def _bound(self, batch, return_loss=False):
         h = self.hparams
         return estimate_iwelbo(self, batch, var_latent_STL=h.var_latent_STL, var_latent_DREG=h.var_latent_DREG,
-                               num_latent_samples=h.num_latent_samples, num_importance_samples=h.num_importance_samples)
+                               num_latent_samples=h.num_latent_samples, num_importance_samples=h.num_importance_samples,
+                               return_loss=return_loss)
 
     def training_step(self, batch, batch_idx) -> STEP_OUTPUT:
-        elbo = self._bound(batch)
+        elbo, loss = self._bound(batch, return_loss=True)       # loss = -elbo, formed where the mean is formed
         self.log("elbo/train", elbo, on_step=True, on_epoch=True, prog_bar=False, logger=True)
-        loss = -elbo
         self.log("loss/train", loss, on_step=True, on_epoch=True, prog_bar=True, logger=True)
         return loss
 
@@ -53,7 +53,8 @@ def log_weights_to_iwelbo(log_weights, *, create_Z_hook=None, var_latent_DREG=Fa
 
 def estimate_iwelbo(model, batch, var_latent_STL: bool = False, var_latent_DREG: bool = False,
                     num_latent_samples: int = 1, num_importance_samples: int = 1, *,
-                    sample_stratifieddistr_without_stratification_norsample=False, eps=None, comp_idx=None, k_shard=None):
+                    sample_stratifieddistr_without_stratification_norsample=False, eps=None, comp_idx=None, k_shard=None,
+                    return_loss=False):
     """Batch-mean IWAE bound (vgiwae/models/iwae.py:125-154).
 
     With gradients enabled this is the fused training pipeline.  The streaming K-sample estimator (no [K, B, .] tensor,
@@ -77,7 +78,7 @@ def estimate_iwelbo(model, batch, var_latent_STL: bool = False, var_latent_DREG:
     if m.fused and num_latent_samples == 1 and not dropout_live and (unstratified or big):
         val, _ = estimate_loglik(dims, enc, dec, X, M, num_importance_samples=num_importance_samples, eps=eps,
                                  comp_idx=comp_idx, k_shard=k_shard)
-        return val
+        return (val, -val) if return_loss else val
     assert k_shard is None or k_shard[1] == 1, "importance samples are sharded by the streaming estimator only"
     if unstratified:
         # all samples in one pass (convolutional trunks; residual MLPs with live dropout): a stratified mixture sampled
@@ -90,6 +91,8 @@ def estimate_iwelbo(model, batch, var_latent_STL: bool = False, var_latent_DREG:
         kw["enc_keep"], kw["dec_keep"] = m.dropout_masks(X.shape[0], num_latent_samples * num_importance_samples * X.shape[0])
     if comp_idx is not None:
         kw["comp_idx"] = comp_idx
-    bound, _ = fn(dims, enc, dec, X, M, num_latent_samples=num_latent_samples, num_importance_samples=num_importance_samples,
-                  STL=var_latent_STL, DREG=var_latent_DREG, eps=eps, **kw)
-    return bound
+    if fused and return_loss:
+        kw["with_loss"] = True
+    return _bound_and_loss(fn(dims, enc, dec, X, M, num_latent_samples=num_latent_samples,
+                              num_importance_samples=num_importance_samples, STL=var_latent_STL, DREG=var_latent_DREG, eps=eps,
+                              **kw), return_loss)

@@ -7,7 +7,7 @@ import torch
 
 import demiss_vae_amd as dmv
 from demiss_vae_amd.pl_compat import STEP_OUTPUT
-from vgiwae.models.vae import VAE, _inner
+from vgiwae.models.vae import _bound_and_loss, VAE, _inner
 
 
 class _MixtureLogitLogging:
@@ -52,17 +52,16 @@ class MultipleIWAE(_MixtureLogitLogging, VAE):
         assert self.hparams.var_latent_distribution.name.startswith("stratified_mixture"), \
             "Only mixture-distributions are supported for encoder in multiple-IWAE."
 
-    def estimate_multiple_iwelbo(self, batch):
+    def estimate_multiple_iwelbo(self, batch, return_loss=False):
         h = self.hparams
         return estimate_multiple_iwelbo(self, batch, var_latent_STL=h.var_latent_STL, var_latent_DREG=h.var_latent_DREG,
                                         num_latent_samples=h.num_latent_samples,
                                         num_importance_samples_for_each_component=h.num_importance_samples_for_each_component,
-                                        use_looser_bound=h.use_looser_bound)
+                                        use_looser_bound=h.use_looser_bound, return_loss=return_loss)
 
     def training_step(self, batch, batch_idx) -> STEP_OUTPUT:
-        elbo = self.estimate_multiple_iwelbo(batch)
+        elbo, loss = self.estimate_multiple_iwelbo(batch, return_loss=True)     # loss = -elbo
         self.log("elbo/train", elbo, on_step=True, on_epoch=True, prog_bar=False, logger=True)
-        loss = -elbo
         self.log("loss/train", loss, on_step=True, on_epoch=True, prog_bar=True, logger=True)
         return loss
 
@@ -75,7 +74,7 @@ class MultipleIWAE(_MixtureLogitLogging, VAE):
 
 def estimate_multiple_iwelbo(model, batch, var_latent_STL: bool = False, var_latent_DREG: bool = False,
                              num_latent_samples: int = 1, num_importance_samples_for_each_component: int = 1,
-                             use_looser_bound: bool = False, eps=None):
+                             use_looser_bound: bool = False, eps=None, return_loss=False):
     """Batch-mean MissSIWAE bound, tight or looser (vgiwae/models/multiple_iwae.py:124-237)."""
     assert not var_latent_DREG
     X, M = batch[:2]
@@ -86,12 +85,14 @@ def estimate_multiple_iwelbo(model, batch, var_latent_STL: bool = False, var_lat
     kw = {}
     if fused:
         kw["enc_keep"], kw["dec_keep"] = m.dropout_masks(X.shape[0], num_latent_samples * I * X.shape[0] * dims.C)
-    bound, _ = fn(dims, enc, dec, X, M, num_latent_samples=num_latent_samples, num_importance_samples_for_each_component=I,
-                  STL=var_latent_STL, looser=use_looser_bound, eps=eps, **kw)
+    if fused and return_loss:
+        kw["with_loss"] = True
+    outs = fn(dims, enc, dec, X, M, num_latent_samples=num_latent_samples, num_importance_samples_for_each_component=I,
+              STL=var_latent_STL, looser=use_looser_bound, eps=eps, **kw)
     if model.training and getattr(model, "_log_due", lambda: False)() and hasattr(model, "mixture_weight_logits_epoch"):
         # diagnostic dump of the (normalised) mixture logits on logging epochs (multiple_iwae.py:220-226); the pipeline
         # keeps the encoder output to itself, so this is one more encoder pass without gradients
         with torch.no_grad():
             p = m.predict_var_latent_params(X * M, M)
             model.mixture_weight_logits_epoch.append(torch.log_softmax(p[..., -dims.C:], dim=-1).cpu().numpy())
-    return bound
+    return _bound_and_loss(outs, return_loss)

@@ -143,9 +143,8 @@ class VAE(ImputerModuleBase, PLEstimateTotalTrainSteps):
 
     # ------------------------------------------------------------------ steps
     def training_step(self, batch, batch_idx) -> STEP_OUTPUT:
-        elbo = estimate_elbo(self, batch, kl_analytic=self.hparams.kl_analytic, var_latent_STL=self.hparams.var_latent_STL,
-                             num_latent_samples=self.hparams.num_latent_samples)
-        loss = -elbo
+        elbo, loss = estimate_elbo(self, batch, kl_analytic=self.hparams.kl_analytic, var_latent_STL=self.hparams.var_latent_STL,
+                                   num_latent_samples=self.hparams.num_latent_samples, return_loss=True)
         self.log("elbo/train", elbo, on_step=True, on_epoch=True, prog_bar=False, logger=True)
         self.log("loss/train", loss, on_step=True, on_epoch=True, prog_bar=True, logger=True)
         return loss
@@ -184,13 +183,21 @@ def _adam(groups):
     return torch.optim.Adam(groups)
 
 
+def _bound_and_loss(outs, return_loss):
+    """What an estimator of this package returns: the batch-mean bound, or (bound, loss = -bound).  The fused engine
+    hands the loss over as a third output (negated by the kernel that forms the mean); otherwise it is negated here."""
+    if not return_loss:
+        return outs[0]
+    return (outs[0], outs[2]) if len(outs) > 2 else (outs[0], -outs[0])
+
+
 def _inner(model):
     """The object that owns the networks (RefitEncoderUsingIWAE passes itself and wraps the trained model)."""
     return getattr(model, "model", model)
 
 
 def estimate_elbo(model, batch, kl_analytic: bool = False, var_latent_STL: bool = False, num_latent_samples: int = 1,
-                  eps=None, comp_idx=None):
+                  eps=None, comp_idx=None, return_loss=False):
     """Batch-mean ELBO (vgiwae/models/vae.py:447-473) through the fused pipeline."""
     X, M = batch[:2]
     m = _inner(model)
@@ -201,6 +208,7 @@ def estimate_elbo(model, batch, kl_analytic: bool = False, var_latent_STL: bool 
         kw["enc_keep"], kw["dec_keep"] = m.dropout_masks(X.shape[0], num_latent_samples * X.shape[0])
     if comp_idx is not None:
         kw["comp_idx"] = comp_idx
-    bound, _ = fn(dims, enc, dec, X, M, num_latent_samples=num_latent_samples, kl_analytic=kl_analytic,
-                  STL=var_latent_STL, eps=eps, **kw)
-    return bound
+    if fused and return_loss:
+        kw["with_loss"] = True
+    return _bound_and_loss(fn(dims, enc, dec, X, M, num_latent_samples=num_latent_samples, kl_analytic=kl_analytic,
+                              STL=var_latent_STL, eps=eps, **kw), return_loss)
