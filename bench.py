@@ -137,7 +137,7 @@ def kernel_roofline(dec, dec_s, rows, device):
 
     def fwd():
         L.check(lib.dmv_mlp_forward(C.byref(dec.c), L.ptr(packed), L.IN_PLAIN, dec_s.in_dim, L.ptr(Z), dec_s.in_dim, None, 0,
-                                    rows, L.ptr(y), y.shape[1], L.ptr(saved), None, st))
+                                    rows, L.ptr(y), y.shape[1], L.ptr(saved), None, None, st))
 
     def chain():
         L.check(lib.dmv_mlp_backward(C.byref(dec.c), L.ptr(packed), L.ptr(saved), None, L.ptr(gy), gy.shape[1], rows,

@@ -19,6 +19,13 @@ Q_OWN, Q_STRATIFIED, Q_IMPUTATION = 0, 1, 2
 BOUND_LSE, BOUND_WEIGHTED, BOUND_PER_COMPONENT, TERMS_ONLY = 0, 1, 2, -1
 
 
+class DmvDropRng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("offset", C.c_uint64), ("offset_base", C.c_void_p)]
+
+
+DROP_GENERATED = C.c_void_p(1)      # dmv_mlp_backward's drop_keep when the forward drew its keep decisions itself
+
+
 class DmvNet(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("out_dim", C.c_int32), ("hidden", C.c_int32), ("nb", C.c_int32),
                 ("act", C.c_int32), ("dropout_p", C.c_float)]
@@ -66,7 +73,10 @@ SIGNATURES = {
     "dmv_mlp_packed_floats": (_SZ, [C.POINTER(DmvNet)]),
     "dmv_mlp_pack": (C.c_int, [C.POINTER(DmvNet), C.POINTER(_P), C.POINTER(_P), _P, _P]),
     "dmv_mlp_saved_floats": (_SZ, [C.POINTER(DmvNet), _I64]),
-    "dmv_mlp_forward": (C.c_int, [C.POINTER(DmvNet), _P, _I32, _I32, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _P, _P]),
+    "dmv_mlp_forward": (C.c_int, [C.POINTER(DmvNet), _P, _I32, _I32, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _P,
+                                  C.POINTER(DmvDropRng), _P]),
+    "dmv_mlp_dropout_rng_elements": (_SZ, [C.POINTER(DmvNet), _I64]),
+    "dmv_mlp_dropout_keep": (C.c_int, [C.POINTER(DmvNet), _I64, C.POINTER(DmvDropRng), _P, _P]),
     "dmv_mlp_backward_ws_bytes": (_SZ, [C.POINTER(DmvNet), _I64]),
     "dmv_mlp_backward": (C.c_int, [C.POINTER(DmvNet), _P, _P, _P, _P, _I64, _I64, _P, _I64,
                                    C.POINTER(_P), C.POINTER(_P), _F, _P, _SZ, _P]),

@@ -5,7 +5,7 @@ import time
 import torch
 
 from . import estimate_iwelbo, estimate_multiple_iwelbo, mvb2_objectives, ModelDims, NetDims, PackedNet  # noqa: F401
-from .mlp import make_keep_masks
+from .imputation import _keep as keep_for
 from . import imputation as imp
 from . import parallel as P
 from .optim import Adam
@@ -41,8 +41,8 @@ def missiwae_step(device, name, B, D, Zd, enc_shape, dec_shape, C=5, dropout=0.0
     opt = Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True)
 
     def step():
-        ek = make_keep_masks(enc.dims, B, device)
-        dk = make_keep_masks(dec.dims, B * C, device)
+        ek = keep_for(enc, B, True, device)           # as the model classes get them: drawn inside the kernels
+        dk = keep_for(dec, B * C, True, device)
         _, _, loss = estimate_multiple_iwelbo(dims, enc, dec, X, M, num_importance_samples_for_each_component=1, STL=True,
                                               enc_keep=ek, dec_keep=dk, with_loss=True)
         opt.zero_grad(set_to_none=True)

@@ -15,6 +15,7 @@
 // fp32 MFMA runs at the fp32 vector rate (64 FLOP/clk/SIMD), so this path is bound by MFMA issue;
 // one wave per SIMD with two 32*NT-register activation sets keeps the matrix pipe busy.
 #include "dmv_common.h"
+#include "dmv_rng.h"
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -133,12 +134,103 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, uint32_t la
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_bytes, off, 0);
 }
 
-// keep-masks of one residual block for this wave's 32 rows, as a buffer: a read past the end of the masks
-// (padded features of the last rows) returns 0 and is never used (those features are identically 0)
-struct DropIn {
-  __amdgpu_buffer_rsrc_t keep;
-  uint32_t lane;   // byte offset of this lane's row + 4 h
+// Where the keep decisions of the residual blocks' dropout layers come from: explicit bytes [nb][rows][hidden]
+// (parity with recorded masks), or generated in the kernel from the Philox stream (training: no mask array is
+// written or read at all).  Generated decisions depend only on (seed, first call, block, row, feature): every
+// kernel family and dmv_mlp_dropout_keep produce the same ones.  A unit draws `bits` random bits (1 when the
+// dropout probability is 1/2, 8 when it is a multiple of 1/256, else 16) and is kept when their value is at least
+// `thresh` = round(p 2^bits).  The draws of one (block, row, half h = the lane's half of the 8-feature groups) are
+// consecutive 128-bit generator calls: unit j = 4 q + e of 32-wide tile t (feature 32 t + 8 q + 4 h + e) owns bits
+// [(16 t + j) bits, (16 t + j + 1) bits) of that run.
+struct DropSrc {
+  int32_t mode;            // 0 off, 1 explicit bytes, 2 generated
+  int32_t bits;
+  uint32_t thresh;
+  const uint8_t* keep;
+  uint64_t seed, q0;       // generated: Philox key, first call number
+  const uint64_t* offset_base;   // generated, nullable: device counter (in elements of 32 bits) added to the start
 };
+enum { DROP_OFF = 0, DROP_BYTES = 1, DROP_GEN = 2 };
+#define DMV_DROP_TAG 0x64726f70ull /* "drop" */
+
+__host__ __device__ inline int drop_calls(int bits, int NT) { return bits == 1 ? (NT + 7) / 8 : bits == 8 ? NT : 2 * NT; }
+
+__device__ __forceinline__ uint64_t drop_first_call(const DropSrc& d) {
+  return d.q0 + (d.offset_base ? (*d.offset_base >> 2) : 0ull);
+}
+
+__device__ __forceinline__ uint32_t u4_word(const dmv_u4& r, int i) { return i == 0 ? r.x : i == 1 ? r.y : i == 2 ? r.z : r.w; }
+
+// Keep bits of row rl, half h, block blk for the 32-wide tiles [tile_lo, tile_hi), in the layout of the sign-bit
+// words: bit 16 (t & 1) + 4 q + e of kb[t >> 1].  Tiles outside the range may come back set or clear.
+template <int NT>
+__device__ __forceinline__ void drop_words(const DropSrc& d, uint64_t q0, int64_t rows, int hidden, int blk, int64_t rl, int h,
+                                           int tile_lo, int tile_hi, uint32_t (&kb)[mask_words(NT)]) {
+#pragma unroll
+  for (int i = 0; i < mask_words(NT); ++i) kb[i] = 0u;
+  if (d.mode == DROP_BYTES) {
+    const uint8_t* k = d.keep + ((int64_t)blk * rows + rl) * hidden + 4 * h;
+    const bool dwords = (hidden & 3) == 0 && ((uintptr_t)d.keep & 3) == 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (t >= tile_lo && t < tile_hi) {
+        uint32_t b16 = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = 32 * t + 8 * q + 4 * h;
+          if (dwords) {
+            const uint32_t w = n < hidden ? *(const uint32_t*)(k + 32 * t + 8 * q) : 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b16 |= (((w >> (8 * e)) & 0xffu) ? 1u : 0u) << (4 * q + e);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b16 |= ((n + e < hidden && k[32 * t + 8 * q + e]) ? 1u : 0u) << (4 * q + e);
+          }
+        }
+        kb[t >> 1] |= b16 << (16 * (t & 1));
+      }
+    return;
+  }
+  const uint64_t qb = q0 + (((uint64_t)blk * (uint64_t)rows + (uint64_t)rl) * 2u + (uint64_t)h) * (uint64_t)drop_calls(d.bits, NT);
+  if (d.bits == 1) {
+#pragma unroll
+    for (int c = 0; c < (NT + 7) / 8; ++c) {
+      const dmv_u4 r = dmv_philox4x32_10(d.seed, qb + c, DMV_DROP_TAG);
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (4 * c + w < mask_words(NT)) kb[4 * c + w] = u4_word(r, w);
+    }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (t >= tile_lo && t < tile_hi) {
+      uint32_t b16 = 0u;
+      if (d.bits == 8) {
+        const dmv_u4 r = dmv_philox4x32_10(d.seed, qb + t, DMV_DROP_TAG);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b16 |= (((u4_word(r, j >> 2) >> (8 * (j & 3))) & 0xffu) >= d.thresh ? 1u : 0u) << j;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const dmv_u4 r = dmv_philox4x32_10(d.seed, qb + 2 * t + c, DMV_DROP_TAG);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            b16 |= (((u4_word(r, j >> 1) >> (16 * (j & 1))) & 0xffffu) >= d.thresh ? 1u : 0u) << (8 * c + j);
+        }
+      }
+      kb[t >> 1] |= b16 << (16 * (t & 1));
+    }
+}
+
+// halfword `tile` of a keep-bit / sign-bit word array, for a tile number known only at run time (wave-uniform)
+template <int MW>
+__device__ __forceinline__ uint32_t half_of(const uint32_t (&kb)[MW], int tile) {
+  uint32_t w = 0u;
+#pragma unroll
+  for (int i = 0; i < MW; ++i) w = (tile >> 1) == i ? kb[i] : w;
+  return (w >> (16 * (tile & 1))) & 0xffffu;
+}
 
 // fragment `frag` (64 lanes x 16 bytes) of a weight image
 __device__ __forceinline__ f32x4 frag_load(__amdgpu_buffer_rsrc_t img, int frag, uint32_t lane_bytes) {
@@ -152,10 +244,9 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
-template <int NT, int PF, bool BIAS, bool DROP = false>
+template <int NT, int PF, bool BIAS>
 __device__ __forceinline__ void gemm_head(const f32x4* __restrict__ Wimg, const float* __restrict__ Bimg, int lane,
-                                          f32x4 (&w)[PF + 1][NT], float (&bf)[NT], const DropIn* drop = nullptr,
-                                          uint32_t* kp = nullptr) {
+                                          f32x4 (&w)[PF + 1][NT], float (&bf)[NT]) {
   constexpr int S = 4 * NT;
   const uint32_t lb = (uint32_t)lane * 16u;
   const __amdgpu_buffer_rsrc_t img = make_rsrc(Wimg, NT * S * 1024u);
@@ -168,10 +259,6 @@ __device__ __forceinline__ void gemm_head(const f32x4* __restrict__ Wimg, const 
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       bf[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bimg, (uint32_t)lane * 4u + t * 256u, 0, 0));
-  }
-  if (DROP) {
-#pragma unroll
-    for (int p = 0; p < PF; ++p) kp[p] = __builtin_amdgcn_raw_buffer_load_b32(drop->keep, drop->lane, 8u * p, 0);
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -216,12 +303,11 @@ __device__ __forceinline__ void collect_mask(const f32x16 (&in)[NT], int s, uint
 // What a GEMM does to its input registers on the way in (in place, four registers per group, in the shadow of
 // the previous group's MFMAs), so that no elementwise pass over the whole state sits between two GEMMs:
 //   IN_MASK:      v = sign bit set ? scale * v : 0           (relu backward, dropout scale folded in)
-//   IN_RELU_DROP: v = keep byte set ? scale * max(v, 0) : 0  (relu then inverted dropout; keep4 = this group's 4 bytes)
+//   IN_RELU_DROP: v = keep bit set ? scale * max(v, 0) : 0  (relu then inverted dropout; the bits as drop_words lays them out)
 enum { IN_ASIS = 0, IN_RELU = 1, IN_MASK = 2, IN_RELU_DROP = 3 };
 
 template <int INOP, int NT>
-__device__ __forceinline__ void in_op(f32x16 (&in)[NT], int s, const uint32_t (&mkin)[mask_words(NT)], float scale,
-                                      uint32_t keep4 = 0u) {
+__device__ __forceinline__ void in_op(f32x16 (&in)[NT], int s, const uint32_t (&mkin)[mask_words(NT)], float scale) {
   if (INOP == IN_ASIS) return;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -229,7 +315,8 @@ __device__ __forceinline__ void in_op(f32x16 (&in)[NT], int s, const uint32_t (&
     if (INOP == IN_RELU) {
       v = __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());   // max(v, 0) in one instruction (NaN -> 0, like fmaxf)
     } else if (INOP == IN_RELU_DROP) {
-      v = ((keep4 >> (8 * e)) & 0xffu) ? scale * __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()) : 0.f;
+      const bool on = (mkin[s >> 3] >> (16 * ((s >> 2) & 1) + 4 * (s & 3) + e)) & 1u;
+      v = on ? scale * __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()) : 0.f;
     } else {
       const bool on = (mkin[s >> 3] >> (16 * ((s >> 2) & 1) + 4 * (s & 3) + e)) & 1u;
       v = on ? v * scale : 0.f;
@@ -242,8 +329,7 @@ template <int NT, int PF, bool FRESH, bool BIAS, bool ST, bool MKW, int INOP>
 __device__ __forceinline__ void gemm_hh(const f32x4* __restrict__ Wimg, int lane, f32x16 (&in)[NT],
                                         f32x16 (&acc)[NT], f32x4 (&w)[PF + 1][NT], const float (&bf)[NT],
                                         float* __restrict__ st_tile, uint32_t st_lane, uint32_t* __restrict__ mk_dst,
-                                        const uint32_t (&mkin)[mask_words(NT)], float scale,
-                                        const DropIn* drop = nullptr, uint32_t* kp = nullptr) {
+                                        const uint32_t (&mkin)[mask_words(NT)], float scale) {
   constexpr int S = 4 * NT;
   const uint32_t lb = (uint32_t)lane * 16u;
   const __amdgpu_buffer_rsrc_t img = make_rsrc(Wimg, NT * S * 1024u);
@@ -258,10 +344,8 @@ __device__ __forceinline__ void gemm_hh(const f32x4* __restrict__ Wimg, int lane
     if (s + PF < S) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) w[(s + PF) % (PF + 1)][t] = frag_load(img, t * S + s + PF, lb);
-      if (INOP == IN_RELU_DROP)
-        kp[(s + PF) % (PF + 1)] = __builtin_amdgcn_raw_buffer_load_b32(drop->keep, drop->lane, 8u * (s + PF), 0);
     }
-    in_op<INOP, NT>(in, s, mkin, scale, INOP == IN_RELU_DROP ? kp[s % (PF + 1)] : 0u);
+    in_op<INOP, NT>(in, s, mkin, scale);
     if (ST) {
       f32x4 o;
 #pragma unroll
@@ -404,7 +488,7 @@ struct FwdArgs {
   DmvLayout L;
   const float* packed;
   int nb, in_dim, hidden, act;
-  float drop_scale;  // 1/(1-p), used only with drop_keep
+  float drop_scale;  // 1/(1-p), used only with dropout on
   int in_mode, D;
   const float* x;
   int64_t ldx;
@@ -416,7 +500,7 @@ struct FwdArgs {
   float* xs;     // saved first-layer input [rows][32*T_in] (nullable)
   float* acts;   // saved activations [(2nb+1)][rows][32*NT] (nullable)
   uint32_t* masks;  // sign bits of the saved activations [(2nb+1)][rows][2][mask_words] (with acts)
-  const uint8_t* drop_keep;  // [nb][rows][hidden] (nullable)
+  DropSrc drop;
 };
 
 // Four consecutive first-layer inputs (columns k0 .. k0+3) of row r, branch-free: loads are unconditional with
@@ -476,6 +560,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
   f32x16 A[NT], T[NT];
   f32x4 w[PF + 1][NT];   // weight ring of the hidden GEMMs
   float bf[NT];          // bias fragments of the next hidden GEMM
+  const uint64_t drop_q0 = (MODE == FWD_RELU_DROP && a.drop.mode == DROP_GEN) ? drop_first_call(a.drop) : 0ull;
 
   TRACE(0);
   TRACE_REAL(13);
@@ -505,21 +590,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
     gemm_hh<NT, PF, true, true, SAVE, SAVE, INR>((const f32x4*)(a.packed + a.L.w[l1]), lane, A, T, w, bf,
                                                  st + (l1 - 1) * act_stride, stl, mkd + (l1 - 1) * mask_stride, nomask, 1.f);
     TRACE(3 + 4 * blk);
-    DropIn drop;
-    uint32_t kp[PF + 1];
-    if (MODE == FWD_RELU_DROP) {
-      // this wave's rows of block blk's keep-masks [nb][rows][hidden]
-      const int64_t left = a.rows - row0;
-      drop.keep = make_rsrc(a.drop_keep + ((int64_t)blk * a.rows + row0) * a.hidden,
-                            (uint32_t)((left < 32 ? left : 32) * a.hidden));
-      drop.lane = (uint32_t)((rl - row0) * a.hidden + 4 * h);
-    }
-    gemm_head<NT, PF, true, MODE == FWD_RELU_DROP>((const f32x4*)(a.packed + a.L.w[l2]), a.packed + a.L.b[l2], lane, w, bf,
-                                                   &drop, kp);
+    gemm_head<NT, PF, true>((const f32x4*)(a.packed + a.L.w[l2]), a.packed + a.L.b[l2], lane, w, bf);
+    uint32_t kb[mask_words(NT)];
+    if (MODE == FWD_RELU_DROP) drop_words<NT>(a.drop, drop_q0, a.rows, a.hidden, blk, rl, h, 0, NT, kb);
     if (!FAST) apply_act<NT, false>(T, a.act);
     TRACE(4 + 4 * blk);
-    if (!FAST && a.drop_keep) {
-      const uint8_t* keep = a.drop_keep + ((int64_t)blk * a.rows + rl) * a.hidden;
+    if (!FAST && a.drop.mode == DROP_BYTES) {
+      const uint8_t* keep = a.drop.keep + ((int64_t)blk * a.rows + rl) * a.hidden;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -529,9 +606,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
           T[t][r] *= kf;
         }
     }
-    gemm_hh<NT, PF, false, true, SAVE, SAVE, MODE == FWD_RELU_DROP ? IN_RELU_DROP : INR>(
-        (const f32x4*)(a.packed + a.L.w[l2]), lane, T, A, w, bf, st + l1 * act_stride, stl, mkd + l1 * mask_stride, nomask,
-        a.drop_scale, &drop, kp);
+    if (MODE == FWD_RELU_DROP)
+      gemm_hh<NT, PF, false, true, SAVE, SAVE, IN_RELU_DROP>((const f32x4*)(a.packed + a.L.w[l2]), lane, T, A, w, bf,
+                                                             st + l1 * act_stride, stl, mkd + l1 * mask_stride, kb, a.drop_scale);
+    else
+      gemm_hh<NT, PF, false, true, SAVE, SAVE, INR>((const f32x4*)(a.packed + a.L.w[l2]), lane, T, A, w, bf,
+                                                    st + l1 * act_stride, stl, mkd + l1 * mask_stride, nomask, 1.f);
     TRACE(5 + 4 * blk);
     if (blk + 1 < a.nb)
       gemm_head<NT, PF, true>((const f32x4*)(a.packed + a.L.w[l2 + 1]), a.packed + a.L.b[l2 + 1], lane, w, bf);
@@ -576,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
 // tiles, so a layer issues a quarter of the MFMAs per wave; the output slices are exchanged through LDS
 // ([tile][register quad][lane] float4: conflict-free) with one barrier pair per layer.  Same accumulation order per
 // output as the one-wave kernels (bit-identical results), same saved-activation / sign-bit layout.
-// relu networks without dropout only; anything else takes the one-wave kernels.
+// relu networks only (with or without dropout); other activations take the one-wave kernels.
 // ------------------------------------------------------------------------------------------
 // Which kernel family runs a batch of `tiles` 32-row tiles: the chip holds 1024 one-wave tiles or 256 four-wave
 // tiles per round, and a four-wave pass takes about a third of a one-wave pass (47 us against 140 us at hidden
@@ -672,16 +752,26 @@ __device__ __forceinline__ void coop_own_slice(const f32x16 (&full)[NT], int wv,
     }
 }
 
-// relu on a slice; with SAVE also the slice's rows of the saved activation and its sign-bit word
-template <int NT, bool SAVE>
-__device__ __forceinline__ void coop_relu_save(f32x16 (&slice)[Coop<NT>::TW], int t0, float* act_row, uint32_t* mask_row) {
+// relu on a slice (DROP: then inverted dropout, keep bits as drop_words lays them out); with SAVE also the slice's
+// rows of the saved activation and its sign-bit word
+template <int NT, bool SAVE, bool DROP = false>
+__device__ __forceinline__ void coop_relu_save(f32x16 (&slice)[Coop<NT>::TW], int t0, float* act_row, uint32_t* mask_row,
+                                               const uint32_t* kb = nullptr, float scale = 1.f) {
   constexpr int TW = Coop<NT>::TW;
 #pragma unroll
   for (int i = 0; i < TW; ++i) {
     uint32_t bits = 0u;
+    uint32_t keep16 = 0xffffu;
+    if (DROP) {
+      uint32_t kw[mask_words(NT)];
+#pragma unroll
+      for (int j = 0; j < mask_words(NT); ++j) kw[j] = kb[j];
+      keep16 = half_of<mask_words(NT)>(kw, t0 + i < NT ? t0 + i : 0);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       slice[i][r] = __builtin_amdgcn_fmed3f(slice[i][r], 0.f, __builtin_inff());
+      if (DROP) slice[i][r] = ((keep16 >> r) & 1u) ? scale * slice[i][r] : 0.f;
       bits |= (slice[i][r] > 0.f ? 1u : 0u) << r;
     }
     if (SAVE && t0 + i < NT) {
@@ -699,7 +789,7 @@ __device__ __forceinline__ void coop_relu_save(f32x16 (&slice)[Coop<NT>::TW], in
   }
 }
 
-template <int NT, bool SAVE>
+template <int NT, bool SAVE, bool DROP>
 __global__ __launch_bounds__(256, 1) void k_mlp_fwd_coop(FwdArgs a) {
   constexpr int TW = Coop<NT>::TW, Hp = 32 * NT, MW = mask_words(NT);
   __shared__ __attribute__((aligned(16))) float lds[Coop<NT>::LDS_BYTES / 4];
@@ -717,6 +807,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_coop(FwdArgs a) {
   uint32_t* mask_row = SAVE ? a.masks + (row * 2 + h) * MW : nullptr;       // layer 0; + l * mask_stride
 
   f32x16 A[NT], T[NT], acc[TW];
+  const uint64_t drop_q0 = (DROP && a.drop.mode == DROP_GEN) ? drop_first_call(a.drop) : 0ull;
 
   // ---- initial layer: this wave's output tiles from the (tiny) network input
   {
@@ -748,8 +839,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_coop(FwdArgs a) {
   // ---- residual blocks
   for (int blk = 0; blk < a.nb; ++blk) {
     const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
+    uint32_t kb[MW];
+    if (DROP) drop_words<NT>(a.drop, drop_q0, a.rows, a.hidden, blk, rl, h, t0, t0 + TW, kb);   // (independent of the GEMM)
     coop_gemm<NT, true, true>((const f32x4*)(a.packed + a.L.w[l1]), a.packed + a.L.b[l1], lane, t0, A, acc);
-    coop_relu_save<NT, SAVE>(acc, t0, act_row + l1 * act_stride, mask_row + l1 * mask_stride);
+    coop_relu_save<NT, SAVE, DROP>(acc, t0, act_row + l1 * act_stride, mask_row + l1 * mask_stride, kb, a.drop_scale);
     coop_exchange<NT>(lds, lane, t0, acc, T);
     // this wave's slice of the residual stream becomes the accumulator of the second GEMM
     coop_own_slice<NT>(A, wv, acc);
@@ -1161,20 +1254,32 @@ __device__ __forceinline__ void r16_own_slice(const f32x4 (&full)[Rows16<NT>::NK
 // relu on a slice; with SAVE also its columns of the saved activation and its sign bits.  Halfword t of a
 // (row, h) mask line holds bit 4 q + e for feature 32 t + 8 q + 4 h + e: this lane owns q = 2 (ot & 1) + (g >> 1)
 // of line h = g & 1, the lane 32 further the other q of the same line.
-template <int NT, bool SAVE>
-__device__ __forceinline__ void r16_relu_save(f32x4 (&slice)[Rows16<NT>::TW], int lane, int t0, float* act_row, uint32_t* mask_line) {
+// DROP: inverted dropout after the relu; kb = the keep bits of this lane's (row, h = g & 1) line (drop_words).
+template <int NT, bool SAVE, bool DROP = false>
+__device__ __forceinline__ void r16_relu_save(f32x4 (&slice)[Rows16<NT>::TW], int lane, int t0, float* act_row, uint32_t* mask_line,
+                                              const uint32_t* kb = nullptr, float scale = 1.f) {
   constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK;
   const int g = lane >> 4;
 #pragma unroll
   for (int p = 0; p < TW / 2; ++p) {
     uint32_t part = 0u;
+    uint32_t keep16 = 0xffffu;
+    if (DROP) {
+      uint32_t kw[mask_words(NT)];
+#pragma unroll
+      for (int j = 0; j < mask_words(NT); ++j) kw[j] = kb[j];
+      const int t32 = (t0 >> 1) + p;                 // the 32-wide tile the pair (2 p, 2 p + 1) of this wave's tiles forms
+      keep16 = half_of<mask_words(NT)>(kw, t32 < NT ? t32 : 0);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int i = 2 * p + j;
       uint32_t nib = 0u;
+      const uint32_t knib = keep16 >> (8 * j + 4 * (g >> 1));     // q = 2 j + (g >> 1)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         slice[i][e] = __builtin_amdgcn_fmed3f(slice[i][e], 0.f, __builtin_inff());
+        if (DROP) slice[i][e] = ((knib >> e) & 1u) ? scale * slice[i][e] : 0.f;
         nib |= (slice[i][e] > 0.f ? 1u : 0u) << e;
       }
       part |= nib << (8 * j + 4 * (g >> 1));
@@ -1187,7 +1292,7 @@ __device__ __forceinline__ void r16_relu_save(f32x4 (&slice)[Rows16<NT>::TW], in
   }
 }
 
-template <int NT, bool SAVE>
+template <int NT, bool SAVE, bool DROP>
 __global__ __launch_bounds__(256, 1) void k_mlp_fwd_rows16(FwdArgs a) {
   constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK, Hp = 32 * NT, MW = mask_words(NT);
   __shared__ __attribute__((aligned(16))) float lds[Rows16<NT>::LDS_BYTES / 4];
@@ -1205,6 +1310,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_rows16(FwdArgs a) {
   const uint32_t lo = r16_lane_off(lane);
 
   f32x4 A[NK], T[NK], acc[TW];
+  const uint64_t drop_q0 = (DROP && a.drop.mode == DROP_GEN) ? drop_first_call(a.drop) : 0ull;
 
   // ---- initial layer: this wave's output tiles from the network input
   {
@@ -1240,8 +1346,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_rows16(FwdArgs a) {
   // ---- residual blocks
   for (int blk = 0; blk < a.nb; ++blk) {
     const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
+    uint32_t kb[MW];
+    if (DROP) drop_words<NT>(a.drop, drop_q0, a.rows, a.hidden, blk, rl, g & 1, t0 >> 1, (t0 + TW) >> 1, kb);
     r16_gemm<NT, true, true>((const f32x4*)(a.packed + a.L.w[l1]), a.packed + a.L.b[l1], lane, t0, A, acc);
-    r16_relu_save<NT, SAVE>(acc, lane, t0, act_row + l1 * act_stride, mask_line + l1 * mask_stride);
+    r16_relu_save<NT, SAVE, DROP>(acc, lane, t0, act_row + l1 * act_stride, mask_line + l1 * mask_stride, kb, a.drop_scale);
     r16_exchange<NT>(lds, lane, t0, acc, T);
     r16_own_slice<NT>(A, wv, acc);                     // the residual stream is the accumulator of the second GEMM
     r16_gemm<NT, false, true>((const f32x4*)(a.packed + a.L.w[l2]), a.packed + a.L.b[l2], lane, t0, T, acc);
@@ -1586,26 +1694,28 @@ template <int NT>
 static int launch_fwd(const FwdArgs& a, hipStream_t st) {
   const int64_t waves = (a.rows + 31) / 32;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  // smallest batches: four waves per 16-row tile (relu, no dropout)
-  if (a.act == DMV_ACT_RELU && !a.drop_keep && dmv_use_rows16(a.rows)) {
+  const bool drop = a.drop.mode != DROP_OFF;
+  // smallest batches: four waves per 16-row tile (relu)
+  if (a.act == DMV_ACT_RELU && dmv_use_rows16(a.rows)) {
     const unsigned tiles = (unsigned)((a.rows + 15) / 16);
-    if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true>), dim3(tiles), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false>), dim3(tiles), dim3(256), 0, st, a);
+    if (a.acts && drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, true>), dim3(tiles), dim3(256), 0, st, a);
+    else if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, false>), dim3(tiles), dim3(256), 0, st, a);
+    else if (drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, true>), dim3(tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, false>), dim3(tiles), dim3(256), 0, st, a);
     DMV_HIP_CHECK_LAUNCH();
     return DMV_OK;
   }
-  // small batches: four waves per 32-row tile (relu, no dropout)
-  if (a.act == DMV_ACT_RELU && !a.drop_keep && dmv_use_coop(waves)) {
-    if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_coop<NT, true>), dim3((unsigned)waves), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_mlp_fwd_coop<NT, false>), dim3((unsigned)waves), dim3(256), 0, st, a);
+  // small batches: four waves per 32-row tile (relu)
+  if (a.act == DMV_ACT_RELU && dmv_use_coop(waves)) {
+    if (a.acts && drop) hipLaunchKernelGGL((k_mlp_fwd_coop<NT, true, true>), dim3((unsigned)waves), dim3(256), 0, st, a);
+    else if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_coop<NT, true, false>), dim3((unsigned)waves), dim3(256), 0, st, a);
+    else if (drop) hipLaunchKernelGGL((k_mlp_fwd_coop<NT, false, true>), dim3((unsigned)waves), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_mlp_fwd_coop<NT, false, false>), dim3((unsigned)waves), dim3(256), 0, st, a);
     DMV_HIP_CHECK_LAUNCH();
     return DMV_OK;
   }
-  // the dropout-specialised kernel reads 4 keep bytes per lane and group: rows of the masks must be dword-aligned
   const bool relu = a.act == DMV_ACT_RELU;
-  const int mode = !relu ? FWD_GENERIC
-                         : !a.drop_keep ? FWD_RELU
-                                        : ((a.hidden & 3) == 0 && ((uintptr_t)a.drop_keep & 3) == 0) ? FWD_RELU_DROP : FWD_GENERIC;
+  const int mode = !relu ? FWD_GENERIC : !drop ? FWD_RELU : FWD_RELU_DROP;
   if (a.acts) {
     if (mode == FWD_RELU) hipLaunchKernelGGL((k_mlp_fwd<NT, true, FWD_RELU>), dim3(grid), dim3(256), 0, st, a);
     else if (mode == FWD_RELU_DROP) hipLaunchKernelGGL((k_mlp_fwd<NT, true, FWD_RELU_DROP>), dim3(grid), dim3(256), 0, st, a);
@@ -1640,8 +1750,11 @@ static int launch_bwd(const BwdArgs& a, hipStream_t st) {
 template <int NT>
 static int launch_fwd_wide(const FwdArgs& a, hipStream_t st) {
   const unsigned tiles = (unsigned)((a.rows + 15) / 16);
-  if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true>), dim3(tiles), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false>), dim3(tiles), dim3(256), 0, st, a);
+  const bool drop = a.drop.mode != DROP_OFF;
+  if (a.acts && drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, true>), dim3(tiles), dim3(256), 0, st, a);
+  else if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, false>), dim3(tiles), dim3(256), 0, st, a);
+  else if (drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, true>), dim3(tiles), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, false>), dim3(tiles), dim3(256), 0, st, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
@@ -1679,9 +1792,86 @@ static int launch_bwd_wide(const BwdArgs& a, hipStream_t st) {
     default: return DMV_E_UNSUPPORTED;            \
   }
 
+// how the generated keep decisions of dropout probability p are drawn (DropSrc)
+static void drop_plan(float p, int32_t* bits, uint32_t* thresh) {
+  const double p2 = (double)p * 2.0, p256 = (double)p * 256.0;
+  if (p2 == 1.0) { *bits = 1; *thresh = 1u; }
+  else if (p256 == (double)(int64_t)p256) { *bits = 8; *thresh = (uint32_t)p256; }
+  else { *bits = 16; *thresh = (uint32_t)((double)p * 65536.0 + 0.5); }
+}
+
+extern "C" size_t dmv_mlp_dropout_rng_elements(const DmvNet* net, int64_t rows) {
+  if (dmv_check_net(net) || rows <= 0 || net->dropout_p <= 0.f) return 0;
+  int32_t bits; uint32_t thresh;
+  drop_plan(net->dropout_p, &bits, &thresh);
+  return (size_t)net->nb * (size_t)rows * 2u * (size_t)drop_calls(bits, dmv_layout(net).NT) * 4u;
+}
+
+template <int NT>
+__global__ void k_dropout_keep(DropSrc d, int nb, int64_t rows, int hidden, uint8_t* keep) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)nb * rows * 2) return;
+  const int h = (int)(i & 1);
+  const int64_t rl = (i >> 1) % rows;
+  const int blk = (int)((i >> 1) / rows);
+  uint32_t kb[mask_words(NT)];
+  drop_words<NT>(d, drop_first_call(d), rows, hidden, blk, rl, h, 0, NT, kb);
+  uint8_t* out = keep + ((int64_t)blk * rows + rl) * hidden;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int n = 32 * t + 8 * (j >> 2) + 4 * h + (j & 3);
+      if (n < hidden) out[n] = (uint8_t)((kb[t >> 1] >> (16 * (t & 1) + j)) & 1u);
+    }
+}
+
+template <int NT>
+static int launch_dropout_keep(const DropSrc& d, int nb, int64_t rows, int hidden, uint8_t* keep, hipStream_t st) {
+  const int64_t n = (int64_t)nb * rows * 2;
+  hipLaunchKernelGGL((k_dropout_keep<NT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, nb, rows, hidden, keep);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+static int drop_source(const DmvNet* net, const uint8_t* drop_keep, const DmvDropRng* gen, DropSrc* d) {
+  d->mode = DROP_OFF; d->bits = 0; d->thresh = 0; d->keep = nullptr; d->seed = 0; d->q0 = 0; d->offset_base = nullptr;
+  if (net->dropout_p <= 0.f || net->nb == 0 || (!drop_keep && !gen)) return DMV_OK;
+  if (drop_keep && gen) return DMV_E_BADARG;
+  if (drop_keep) { d->mode = DROP_BYTES; d->keep = drop_keep; return DMV_OK; }
+  if (net->act != DMV_ACT_RELU) return DMV_E_UNSUPPORTED;     // the backward of other activations reads keep bytes
+  if (gen->offset & 3) return DMV_E_BADARG;
+  d->mode = DROP_GEN;
+  drop_plan(net->dropout_p, &d->bits, &d->thresh);
+  d->seed = gen->seed; d->q0 = gen->offset >> 2; d->offset_base = gen->offset_base;
+  return DMV_OK;
+}
+
+extern "C" int dmv_mlp_dropout_keep(const DmvNet* net, int64_t rows, const DmvDropRng* gen, uint8_t* keep, void* stream) {
+  int rc = dmv_check_net(net);
+  if (rc) return rc;
+  if (!gen || !keep || rows < 0 || net->dropout_p <= 0.f) return DMV_E_BADARG;
+  if (rows == 0 || net->nb == 0) return DMV_OK;
+  DropSrc d;
+  rc = drop_source(net, nullptr, gen, &d);
+  if (rc) return rc;
+  const int NT = dmv_layout(net).NT;
+  switch (NT) {
+    case 1: return launch_dropout_keep<1>(d, net->nb, rows, net->hidden, keep, (hipStream_t)stream);
+    case 2: return launch_dropout_keep<2>(d, net->nb, rows, net->hidden, keep, (hipStream_t)stream);
+    case 3: return launch_dropout_keep<3>(d, net->nb, rows, net->hidden, keep, (hipStream_t)stream);
+    case 4: return launch_dropout_keep<4>(d, net->nb, rows, net->hidden, keep, (hipStream_t)stream);
+    case 5: return launch_dropout_keep<5>(d, net->nb, rows, net->hidden, keep, (hipStream_t)stream);
+    case 6: return launch_dropout_keep<6>(d, net->nb, rows, net->hidden, keep, (hipStream_t)stream);
+    case 7: return launch_dropout_keep<7>(d, net->nb, rows, net->hidden, keep, (hipStream_t)stream);
+    case 8: return launch_dropout_keep<8>(d, net->nb, rows, net->hidden, keep, (hipStream_t)stream);
+    default: return [&]() -> int { DMV_DISPATCH_WIDE(NT, launch_dropout_keep, d, net->nb, rows, net->hidden, keep, (hipStream_t)stream); }();
+  }
+}
+
 extern "C" int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t in_mode, int32_t D, const float* x,
                                int64_t ldx, const uint8_t* m, int64_t ldm, int64_t rows, float* y, int64_t ldy,
-                               float* saved, const uint8_t* drop_keep, void* stream) {
+                               float* saved, const uint8_t* drop_keep, const DmvDropRng* drop_rng, void* stream) {
   int rc = dmv_check_net(net);
   if (rc) return rc;
   if (!packed || !x || !y || rows < 0) return DMV_E_BADARG;
@@ -1691,8 +1881,10 @@ extern "C" int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t i
   const int want_in = (in_mode >= DMV_IN_CONCAT) ? 2 * D : D;
   if (want_in != net->in_dim || ldx < D || (m && ldm < D)) return DMV_E_BADARG;
   if (ldy < dmv_pad32(net->out_dim) || (ldy & 3) || ((uintptr_t)y & 15)) return DMV_E_BADARG;
-  if (net->dropout_p > 0.f && !drop_keep && saved) return DMV_E_BADARG;  // training-mode dropout needs its masks
+  if (net->dropout_p > 0.f && net->nb > 0 && !drop_keep && !drop_rng && saved) return DMV_E_BADARG;  // training-mode dropout needs its source
   FwdArgs a;
+  rc = drop_source(net, drop_keep, drop_rng, &a.drop);
+  if (rc) return rc;
   a.L = dmv_layout(net);
   a.packed = packed;
   a.nb = net->nb; a.in_dim = net->in_dim; a.hidden = net->hidden; a.act = net->act;
@@ -1704,9 +1896,8 @@ extern "C" int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t i
   const int64_t rp = (rows + 31) & ~(int64_t)31;
   a.acts = saved ? saved + rp * dmv_pad32(net->in_dim) : nullptr;
   a.masks = saved ? (uint32_t*)(a.acts + (2 * net->nb + 1) * rp * dmv_pad32(net->hidden)) : nullptr;
-  a.drop_keep = drop_keep;
   if (a.L.NT > 8) {
-    if (drop_keep) return DMV_E_UNSUPPORTED;
+    if (a.drop.mode != DROP_OFF && net->act != DMV_ACT_RELU) return DMV_E_UNSUPPORTED;
     DMV_DISPATCH_WIDE(a.L.NT, launch_fwd_wide, a, (hipStream_t)stream);
   }
   DMV_DISPATCH_NT(a.L.NT, launch_fwd, a, (hipStream_t)stream);
@@ -1798,7 +1989,8 @@ static int mlp_backward_impl(const DmvNet* net, const float* packed, const float
   if (rows == 0) return DMV_OK;
   if (ldgy < dmv_pad32(net->out_dim) || (ldgy & 3) || ((uintptr_t)gy & 15)) return DMV_E_BADARG;
   if (dx && (lddx < dmv_pad32(net->in_dim) || (lddx & 3) || ((uintptr_t)dx & 15))) return DMV_E_BADARG;
-  if (run_chain && net->dropout_p > 0.f && !drop_keep) return DMV_E_BADARG;
+  if (run_chain && net->dropout_p > 0.f && net->nb > 0 && !drop_keep) return DMV_E_BADARG;
+  if (drop_keep == DMV_DROP_GENERATED && net->act != DMV_ACT_RELU) return DMV_E_UNSUPPORTED;
   if (ws_bytes < dmv_mlp_backward_ws_bytes(net, rows)) return DMV_E_WORKSPACE;
   if ((uintptr_t)ws & 15) return DMV_E_BADARG;
   hipStream_t st = (hipStream_t)stream;

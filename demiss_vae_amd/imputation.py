@@ -21,7 +21,7 @@ import torch
 
 from . import _lib as L
 from . import rng
-from .mlp import PackedNet, mlp_forward, make_keep_masks, pad32
+from .mlp import PackedNet, GeneratedDropout, mlp_forward, make_keep_masks, pad32
 from .objectives import ModelDims, _u8
 
 
@@ -129,8 +129,12 @@ def _tail(dims, dec_out, row_map, X_old, M, noise, clip_min, clip_max, clip_afte
 
 
 def _keep(net, rows, training, device):
-    if not isinstance(net, PackedNet) or not training or net.dims.dropout <= 0:
+    """what a training-mode call of `net` on `rows` rows passes as drop_keep: for relu networks the kernels draw the
+    keep decisions themselves (GeneratedDropout), else a mask tensor from the same Philox stream"""
+    if not isinstance(net, PackedNet) or not training or net.dims.dropout <= 0 or net.dims.nb == 0:
         return None
+    if GeneratedDropout.supported(net):
+        return GeneratedDropout(net, rows)
     n = net.dims.nb * rows * net.dims.hidden
     keep = torch.empty(n, dtype=torch.uint8, device=device)
     seed, off = rng.next_offset(n)

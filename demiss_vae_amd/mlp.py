@@ -159,10 +159,40 @@ class PackedNet:
         return self._packed
 
 
+class GeneratedDropout:
+    """Stands where a keep-mask tensor would: the kernels draw the keep decisions of this call themselves from the
+    library's Philox stream (relu networks), so no [nb, rows, hidden] mask array is written or read.  reserve() takes
+    the counter range of one forward call; keep_bytes() writes the same decisions out as a mask tensor."""
+
+    def __init__(self, net: PackedNet, rows: int):
+        from . import rng
+        self.net, self.rows = net, rows
+        n = L.lib().dmv_mlp_dropout_rng_elements(C.byref(net.c), rows)
+        seed, off = rng.next_offset(n)
+        self.c = L.DmvDropRng(seed, off, rng.base_ptr())
+
+    @staticmethod
+    def supported(net: PackedNet) -> bool:
+        return net.dims.act == "relu"
+
+    def keep_bytes(self) -> torch.Tensor:
+        d = self.net.dims
+        keep = torch.empty((d.nb, self.rows, d.hidden), dtype=torch.uint8, device=self.net.weights[0].device)
+        L.check(L.lib().dmv_mlp_dropout_keep(C.byref(self.net.c), self.rows, C.byref(self.c), L.ptr(keep), L.stream_ptr()))
+        return keep
+
+
+def _drop_args(drop_keep):
+    """(drop_keep pointer, drop_rng pointer) of dmv_mlp_forward"""
+    if isinstance(drop_keep, GeneratedDropout):
+        return None, C.byref(drop_keep.c)
+    return L.ptr(drop_keep), None
+
+
 def mlp_forward(net: PackedNet, x: torch.Tensor, ldx: int, rows: int, *, in_mode=L.IN_PLAIN, D: Optional[int] = None,
-                m: Optional[torch.Tensor] = None, ldm: int = 0, save: bool = False,
-                drop_keep: Optional[torch.Tensor] = None):
-    """y [rows, pad32(out_dim)] (columns past out_dim are zero) and the saved-activation buffer (or None)."""
+                m: Optional[torch.Tensor] = None, ldm: int = 0, save: bool = False, drop_keep=None):
+    """y [rows, pad32(out_dim)] (columns past out_dim are zero) and the saved-activation buffer (or None).
+    drop_keep: None, a keep-mask tensor [nb, rows, hidden] uint8, or a GeneratedDropout."""
     d = net.dims
     if D is None:
         D = d.in_dim
@@ -172,8 +202,11 @@ def mlp_forward(net: PackedNet, x: torch.Tensor, ldx: int, rows: int, *, in_mode
     if save:
         saved = torch.empty(L.lib().dmv_mlp_saved_floats(C.byref(net.c), rows), dtype=torch.float32, device=dev)
     if rows:
+        if isinstance(drop_keep, GeneratedDropout):
+            assert drop_keep.net is net and drop_keep.rows == rows
+        kp, kr = _drop_args(drop_keep)
         L.check(L.lib().dmv_mlp_forward(C.byref(net.c), L.ptr(net.packed()), in_mode, D, L.ptr(x), ldx, L.ptr(m), ldm,
-                                        rows, L.ptr(y), y.shape[1], L.ptr(saved), L.ptr(drop_keep), L.stream_ptr()))
+                                        rows, L.ptr(y), y.shape[1], L.ptr(saved), kp, kr, L.stream_ptr()))
     return y, saved
 
 
@@ -194,7 +227,7 @@ def overlap_pays(rows: int) -> bool:
 
 
 def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: int, *, need_dx: bool,
-                 need_param_grads: bool, drop_keep: Optional[torch.Tensor] = None,
+                 need_param_grads: bool, drop_keep=None,
                  wgrad_stream: Optional[torch.cuda.Stream] = None, keepalive: Optional[list] = None,
                  complete: bool = False):
     """gy [rows, pad32(out_dim)] -> (dx [rows, pad32(in_dim)] or None, [gW0, gb0, gW1, ...] or None).
@@ -209,6 +242,7 @@ def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: in
     d = net.dims
     dev = gy.device
     assert gy.shape == (rows, pad32(d.out_dim)) and gy.is_contiguous()
+    keep_ptr = L.DROP_GENERATED if isinstance(drop_keep, GeneratedDropout) else L.ptr(drop_keep)
     dx = torch.empty((rows, pad32(d.in_dim)), dtype=torch.float32, device=dev) if need_dx else None
     gws = gbs = None
     gw_arr = gb_arr = None
@@ -225,7 +259,7 @@ def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: in
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
     if rows and wgrad_stream is not None and need_param_grads:
         lib = L.lib()
-        L.check(lib.dmv_mlp_backward(C.byref(net.c), L.ptr(net.packed()), L.ptr(saved), L.ptr(drop_keep),
+        L.check(lib.dmv_mlp_backward(C.byref(net.c), L.ptr(net.packed()), L.ptr(saved), keep_ptr,
                                      L.ptr(gy), gy.shape[1], rows, L.ptr(dx), dx.shape[1] if need_dx else 0,
                                      None, None, 0.0, L.ptr(ws), nbytes, L.stream_ptr()))
         wgrad_stream.wait_stream(torch.cuda.current_stream())
@@ -237,7 +271,7 @@ def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: in
                 net.on_grads_ready(net)
             complete = False
     elif rows:
-        L.check(L.lib().dmv_mlp_backward(C.byref(net.c), L.ptr(net.packed()), L.ptr(saved), L.ptr(drop_keep),
+        L.check(L.lib().dmv_mlp_backward(C.byref(net.c), L.ptr(net.packed()), L.ptr(saved), keep_ptr,
                                          L.ptr(gy), gy.shape[1], rows, L.ptr(dx), dx.shape[1] if need_dx else 0,
                                          gw_arr, gb_arr, 0.0, L.ptr(ws), nbytes, L.stream_ptr()))
     elif need_param_grads:

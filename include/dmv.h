@@ -96,11 +96,26 @@ int32_t dmv_pad32(int32_t n);
  *   y [rows][ldy], ldy >= dmv_pad32(out_dim): columns >= out_dim are written as zeros
  *   saved: NULL for inference, or dmv_mlp_saved_floats(net, rows) floats that dmv_mlp_backward reads
  *          (opaque; sized for rows rounded up to whole 32-row wave tiles)
- *   drop_keep: NULL, or nb keep-masks [nb][rows][hidden] uint8 (1 = keep), scaled by 1/(1-p) */
+ *   Dropout inside the residual blocks (ResidualBlock.forward, vgiwae/shared/neural_nets.py:67-72: kept units are
+ *   scaled by 1/(1-p)) takes its keep decisions from ONE of
+ *     drop_keep: nb keep-masks [nb][rows][hidden] uint8 (1 = keep) - recorded masks, parity runs;
+ *     drop_rng:  the library's Philox stream, drawn inside the kernels (relu networks): no mask array exists.  The
+ *                caller reserves dmv_mlp_dropout_rng_elements(net, rows) counter elements starting at `offset` (a
+ *                multiple of 4); *offset_base (nullable, device memory) is added at run time, which keeps a step
+ *                recorded in a HIP graph random.  dmv_mlp_dropout_keep writes the same decisions out as bytes.
+ *   Both NULL: no dropout (inference; with saved != NULL and dropout_p > 0 that is an error). */
+typedef struct DmvDropRng {
+  uint64_t seed;
+  uint64_t offset;
+  const uint64_t* offset_base;
+} DmvDropRng;
 size_t dmv_mlp_saved_floats(const DmvNet* net, int64_t rows);
+size_t dmv_mlp_dropout_rng_elements(const DmvNet* net, int64_t rows);
+int dmv_mlp_dropout_keep(const DmvNet* net, int64_t rows, const DmvDropRng* drop_rng, uint8_t* keep, void* stream);
 int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t in_mode, int32_t D,
                     const float* x, int64_t ldx, const uint8_t* m, int64_t ldm, int64_t rows,
-                    float* y, int64_t ldy, float* saved, const uint8_t* drop_keep, void* stream);
+                    float* y, int64_t ldy, float* saved, const uint8_t* drop_keep, const DmvDropRng* drop_rng,
+                    void* stream);
 
 /* ----- backward ---------------------------------------------------------------------------
  * Replaces autograd's backward of the same network: given gy [rows][ldgy] (ldgy >= pad32(out_dim),
@@ -108,7 +123,10 @@ int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t in_mode, int
  *   dx [rows][lddx] (lddx >= pad32(in_dim); NULL = not needed), and, when grad_w != NULL, the
  *   parameter gradients, written (beta = 0) or accumulated (beta = 1) into the 2*nb+2 tensors
  *   grad_w[l] ([out][in]) and grad_b[l].
- * ws: workspace of dmv_mlp_backward_ws_bytes(net, rows) bytes. */
+ * ws: workspace of dmv_mlp_backward_ws_bytes(net, rows) bytes.
+ * drop_keep: what the forward call was given; DMV_DROP_GENERATED when it drew its decisions itself (drop_rng; relu
+ * networks: the backward reads kept-and-active from the sign bits the forward saved). */
+#define DMV_DROP_GENERATED ((const uint8_t*)(uintptr_t)1)
 size_t dmv_mlp_backward_ws_bytes(const DmvNet* net, int64_t rows);
 int dmv_mlp_backward(const DmvNet* net, const float* packed, const float* saved,
                      const uint8_t* drop_keep, const float* gy, int64_t ldgy, int64_t rows,

@@ -277,3 +277,68 @@ def test_library_adam_matches_torch_adam(clip):
         assert sa[k].keys() == sb[k].keys() and float(sa[k]["step"]) == float(sb[k]["step"]) == 6
         torch.testing.assert_close(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
     assert torch.equal(mine[0].grad, gs[0])                                # gradients are not rescaled in memory
+
+
+@pytest.mark.parametrize("rows,hidden,nb", [(300, 64, 2), (5000, 256, 2), (20000, 256, 1), (777, 200, 3), (45, 96, 1), (200, 320, 1)])
+@pytest.mark.parametrize("p", [0.5, 0.25, 0.1])
+def test_generated_dropout_equals_its_own_masks(rows, hidden, nb, p):
+    """Dropout decisions drawn inside the kernels (no mask array): in every kernel family (16-row tiles, four-wave
+    tiles, one wave per tile, by batch size; hidden widths above 256) the outputs, input gradients and weight
+    gradients are bit-identical to a run that is handed the same decisions as explicit keep bytes
+    (dmv_mlp_dropout_keep), for dropout probabilities that draw 1, 8 and 16 bits per unit."""
+    import demiss_vae_amd as dmv
+    import gpu_util as G
+    from demiss_vae_amd import rng
+    spec = NetSpec(12, 20, nb, hidden, dropout=p)
+    params = make_params(spec, 31)
+    x_cpu, gy_cpu = make_noise(32, rows, 12), make_noise(33, rows, 20)
+
+    def run(keep_of):
+        net = G.packed_net(spec, params)
+        x = x_cpu.cuda().requires_grad_(True)
+        keep = keep_of(net)
+        y = dmv.ResidualMLPFunction.apply(net, True, keep, x, *net.params())
+        y.backward(gy_cpu.cuda())
+        return y.detach(), x.grad, [t.grad for t in net.params()], keep
+
+    rng.set_seed(99)
+    rng.next_offset(40)
+    y1, dx1, g1, gen = run(lambda net: dmv.GeneratedDropout(net, rows))
+    masks = gen.keep_bytes()
+    assert masks.shape == (nb, rows, hidden)
+    y2, dx2, g2, _ = run(lambda net: masks)
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    # the decisions themselves: keep rate 1 - p, no dependence between neighbours, blocks or rows
+    k = masks.float()
+    n = k.numel()
+    assert abs(k.mean().item() - (1 - p)) < 5 * (p * (1 - p) / n) ** 0.5 + 1e-5
+    if n > 100000:
+        c = k - k.mean()
+        for a, b in ((c[:, :, :-1], c[:, :, 1:]), (c[:, :-1], c[:, 1:])) + (((c[:-1], c[1:]),) if nb > 1 else ()):
+            assert abs((a * b).mean().item()) / (p * (1 - p)) < 6 / a.numel() ** 0.5
+    # a second reservation draws other decisions
+    assert not torch.equal(dmv.GeneratedDropout(G.packed_net(spec, params), rows).keep_bytes(), masks)
+
+
+def test_explicit_masks_in_every_kernel_family_match_the_oracle():
+    """recorded keep masks through the 16-row, four-wave and one-wave kernels against the float64 oracle"""
+    import demiss_vae_amd as dmv
+    import gpu_util as G
+    spec = NetSpec(10, 6, 2, 128, dropout=0.5)
+    params = make_params(spec, 41)
+    for rows in (100, 6000, 40000):
+        x_cpu, gy_cpu = make_noise(42, rows, 10), make_noise(43, rows, 6)
+        ok = _rows_clear_of_relu_kinks(spec, params, x_cpu)
+        masks = gu.dropout_masks(44, spec, (rows,))
+        net = G.packed_net(spec, params)
+        x = x_cpu.cuda().requires_grad_(True)
+        y = dmv.ResidualMLPFunction.apply(net, True, G.keep_to_dev(masks), x, *net.params())
+        y.backward(gy_cpu.cuda())
+        p64 = {k: v.double() for k, v in params.items()}
+        x64 = x_cpu.double().requires_grad_(True)
+        y64 = core.mlp_forward(p64, x64, spec, masks)
+        y64.backward(gy_cpu.double())
+        torch.testing.assert_close(y.detach().cpu().double()[ok], y64.detach()[ok], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(x.grad.cpu().double()[ok], x64.grad[ok], rtol=1e-4, atol=1e-5)

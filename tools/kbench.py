@@ -34,7 +34,7 @@ packed = net.packed()
 
 def fwd(sv):
     L.check(lib.dmv_mlp_forward(C.byref(net.c), L.ptr(packed), 0, spec.in_dim, L.ptr(x), spec.in_dim, None, 0, rows,
-                                L.ptr(y), y.shape[1], L.ptr(sv), None, st))
+                                L.ptr(y), y.shape[1], L.ptr(sv), None, None, st))
 
 
 def bwd(with_w):
