@@ -495,6 +495,7 @@ struct FwdArgs {
   const uint8_t* m;
   int64_t ldm;
   int64_t rows;
+  int64_t row_begin, row_end;   // this launch covers rows [row_begin, row_end) (row_begin a multiple of 32)
   float* y;
   int64_t ldy;
   float* xs;     // saved first-layer input [rows][32*T_in] (nullable)
@@ -543,8 +544,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
   constexpr bool FAST = MODE != FWD_GENERIC;
   constexpr int PF = 1;
   const int lane = threadIdx.x & 63;
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 32;
-  if (row0 >= a.rows) return;
+  const int64_t row0 = a.row_begin + ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 32;
+  if (row0 >= a.row_end) return;
   const int m = lane & 31, h = lane >> 5;
   const int64_t row = row0 + m;
   const bool live = row < a.rows;
@@ -658,15 +659,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
 // output as the one-wave kernels (bit-identical results), same saved-activation / sign-bit layout.
 // relu networks only (with or without dropout); other activations take the one-wave kernels.
 // ------------------------------------------------------------------------------------------
-// Which kernel family runs a batch of `tiles` 32-row tiles: the chip holds 1024 one-wave tiles or 256 four-wave
-// tiles per round, and a four-wave pass takes about a third of a one-wave pass (47 us against 140 us at hidden
-// 256), so the four-wave kernels win while ceil(tiles / 256) * 0.34 < ceil(tiles / 1024): small batches, and batches
-// just past a multiple of 1024 tiles whose last one-wave round would run almost empty.
-static inline bool dmv_use_coop(int64_t tiles) {
-  const int64_t coop_rounds = (tiles + 255) / 256, one_rounds = (tiles + 1023) / 1024;
-  return coop_rounds * 34 < one_rounds * 100;
-}
-
+// (plan_row_segments decides which rows of a batch these kernels take)
 template <int NT>
 struct Coop {
   static constexpr int TW = (NT + 3) / 4;
@@ -796,7 +789,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_coop(FwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t0 = wv * TW;
-  const int64_t row0 = (int64_t)blockIdx.x * 32;
+  const int64_t row0 = a.row_begin + (int64_t)blockIdx.x * 32;
   const int m = lane & 31, h = lane >> 5;
   const int64_t row = row0 + m;
   const bool live = row < a.rows;
@@ -889,6 +882,7 @@ struct BwdArgs {
   const float* gy;
   int64_t ldgy;
   int64_t rows;
+  int64_t row_begin, row_end;   // this launch covers rows [row_begin, row_end) (row_begin a multiple of 32)
   float* dacts;  // [(2nb+1)][rows][Hp]: gradient w.r.t. each hidden layer's pre-activation output
   float* dx;     // nullable, [rows][lddx]
   int64_t lddx;
@@ -926,8 +920,8 @@ template <int NT, bool RELU>
 __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
   constexpr int PF = 1;
   const int lane = threadIdx.x & 63;
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 32;
-  if (row0 >= a.rows) return;
+  const int64_t row0 = a.row_begin + ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 32;
+  if (row0 >= a.row_end) return;
   const int m = lane & 31, h = lane >> 5;
   const int64_t row = row0 + m;
   const bool live = row < a.rows;
@@ -1062,7 +1056,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_coop(BwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t0 = wv * TW;
-  const int64_t row0 = (int64_t)blockIdx.x * 32;
+  const int64_t row0 = a.row_begin + (int64_t)blockIdx.x * 32;
   const int m = lane & 31, h = lane >> 5;
   const int64_t row = row0 + m;
   const bool live = row < a.rows;
@@ -1300,7 +1294,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_rows16(FwdArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t0 = wv * TW;
   const int m = lane & 15, g = lane >> 4;
-  const int64_t row = (int64_t)blockIdx.x * 16 + m;
+  const int64_t row = a.row_begin + (int64_t)blockIdx.x * 16 + m;
   const bool live = row < a.rows;
   const int64_t rl = live ? row : a.rows - 1;
   const int64_t rp = (a.rows + 31) & ~(int64_t)31;
@@ -1396,7 +1390,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_rows16(BwdArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t0 = wv * TW;
   const int m = lane & 15, g = lane >> 4;
-  const int64_t row = (int64_t)blockIdx.x * 16 + m;
+  const int64_t row = a.row_begin + (int64_t)blockIdx.x * 16 + m;
   const bool live = row < a.rows;
   const int64_t rl = live ? row : a.rows - 1;
   const int64_t rp = (a.rows + 31) & ~(int64_t)31;
@@ -1690,65 +1684,105 @@ extern "C" size_t dmv_mlp_saved_floats(const DmvNet* net, int64_t rows) {
   return (size_t)(rp * Ip + (2 * net->nb + 1) * rp * (Hp + mw));
 }
 
-template <int NT>
-static int launch_fwd(const FwdArgs& a, hipStream_t st) {
-  const int64_t waves = (a.rows + 31) / 32;
-  const unsigned grid = (unsigned)((waves + 3) / 4);
-  const bool drop = a.drop.mode != DROP_OFF;
-  // smallest batches: four waves per 16-row tile (relu)
-  if (a.act == DMV_ACT_RELU && dmv_use_rows16(a.rows)) {
-    const unsigned tiles = (unsigned)((a.rows + 15) / 16);
-    if (a.acts && drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, true>), dim3(tiles), dim3(256), 0, st, a);
-    else if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, false>), dim3(tiles), dim3(256), 0, st, a);
-    else if (drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, true>), dim3(tiles), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, false>), dim3(tiles), dim3(256), 0, st, a);
-    DMV_HIP_CHECK_LAUNCH();
-    return DMV_OK;
-  }
-  // small batches: four waves per 32-row tile (relu)
-  if (a.act == DMV_ACT_RELU && dmv_use_coop(waves)) {
-    if (a.acts && drop) hipLaunchKernelGGL((k_mlp_fwd_coop<NT, true, true>), dim3((unsigned)waves), dim3(256), 0, st, a);
-    else if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_coop<NT, true, false>), dim3((unsigned)waves), dim3(256), 0, st, a);
-    else if (drop) hipLaunchKernelGGL((k_mlp_fwd_coop<NT, false, true>), dim3((unsigned)waves), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_mlp_fwd_coop<NT, false, false>), dim3((unsigned)waves), dim3(256), 0, st, a);
-    DMV_HIP_CHECK_LAUNCH();
-    return DMV_OK;
-  }
-  const bool relu = a.act == DMV_ACT_RELU;
-  const int mode = !relu ? FWD_GENERIC : !drop ? FWD_RELU : FWD_RELU_DROP;
-  if (a.acts) {
-    if (mode == FWD_RELU) hipLaunchKernelGGL((k_mlp_fwd<NT, true, FWD_RELU>), dim3(grid), dim3(256), 0, st, a);
-    else if (mode == FWD_RELU_DROP) hipLaunchKernelGGL((k_mlp_fwd<NT, true, FWD_RELU_DROP>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_mlp_fwd<NT, true, FWD_GENERIC>), dim3(grid), dim3(256), 0, st, a);
+// How a relu pass over `rows` rows is cut into launches.  The chip holds 1024 one-wave tiles (32 rows), 256
+// four-wave tiles or 256 sixteen-row tiles per round, and a round of those takes about 140 / 47 / 28 us at
+// hidden 256.  Whole rounds of 1024 tiles go to the one-wave kernels; what is left takes whichever is shortest: one
+// more one-wave round, rounds of four-wave tiles, or four-wave rounds with a last partial round of sixteen-row tiles.
+enum { FAM_ONE = 0, FAM_COOP = 1, FAM_ROWS16 = 2 };
+struct RowSeg { int family; int64_t begin, end; };
+
+static int plan_row_segments(int64_t rows, RowSeg (&seg)[3]) {
+  int n = 0;
+  if (dmv_use_rows16(rows)) { seg[n++] = RowSeg{FAM_ROWS16, 0, rows}; return n; }
+  const int64_t tiles = (rows + 31) / 32;
+  const int64_t full = (tiles / 1024) * 1024;
+  if (full) seg[n++] = RowSeg{FAM_ONE, 0, std::min<int64_t>(rows, full * 32)};
+  const int64_t rest = tiles - full;
+  if (rest == 0) return n;
+  const int64_t b = full * 32;
+  const int64_t coop_rounds = (rest + 255) / 256, tail = rest % 256;
+  const int64_t cost_one = 140, cost_coop = coop_rounds * 47;
+  const int64_t cost_mixed = (tail > 0 && tail <= 128) ? (rest / 256) * 47 + 28 : INT64_MAX;
+  if (cost_one <= cost_coop && cost_one <= cost_mixed) {
+    if (n && seg[n - 1].family == FAM_ONE) seg[n - 1].end = rows;
+    else seg[n++] = RowSeg{FAM_ONE, b, rows};
+  } else if (cost_coop <= cost_mixed) {
+    seg[n++] = RowSeg{FAM_COOP, b, rows};
   } else {
-    if (mode == FWD_RELU) hipLaunchKernelGGL((k_mlp_fwd<NT, false, FWD_RELU>), dim3(grid), dim3(256), 0, st, a);
-    else if (mode == FWD_RELU_DROP) hipLaunchKernelGGL((k_mlp_fwd<NT, false, FWD_RELU_DROP>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_mlp_fwd<NT, false, FWD_GENERIC>), dim3(grid), dim3(256), 0, st, a);
+    const int64_t mid = b + (rest / 256) * 256 * 32;
+    if (mid > b) seg[n++] = RowSeg{FAM_COOP, b, mid};
+    seg[n++] = RowSeg{FAM_ROWS16, mid, rows};
   }
-  DMV_HIP_CHECK_LAUNCH();
+  return n;
+}
+
+template <int NT, bool SAVE, bool DROP>
+static void launch_fwd_family(int family, const FwdArgs& a, hipStream_t st) {
+  const int64_t n = a.row_end - a.row_begin;
+  if (family == FAM_ROWS16)
+    hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, SAVE, DROP>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, a);
+  else if (family == FAM_COOP)
+    hipLaunchKernelGGL((k_mlp_fwd_coop<NT, SAVE, DROP>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_mlp_fwd<NT, SAVE, DROP ? FWD_RELU_DROP : FWD_RELU>), dim3((unsigned)((n + 127) / 128)), dim3(256), 0, st, a);
+}
+
+template <int NT>
+static int launch_fwd(const FwdArgs& a0, hipStream_t st) {
+  FwdArgs a = a0;
+  const bool drop = a.drop.mode != DROP_OFF;
+  if (a.act != DMV_ACT_RELU) {
+    a.row_begin = 0; a.row_end = a.rows;
+    const unsigned grid = (unsigned)((a.rows + 127) / 128);
+    if (a.acts) hipLaunchKernelGGL((k_mlp_fwd<NT, true, FWD_GENERIC>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_mlp_fwd<NT, false, FWD_GENERIC>), dim3(grid), dim3(256), 0, st, a);
+    DMV_HIP_CHECK_LAUNCH();
+    return DMV_OK;
+  }
+  RowSeg seg[3];
+  const int n = plan_row_segments(a.rows, seg);
+  for (int i = 0; i < n; ++i) {
+    a.row_begin = seg[i].begin; a.row_end = seg[i].end;
+    if (a.acts && drop) launch_fwd_family<NT, true, true>(seg[i].family, a, st);
+    else if (a.acts) launch_fwd_family<NT, true, false>(seg[i].family, a, st);
+    else if (drop) launch_fwd_family<NT, false, true>(seg[i].family, a, st);
+    else launch_fwd_family<NT, false, false>(seg[i].family, a, st);
+    DMV_HIP_CHECK_LAUNCH();
+  }
   return DMV_OK;
 }
 
 template <int NT>
-static int launch_bwd(const BwdArgs& a, hipStream_t st) {
-  const int64_t waves = (a.rows + 31) / 32;
-  const unsigned grid = (unsigned)((waves + 3) / 4);
-  if (a.act == DMV_ACT_RELU && dmv_use_rows16(a.rows))
-    hipLaunchKernelGGL((k_mlp_bwd_rows16<NT>), dim3((unsigned)((a.rows + 15) / 16)), dim3(256), 0, st, a);
-  else if (a.act == DMV_ACT_RELU && dmv_use_coop(waves))
-    hipLaunchKernelGGL((k_mlp_bwd_coop<NT>), dim3((unsigned)waves), dim3(256), 0, st, a);
-  else if (a.act == DMV_ACT_RELU)
-    hipLaunchKernelGGL((k_mlp_bwd<NT, true>), dim3(grid), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((k_mlp_bwd<NT, false>), dim3(grid), dim3(256), 0, st, a);
-  DMV_HIP_CHECK_LAUNCH();
+static int launch_bwd(const BwdArgs& a0, hipStream_t st) {
+  BwdArgs a = a0;
+  if (a.act != DMV_ACT_RELU) {
+    a.row_begin = 0; a.row_end = a.rows;
+    hipLaunchKernelGGL((k_mlp_bwd<NT, false>), dim3((unsigned)((a.rows + 127) / 128)), dim3(256), 0, st, a);
+    DMV_HIP_CHECK_LAUNCH();
+    return DMV_OK;
+  }
+  RowSeg seg[3];
+  const int n = plan_row_segments(a.rows, seg);
+  for (int i = 0; i < n; ++i) {
+    a.row_begin = seg[i].begin; a.row_end = seg[i].end;
+    const int64_t m = a.row_end - a.row_begin;
+    if (seg[i].family == FAM_ROWS16)
+      hipLaunchKernelGGL((k_mlp_bwd_rows16<NT>), dim3((unsigned)((m + 15) / 16)), dim3(256), 0, st, a);
+    else if (seg[i].family == FAM_COOP)
+      hipLaunchKernelGGL((k_mlp_bwd_coop<NT>), dim3((unsigned)((m + 31) / 32)), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_mlp_bwd<NT, true>), dim3((unsigned)((m + 127) / 128)), dim3(256), 0, st, a);
+    DMV_HIP_CHECK_LAUNCH();
+  }
   return DMV_OK;
 }
 
 // hidden widths above 256 (9..16 tiles of 32): two activation sets no longer fit one wave's registers as 32-row
 // tiles; the 16-row kernels hold them (a quarter of Hp floats per lane and set) at every batch size
 template <int NT>
-static int launch_fwd_wide(const FwdArgs& a, hipStream_t st) {
+static int launch_fwd_wide(const FwdArgs& a0, hipStream_t st) {
+  FwdArgs a = a0;
+  a.row_begin = 0; a.row_end = a.rows;
   const unsigned tiles = (unsigned)((a.rows + 15) / 16);
   const bool drop = a.drop.mode != DROP_OFF;
   if (a.acts && drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, true>), dim3(tiles), dim3(256), 0, st, a);
@@ -1760,7 +1794,9 @@ static int launch_fwd_wide(const FwdArgs& a, hipStream_t st) {
 }
 
 template <int NT>
-static int launch_bwd_wide(const BwdArgs& a, hipStream_t st) {
+static int launch_bwd_wide(const BwdArgs& a0, hipStream_t st) {
+  BwdArgs a = a0;
+  a.row_begin = 0; a.row_end = a.rows;
   hipLaunchKernelGGL((k_mlp_bwd_rows16<NT>), dim3((unsigned)((a.rows + 15) / 16)), dim3(256), 0, st, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;

@@ -73,9 +73,9 @@ def test_mlp_empty_and_errors():
 
 
 def test_small_batch_and_large_batch_kernels_agree_bitwise():
-    """Up to 512 row tiles a tile is shared by the four waves of a workgroup; beyond, one wave owns a tile for the
-    whole network.  Both accumulate every output in the same order: identical bits for outputs and input gradients
-    (the golden cases above run the small-batch kernels; this ties the large-batch ones to them)."""
+    """A whole round of 1024 row tiles runs with one wave per tile for the whole network; a quarter of it (256 tiles)
+    with a tile shared by the four waves of a workgroup.  Both accumulate every output in the same order: identical
+    bits for outputs and input gradients."""
     import demiss_vae_amd as dmv
     from demiss_vae_amd.mlp import ResidualMLPFunction
     from oracle.recipes import NetSpec, make_params
@@ -83,11 +83,11 @@ def test_small_batch_and_large_batch_kernels_agree_bitwise():
     torch.manual_seed(0)
     for spec in (NetSpec(16, 16, 2, 256), NetSpec(5, 4, 3, 200)):
         p = make_params(spec, 11)
-        rows = 512 * 32 + 700                     # above the small-batch limit, ragged last tile
+        rows = 1024 * 32                          # one full round of one-wave tiles; a quarter of it: four-wave tiles
         x = torch.randn(rows, spec.in_dim, device="cuda")
         gy = torch.randn(rows, spec.out_dim, device="cuda")
         outs = []
-        for chunks in (1, 3):
+        for chunks in (1, 4):
             net = G.packed_net(spec, p)
             ys, dxs = [], []
             for xc, gc in zip(x.chunk(chunks), gy.chunk(chunks)):
@@ -342,3 +342,37 @@ def test_explicit_masks_in_every_kernel_family_match_the_oracle():
         y64.backward(gy_cpu.double())
         torch.testing.assert_close(y.detach().cpu().double()[ok], y64.detach()[ok], rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(x.grad.cpu().double()[ok], x64.grad[ok], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows", [8192 + 4096 - 5, 32768 + 300, 32768 + 8192 + 1000, 2 * 32768 + 20000])
+def test_batches_cut_into_launches_of_different_kernel_families(rows):
+    """Whole rounds of 1024 row tiles run one wave per tile, the remainder on four-wave tiles, a last partial round on
+    16-row tiles: every row of such a batch equals the same row computed alone in a small batch (bitwise for the
+    first two families, to rounding on the 16-row tiles), and the weight gradients equal the float64 oracle's."""
+    import demiss_vae_amd as dmv
+    import gpu_util as G
+    spec = NetSpec(16, 16, 2, 256)
+    params = make_params(spec, 51)
+    x_cpu, gy_cpu = make_noise(52, rows, 16), make_noise(53, rows, 16)
+    net = G.packed_net(spec, params)
+    x = x_cpu.cuda().requires_grad_(True)
+    y = dmv.ResidualMLPFunction.apply(net, True, None, x, *net.params())
+    y.backward(gy_cpu.cuda())
+    # the same rows in chunks of one four-wave round (256 tiles)
+    ys, dxs = [], []
+    net2 = G.packed_net(spec, params)
+    for lo in range(0, rows, 8192):
+        xc = x_cpu[lo:lo + 8192].cuda().requires_grad_(True)
+        yc = dmv.ResidualMLPFunction.apply(net2, True, None, xc, *net2.params())
+        yc.backward(gy_cpu[lo:lo + 8192].cuda())
+        ys.append(yc.detach())
+        dxs.append(xc.grad)
+    y2, dx2 = torch.cat(ys), torch.cat(dxs)
+    ok = _rows_clear_of_relu_kinks(spec, params, x_cpu).cuda()
+    torch.testing.assert_close(y.detach()[ok], y2[ok], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(x.grad[ok], dx2[ok], rtol=1e-4, atol=1e-5)
+    whole = (rows // 32768) * 32768
+    if whole:
+        assert torch.equal(y.detach()[:whole], y2[:whole]) and torch.equal(x.grad[:whole], dx2[:whole])
+    for a, b in zip(net.params(), net2.params()):
+        torch.testing.assert_close(a.grad, b.grad, rtol=2e-4, atol=2e-4 * float(b.grad.abs().max()))

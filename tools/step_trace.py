@@ -21,7 +21,7 @@ K = 5
 if what in ("hepmass", "miniboone"):
     # MissSIWAE (stratified mixture of 5, one sample per component): configs/uci_hepmass, configs/uci_miniboone shapes
     from demiss_vae_amd import synth
-    from demiss_vae_amd.mlp import make_keep_masks
+    from demiss_vae_amd.imputation import _keep as keep_for
     B, D, Zd, es, ds, p = (4096, 21, 16, (42, 165, 2, 256), (16, 42, 2, 256), 0.0) if what == "hepmass" else \
         (8192, 43, 32, (86, 325, 5, 256), (32, 86, 2, 256), 0.5)
     enc = synth.packed_net(synth.NetShape(*es, dropout=p), 1, "cuda")
@@ -31,7 +31,7 @@ if what in ("hepmass", "miniboone"):
     opt = Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True)
 
     def step():
-        ek, dk = make_keep_masks(enc.dims, B, "cuda"), make_keep_masks(dec.dims, B * 5, "cuda")
+        ek, dk = keep_for(enc, B, True, "cuda"), keep_for(dec, B * 5, True, "cuda")      # what the model classes pass
         _, _, loss = dmv.estimate_multiple_iwelbo(dims, enc, dec, X, M, num_importance_samples_for_each_component=1, STL=True,
                                                   enc_keep=ek, dec_keep=dk, with_loss=True)
         opt.zero_grad(set_to_none=True)
