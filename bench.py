@@ -236,6 +236,7 @@ def main():
     import demiss_vae_amd as dmv
     from demiss_vae_amd import rng
     from demiss_vae_amd.parallel import all_reduce, allreduce_grads, overlap_grad_exchange
+    from demiss_vae_amd.run import _unit_gradient as unit_gradient
     rng.set_seed(20220118 + rank)
 
     B, K = args.batch, 5
@@ -252,7 +253,7 @@ def main():
         opt = torch.optim.Adam(groups, fused=True)
     else:                       # the library's clip + AMSGrad step (three launches; what the model classes use)
         from demiss_vae_amd.optim import Adam
-        opt = Adam(groups)
+        opt = Adam(groups).attach_images((enc, dec))        # as the trainer sets it up: the step keeps the MFMA images current
 
     def barrier():
         if dist:
@@ -262,7 +263,7 @@ def main():
         # the loss (minus the bound) comes out of the library with the bound, as in the model classes' training_step
         _, _, loss = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=1, num_importance_samples=K, STL=True,
                                          with_loss=True)
-        loss.backward()
+        loss.backward(unit_gradient(loss))      # the trainer's cached root gradient: no ones-fill per step
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -322,13 +323,13 @@ def main():
             dims2, enc2, dec2, X2, M2 = d2[0], d2[1], d2[2], d2[5], d2[6]
             p2 = enc2.params() + dec2.params()
             from demiss_vae_amd.optim import Adam as LibAdam
-            opt2 = LibAdam(p2, lr=1e-3, amsgrad=True)
+            opt2 = LibAdam(p2, lr=1e-3, amsgrad=True).attach_images((enc2, dec2))
 
             def step512():
                 opt2.zero_grad(set_to_none=True)
                 _, _, loss = dmv.estimate_iwelbo(dims2, enc2, dec2, X2, M2, num_latent_samples=1, num_importance_samples=K,
                                                  STL=True, with_loss=True)
-                loss.backward()
+                loss.backward(unit_gradient(loss))      # the trainer's cached root gradient: no ones-fill per step
                 opt2.clip_on_next_step(5.0)
                 opt2.step()
 

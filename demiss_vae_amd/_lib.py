@@ -54,6 +54,11 @@ class DmvObjFwd(C.Structure):
                 ("neg_mean_out", C.c_void_p)]
 
 
+class DmvPackMap(C.Structure):
+    _fields_ = [("image", C.c_void_p), ("fwd_off", C.c_int64), ("tr_off", C.c_int64), ("N", C.c_int32), ("K", C.c_int32),
+                ("S", C.c_int32), ("Sn", C.c_int32), ("is_bias", C.c_int32), ("reserved", C.c_int32)]
+
+
 class DmvAdamGroup(C.Structure):
     _fields_ = [("lr", C.c_void_p), ("step", C.c_void_p), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
 
@@ -98,8 +103,9 @@ SIGNATURES = {
     "dmv_grid_marginal_ws_floats": (_SZ, [_I64, _I32]),
     "dmv_grid_marginal": (C.c_int, [_I32, _I32, _I64, _P, _I64, _P, _I32, _P, _P, _P, _P, _P, _P]),
     "dmv_opt_ws_floats": (_SZ, [_I32, _P]),
-    "dmv_opt_adam_step": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _SZ, _P, _P]),
-    "dmv_opt_adam_step_static": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _P]),
+    "dmv_opt_adam_step": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _SZ, _P, _P, _P]),
+    "dmv_opt_adam_step_static": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _P, _P]),
+    "dmv_mlp_pack_map": (C.c_int, [C.POINTER(DmvNet), _P, C.POINTER(DmvPackMap), C.POINTER(DmvPackMap)]),
     "dmv_grid_divergences": (C.c_int, [_I32, _I32, _I32, _I64, _P, _P, _P, _F, _I32, _P, _P, _P, _I32, _P, _P, _P, _P]),
     "dmv_lse_update": (C.c_int, [_I32, _I64, _P, _I32, _P, _P, _P]),
     "dmv_rows_gather": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),

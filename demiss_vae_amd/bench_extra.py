@@ -6,6 +6,7 @@ import torch
 
 from . import estimate_iwelbo, estimate_multiple_iwelbo, mvb2_objectives, ModelDims, NetDims, PackedNet  # noqa: F401
 from .imputation import _keep as keep_for
+from .run import _unit_gradient as unit_gradient
 from . import imputation as imp
 from . import parallel as P
 from .optim import Adam
@@ -38,7 +39,7 @@ def missiwae_step(device, name, B, D, Zd, enc_shape, dec_shape, C=5, dropout=0.0
     dims = ModelDims(D=D, Zd=Zd, q_dist="stratified_with_eps", C=C, encoder_use_mis_mask=True)
     X, M = make_batch(3, B, D)
     X, M = X.to(device), M.to(device)
-    opt = Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True)
+    opt = Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True).attach_images((enc, dec))
 
     def step():
         ek = keep_for(enc, B, True, device)           # as the model classes get them: drawn inside the kernels
@@ -46,7 +47,7 @@ def missiwae_step(device, name, B, D, Zd, enc_shape, dec_shape, C=5, dropout=0.0
         _, _, loss = estimate_multiple_iwelbo(dims, enc, dec, X, M, num_importance_samples_for_each_component=1, STL=True,
                                               enc_keep=ek, dec_keep=dk, with_loss=True)
         opt.zero_grad(set_to_none=True)
-        loss.backward()
+        loss.backward(unit_gradient(loss))      # the trainer's cached root gradient: no ones-fill per step
         opt.step()
 
     t = _sync_time(step, 20, 5)
@@ -75,7 +76,7 @@ def iwae_step(device, B, I=5, *, name="UCI-gas", D=8, Zd=16, enc_shape=(16, 32, 
     def step():
         _, _, loss = estimate_iwelbo(dims, enc, dec, X, M, num_importance_samples=I, STL=True, with_loss=True)
         opt.zero_grad(set_to_none=True)
-        loss.backward()
+        loss.backward(unit_gradient(loss))      # the trainer's cached root gradient: no ones-fill per step
         opt.step()
 
     if graph:       # the whole step recorded once and replayed (library noise stays fresh through its device counter)

@@ -1676,6 +1676,24 @@ extern "C" int dmv_mlp_pack(const DmvNet* net, const float* const* weights, cons
   return DMV_OK;
 }
 
+extern "C" int dmv_mlp_pack_map(const DmvNet* net, float* packed, DmvPackMap* weights, DmvPackMap* biases) {
+  int rc = dmv_check_net(net);
+  if (rc) return rc;
+  if (!packed || !weights || !biases) return DMV_E_BADARG;
+  const DmvLayout L = dmv_layout(net);
+  for (int l = 0; l < L.nl; ++l) {
+    DmvPackMap w;
+    w.image = packed; w.fwd_off = L.w[l]; w.tr_off = L.wt[l];
+    w.N = L.N[l]; w.K = L.K[l]; w.S = L.S[l]; w.Sn = L.Sn[l];
+    w.is_bias = 0; w.reserved = 0;
+    weights[l] = w;
+    DmvPackMap b = w;
+    b.fwd_off = L.b[l]; b.tr_off = 0; b.K = 1; b.is_bias = 1;
+    biases[l] = b;
+  }
+  return DMV_OK;
+}
+
 extern "C" size_t dmv_mlp_saved_floats(const DmvNet* net, int64_t rows) {
   if (dmv_check_net(net) != DMV_OK || rows < 0) return 0;
   const int64_t Hp = dmv_pad32(net->hidden), Ip = dmv_pad32(net->in_dim);
@@ -1944,13 +1962,14 @@ extern "C" int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t i
 // one row slice; slices are sized so that every wave issues about the same number of MFMAs (a layer whose
 // blocks hold c of bt^2 tiles gets slices bt^2/c times longer), and the wave count aims at one full round of the
 // 1024 wave slots (256 CUs x 4 SIMDs, one wave per SIMD).  Long batches take 4x4 blocks (each operand row feeds
-// four MFMAs).  Up to 16384 rows the blocks are 2x2: four times as many blocks fill the chip with a quarter of the
+// four MFMAs).  Up to 16384 rows (24576 at hidden 256) the blocks are 2x2: four times as many blocks fill the chip with a quarter of the
 // row slices, and every slice costs one more copy of all gradients written to the slab and read back by the
 // reduction (at 2560 rows and hidden 256: 15 slices instead of 40, 33 MB instead of 88 MB each way; 30 us instead
-// of 47 us for both kernels).  Measured crossover: 12 k rows at hidden 200, 28 k rows at hidden 256.
+// of 47 us for both kernels).  Measured crossover: 12 k rows at hidden 200; at hidden 256 the 2x2 blocks still win at
+// 20480 rows (127 us against 149 us) and lose at 28672 (196 us against 186 us).
 static int64_t wgrad_plan(const DmvNet* net, int64_t rows, WgradArgs* wa, ReduceArgs* ra) {
   DmvLayout L = dmv_layout(net);
-  const int bt = rows <= 16384 ? 2 : 4, full = bt * bt;
+  const int bt = rows <= (L.NT >= 8 ? 24576 : 16384) ? 2 : 4, full = bt * bt;
   double weight = 0.0;   // waves per unit of slices, in units of a full block
   int cost[DMV_MAX_LAYERS];
   for (int l = 0; l < L.nl; ++l) {

@@ -1,15 +1,20 @@
 // Optimiser step of the training loop: global gradient-norm clipping + Adam / AMSGrad over all parameter tensors of
-// both networks in three launches (vgiwae/models/vae.py:349-390: torch.optim.Adam with two parameter groups, then
+// both networks in two launches (vgiwae/models/vae.py:349-390: torch.optim.Adam with two parameter groups, then
 // clip_grad_norm_ over all parameters; torch needs about a dozen launches for the same work, and its multi-tensor
 // Adam runs a 547 k-parameter model on ten workgroups).
 //
 //   k_opt_sumsq   partial sums of g^2 over fixed 1024-element quarters of 4096-element chunks (one workgroup per
-//                 quarter: the summation order does not depend on the launch geometry)
-//   k_opt_prep    one workgroup: total norm -> clip coefficient min(1, max_norm / (norm + 1e-6)) (torch's
-//                 clip_grad_norm_), step counters += 1, bias corrections per group
+//                 quarter: the summation order does not depend on the launch geometry); its first workgroup also
+//                 advances the groups' step counters.  Without clipping k_opt_tick (one thread) advances them.
 //   k_opt_apply   one workgroup per quarter chunk (a 547 k-parameter model fills the chip only at this grain;
-//                 16-byte accesses where the tensors allow):  g' = coef g;  m = m + (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;
-//                 [vmax = max(vmax, v)];  p -= (lr / (1 - b1^t)) m / (sqrt(v or vmax) / sqrt(1 - b2^t) + eps)
+//                 16-byte accesses where the tensors allow).  Every workgroup first sums the partials in the same
+//                 order (a few hundred floats from L2) -> total norm -> clip coefficient min(1, max_norm / (norm +
+//                 1e-6)) (torch's clip_grad_norm_) and forms its group's bias corrections from the step counter, then
+//                 g' = coef g;  m = m + (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;  [vmax = max(vmax, v)];
+//                 p -= (lr / (1 - b1^t)) m / (sqrt(v or vmax) / sqrt(1 - b2^t) + eps).
+//                 With a pack map it also writes each new parameter value to its places in the owning network's MFMA
+//                 fragment image (forward fragment, transposed fragment or bias fragment: the layout of k_pack in
+//                 dmv_mlp.hip), so the next forward pass needs no packing launch.
 // Tensor tables travel by value in the kernel arguments (like torch's multi-tensor kernels), so a recorded step
 // replays against the same gradient addresses without host copies.  Learning rates and step counters are read from
 // device memory: schedulers and replays change them without re-recording.
@@ -45,13 +50,6 @@ struct OptGroups {
   double beta1d[kMaxG], beta2d[kMaxG];
 };
 
-// state block at the head of the workspace
-struct OptState {
-  float coef;
-  float bc1[kMaxG];
-  float bc2_sqrt[kMaxG];
-};
-
 __device__ inline int find_tensor(const OptTable& t, int chunk) {
   int lo = 0, hi = t.n - 1;
   while (lo < hi) {
@@ -73,7 +71,11 @@ __device__ inline float block_sum(float x, float* red) {
   return s;   // valid in thread 0
 }
 
-__global__ void k_opt_sumsq(OptTable t, float* __restrict__ partial) {
+__device__ inline void tick(const OptGroups& gr) {
+  for (int g = 0; g < gr.n; ++g) gr.step[g][0] = gr.step[g][0] + 1.f;
+}
+
+__global__ void k_opt_sumsq(OptTable t, OptGroups gr, float* __restrict__ partial) {
   __shared__ float red[4];
   const int chunk = blockIdx.x / kSub;
   const int ti = find_tensor(t, chunk);
@@ -83,33 +85,13 @@ __global__ void k_opt_sumsq(OptTable t, float* __restrict__ partial) {
   float acc = 0.f;
   for (int i = base + threadIdx.x; i < end; i += blockDim.x) { const float x = g[i]; acc += x * x; }
   const float s = block_sum(acc, red);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = s;
+    if (blockIdx.x == 0) tick(gr);
+  }
 }
 
-__global__ void k_opt_prep(OptGroups gr, int n_chunks, float max_norm, const float* __restrict__ partial, OptState* st,
-                           float* norm_out) {
-  __shared__ float red[4];
-  float coef = 1.f;
-  if (max_norm > 0.f) {
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < n_chunks; i += blockDim.x) acc += partial[i];
-    const float tot = block_sum(acc, red);
-    if (threadIdx.x == 0) {
-      const float norm = sqrtf(tot);
-      if (norm_out) norm_out[0] = norm;
-      coef = fminf(max_norm / (norm + 1e-6f), 1.f);
-    }
-  }
-  if (threadIdx.x == 0) {
-    st->coef = coef;
-    for (int g = 0; g < gr.n; ++g) {
-      const float s = gr.step[g][0] + 1.f;
-      gr.step[g][0] = s;
-      st->bc1[g] = (float)(1.0 - pow(gr.beta1d[g], (double)s));          // double, like torch's host-side scalars
-      st->bc2_sqrt[g] = (float)sqrt(1.0 - pow(gr.beta2d[g], (double)s));
-    }
-  }
-}
+__global__ void k_opt_tick(OptGroups gr) { tick(gr); }
 
 struct AdamCoef {
   float coef, b2, eps, omb1, omb2, step_size, bc2s;
@@ -124,21 +106,54 @@ __device__ __forceinline__ void adam_one(const AdamCoef& c, float g, float& p, f
   p = p - c.step_size * (m / (sqrtf(d) / c.bc2s + c.eps));
 }
 
-__global__ void k_opt_apply(OptTable t, OptGroups gr, const OptState* __restrict__ st) {
+// new value of element i of a tensor -> its places in the network's fragment image
+__device__ __forceinline__ void image_store(const DmvPackMap& pm, int i, float val) {
+  if (pm.is_bias) { pm.image[pm.fwd_off + (int64_t)(i >> 5) * 64 + (i & 31)] = val; return; }
+  const int n = i / pm.K, k = i - n * pm.K;
+  pm.image[pm.fwd_off + 4 * ((int64_t)((n >> 5) * pm.S + (k >> 3)) * 64 + (n & 31) + 32 * ((k >> 2) & 1)) + (k & 3)] = val;
+  pm.image[pm.tr_off + 4 * ((int64_t)((k >> 5) * pm.Sn + (n >> 3)) * 64 + (k & 31) + 32 * ((n >> 2) & 1)) + (n & 3)] = val;
+}
+
+__global__ void k_opt_apply(OptTable t, OptGroups gr, int n_partials, float max_norm, const float* __restrict__ partial,
+                            float* norm_out, const DmvPackMap* __restrict__ pack_map) {
+  __shared__ float red[4];
+  __shared__ float sh[3];      // clip coefficient, lr / (1 - b1^t), sqrt(1 - b2^t)
   const int chunk = blockIdx.x / kSub;
   const int ti = find_tensor(t, chunk);
   const int base = (chunk - t.first_chunk[ti]) * kChunk + (blockIdx.x % kSub) * kQuarter;
   const int end = min(base + kQuarter, t.numel[ti]);
-  if (base >= end) return;
   const int gi = t.group[ti];
+  {
+    float acc = 0.f;
+    if (max_norm > 0.f)
+      for (int i = threadIdx.x; i < n_partials; i += blockDim.x) acc += partial[i];
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+      float coef = 1.f;
+      if (max_norm > 0.f) {
+        const float norm = sqrtf(tot);
+        if (norm_out && blockIdx.x == 0) norm_out[0] = norm;
+        coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+      }
+      const double sd = (double)gr.step[gi][0];                         // already advanced for this step
+      sh[0] = coef;
+      sh[1] = gr.lr[gi][0] / (float)(1.0 - pow(gr.beta1d[gi], sd));     // double, like torch's host-side scalars
+      sh[2] = (float)sqrt(1.0 - pow(gr.beta2d[gi], sd));
+    }
+    __syncthreads();
+  }
+  if (base >= end) return;
   AdamCoef c;
-  c.coef = st->coef; c.b2 = gr.beta2[gi]; c.eps = gr.eps[gi]; c.omb1 = gr.omb1[gi]; c.omb2 = gr.omb2[gi];
-  c.step_size = gr.lr[gi][0] / st->bc1[gi]; c.bc2s = st->bc2_sqrt[gi];
+  c.coef = sh[0]; c.b2 = gr.beta2[gi]; c.eps = gr.eps[gi]; c.omb1 = gr.omb1[gi]; c.omb2 = gr.omb2[gi];
+  c.step_size = sh[1]; c.bc2s = sh[2];
   float* p = t.p[ti];
   const float* g = t.g[ti];
   float* m = t.m[ti];
   float* v = t.v[ti];
   float* vm = t.vmax[ti];
+  DmvPackMap pm;
+  pm.image = nullptr;
+  if (pack_map) pm = pack_map[ti];
   // a quarter starts at a multiple of 1024 elements: 16-byte accesses need only aligned tensor bases
   const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vm) & 15) == 0;
   const int i4 = base + 4 * (int)threadIdx.x;       // blockDim.x * 4 == kQuarter
@@ -154,9 +169,26 @@ __global__ void k_opt_apply(OptTable t, OptGroups gr, const OptState* __restrict
     }
     *(f32x4*)(p + i4) = P; *(f32x4*)(m + i4) = M; *(f32x4*)(v + i4) = V;
     if (vm) *(f32x4*)(vm + i4) = X;
+    if (pm.image) {
+      if (!pm.is_bias && (pm.K & 3) == 0) {
+        // four consecutive inputs of one output row: one 16-byte store into the forward fragment, four words into
+        // the transposed one
+        const int n = i4 / pm.K, k = i4 - n * pm.K;
+        *(f32x4*)(pm.image + pm.fwd_off + 4 * ((int64_t)((n >> 5) * pm.S + (k >> 3)) * 64 + (n & 31) + 32 * ((k >> 2) & 1))) = P;
+        float* tr = pm.image + pm.tr_off + 4 * ((int64_t)((k >> 5) * pm.Sn + (n >> 3)) * 64 + (k & 31) + 32 * ((n >> 2) & 1)) + (n & 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tr[4 * e] = P[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) image_store(pm, i4 + e, P[e]);
+      }
+    }
     return;
   }
-  for (int i = i4; i < min(i4 + 4, end); ++i) adam_one(c, g[i], p[i], m[i], v[i], vm ? vm + i : nullptr);
+  for (int i = i4; i < min(i4 + 4, end); ++i) {
+    adam_one(c, g[i], p[i], m[i], v[i], vm ? vm + i : nullptr);
+    if (pm.image) image_store(pm, i, p[i]);
+  }
 }
 
 }  // namespace
@@ -168,15 +200,15 @@ extern "C" size_t dmv_opt_ws_floats(int32_t n, const int64_t* numel) {
     if (numel[i] < 0 || numel[i] > 0x7fffffff) return 0;
     chunks += (size_t)((numel[i] + kChunk - 1) / kChunk);
   }
-  return (sizeof(OptState) + 3) / 4 + kSub * chunks + 1;
+  return kSub * chunks + 1;
 }
 
-// Both entry points: argument checks, the tables, the three launches.  ws: a device address with room for
+// Both entry points: argument checks, the tables, the two launches.  ws: a device address with room for
 // dmv_opt_ws_floats(n, numel) floats (the caller's workspace, or this GPU's copy of the static array below).
 static int adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
                      const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm,
-                     float* ws, float* norm_out, void* stream) {
+                     float* ws, float* norm_out, const DmvPackMap* pack_map, void* stream) {
   OptTable t;
   t.n = n;
   int chunks = 0;
@@ -207,16 +239,13 @@ static int adam_step(int32_t n, float* const* params, const float* const* grads,
     gr.omb2[g] = live ? (float)(1.0 - groups[g].beta2) : 0.f;
   }
   if (chunks == 0) return DMV_OK;
-  OptState* st = (OptState*)ws;
-  float* partial = ws + (sizeof(OptState) + 3) / 4;
+  float* partial = ws;
   hipStream_t s = (hipStream_t)stream;
-  if (max_norm > 0.f) {
-    hipLaunchKernelGGL(k_opt_sumsq, dim3((unsigned)(kSub * chunks)), dim3(256), 0, s, t, partial);
-    DMV_HIP_CHECK_LAUNCH();
-  }
-  hipLaunchKernelGGL(k_opt_prep, dim3(1), dim3(256), 0, s, gr, kSub * chunks, max_norm, partial, st, norm_out);
+  if (max_norm > 0.f) hipLaunchKernelGGL(k_opt_sumsq, dim3((unsigned)(kSub * chunks)), dim3(256), 0, s, t, gr, partial);
+  else hipLaunchKernelGGL(k_opt_tick, dim3(1), dim3(1), 0, s, gr);
   DMV_HIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_opt_apply, dim3((unsigned)(kSub * chunks)), dim3(kQuarter / 4), 0, s, t, gr, st);
+  hipLaunchKernelGGL(k_opt_apply, dim3((unsigned)(kSub * chunks)), dim3(kQuarter / 4), 0, s, t, gr, kSub * chunks, max_norm,
+                     partial, norm_out, pack_map);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
@@ -232,18 +261,18 @@ static int check_tables(int32_t n, float* const* params, const float* const* gra
 extern "C" int dmv_opt_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
                                  float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
                                  const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm,
-                                 float* ws, size_t ws_floats, float* norm_out, void* stream) {
+                                 float* ws, size_t ws_floats, float* norm_out, const DmvPackMap* pack_map, void* stream) {
   const int rc = check_tables(n, params, grads, exp_avg, exp_avg_sq, numel, group_of, n_groups, groups);
   if (rc) return rc;
   if (!ws) return DMV_E_BADARG;
   if (ws_floats < dmv_opt_ws_floats(n, numel) || dmv_opt_ws_floats(n, numel) == 0) return DMV_E_WORKSPACE;
   return adam_step(n, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq, numel, group_of, n_groups, groups, max_norm,
-                   ws, norm_out, stream);
+                   ws, norm_out, pack_map, stream);
 }
 
 // ------------------------------------------------------------------------------------------
-// The same step for callers that cannot allocate: the workspace (clip coefficient, bias corrections, partial sums of
-// squares) lives in a file-scope device array instead of a caller buffer.  Every GPU that runs the library holds its
+// The same step for callers that cannot allocate: the workspace (the partial sums of squares) lives in a file-scope
+// device array instead of a caller buffer.  Every GPU that runs the library holds its
 // own copy of the array at its own address until the process ends; `scratch` below is only the host-side handle of
 // the symbol, never a device address: the address on a GPU comes from hipGetSymbolAddress, looked up once per device
 // (with that device current) and kept.
@@ -277,7 +306,8 @@ int scratch_address(float** out) {
 extern "C" int dmv_opt_adam_step_static(int32_t n, float* const* params, const float* const* grads,
                                         float* const* exp_avg, float* const* exp_avg_sq, float* const* max_exp_avg_sq,
                                         const int64_t* numel, const int32_t* group_of, int32_t n_groups,
-                                        const DmvAdamGroup* groups, float max_norm, float* norm_out, void* stream) {
+                                        const DmvAdamGroup* groups, float max_norm, float* norm_out,
+                                        const DmvPackMap* pack_map, void* stream) {
   const int rc = check_tables(n, params, grads, exp_avg, exp_avg_sq, numel, group_of, n_groups, groups);
   if (rc) return rc;
   const size_t need = dmv_opt_ws_floats(n, numel);
@@ -286,8 +316,8 @@ extern "C" int dmv_opt_adam_step_static(int32_t n, float* const* params, const f
   float* ws = nullptr;
   const int rs = scratch_address(&ws);
   if (rs) return rs;
-  // nothing in the array has to start at zero: k_opt_sumsq writes every partial sum k_opt_prep reads, and k_opt_prep
-  // writes the whole state block before k_opt_apply reads it, on the same stream
+  // nothing in the array has to start at zero: k_opt_sumsq writes every partial sum k_opt_apply reads, on the same
+  // stream
   return adam_step(n, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq, numel, group_of, n_groups, groups, max_norm,
-                   ws, norm_out, stream);
+                   ws, norm_out, pack_map, stream);
 }

@@ -17,7 +17,10 @@ class GraphedStep:
         """body(): one training step on static tensors, returns a tensor (e.g. the bound) or None.
         refresh(): refills the static noise / batch tensors; called before every replay.
         nets: the PackedNets the step trains.  Their fragment images are re-packed inside the recording (so every
-        replay packs the current weights) and marked stale after each replay for code running outside the graph."""
+        replay packs the current weights) and marked stale after each replay for code running outside the graph -
+        unless the step's optimiser keeps the images current itself (demiss_vae_amd.optim.Adam.attach_images): then
+        nothing is packed inside the recording, and a replay only checks on the host that nothing else changed the
+        parameters since."""
         self.refresh, self.nets = refresh, tuple(nets)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -34,17 +37,23 @@ class GraphedStep:
             refresh()
         for n in self.nets:
             n.packed()          # allocate the image outside the recording ...
-            n.invalidate()      # ... and make sure the packing kernel is part of it
+            if not n.image_kept_by_optimizer:
+                n.invalidate()      # ... and make sure the packing kernel is part of it
         with torch.cuda.graph(self.graph):
             with self.noise:
                 self.out = body()
         for n in self.nets:
-            n.invalidate()
+            if not n.image_kept_by_optimizer:
+                n.invalidate()
 
     def __call__(self):
         if self.refresh is not None:
             self.refresh()
+        for n in self.nets:
+            if n.image_kept_by_optimizer:
+                n.packed()      # re-packs (eagerly, before the replay) only if something else changed the parameters
         self.graph.replay()
         for n in self.nets:
-            n.invalidate()
+            if not n.image_kept_by_optimizer:
+                n.invalidate()
         return self.out

@@ -20,9 +20,13 @@ from . import _lib as L
 _optimizer_steps = 0
 
 
-def _count_optimizer_step(*_args, **_kwargs):
+def _count_optimizer_step(opt=None, *_args, **_kwargs):
     global _optimizer_steps
     _optimizer_steps += 1
+    # an optimiser that wrote the new parameters into its networks' fragment images itself (demiss_vae_amd.optim.Adam
+    # with attach_images) leaves those images current
+    for net in getattr(opt, "_images_written", ()):
+        net._stamp = net._current_stamp()
 
 
 register_optimizer_step_post_hook(_count_optimizer_step)
@@ -80,6 +84,7 @@ class PackedNet:
         if n == 0:
             raise RuntimeError(f"unsupported network shape for the HIP kernels: {dims}")
         self._n_packed = n
+        self.image_kept_by_optimizer = False     # set by demiss_vae_amd.optim.Adam.attach_images
         self.flat_grads = False
         self._slab = None
         self._slab_offsets = None
@@ -138,6 +143,18 @@ class PackedNet:
         """Forget the fragment image: the next use re-packs.  Needed when the parameters changed without torch
         noticing (an optimiser step replayed inside a captured graph does not bump tensor versions)."""
         self._stamp = None
+
+    def pack_maps(self):
+        """DmvPackMap entries of the weight and bias tensors in params() order: where each lives in the fragment
+        image (which is allocated here if it is not yet and then stays where it is)."""
+        self.packed()
+        nl = self.dims.num_layers
+        ws, bs = (L.DmvPackMap * nl)(), (L.DmvPackMap * nl)()
+        L.check(L.lib().dmv_mlp_pack_map(C.byref(self.c), L.ptr(self._packed), ws, bs))
+        out = []
+        for w, b in zip(ws, bs):
+            out += [w, b]
+        return out
 
     def _current_stamp(self):
         return (_optimizer_steps,) + tuple((t.data_ptr(), t._version) for t in self.params())

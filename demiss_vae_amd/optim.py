@@ -1,4 +1,4 @@
-"""Adam / AMSGrad with global gradient-norm clipping in three kernel launches (dmv_opt_adam_step in include/dmv.h).
+"""Adam / AMSGrad with global gradient-norm clipping in two kernel launches (dmv_opt_adam_step in include/dmv.h).
 
 `Adam` takes what `torch.optim.Adam` takes in the reference's `configure_optimizers` (vgiwae/models/vae.py:349-374:
 parameter groups with their own `lr` and `amsgrad`) and applies the same update rule; `state_dict()` has torch's
@@ -25,6 +25,18 @@ class Adam(torch.optim.Optimizer):
         self._clip = 0.0
         self._built = None
         self.grad_norm = None          # device scalar: norm of the gradients seen by the last clipped step
+        self._image_nets = []
+        self._images_written = ()
+
+    def attach_images(self, nets):
+        """The PackedNets among `nets` all of whose parameters this optimiser updates: step() then also writes every
+        new parameter value into their MFMA fragment images, and the next forward pass launches no packing kernel."""
+        mine = {id(p) for g in self.param_groups for p in g["params"]}
+        self._image_nets = [n for n in nets if all(id(p) in mine for p in n.params())]
+        for n in self._image_nets:
+            n.image_kept_by_optimizer = True
+        self._built = None
+        return self
 
     def clip_on_next_step(self, max_norm: float):
         self._clip = float(max_norm or 0.0)
@@ -67,7 +79,18 @@ class Adam(torch.optim.Optimizer):
                  v=L.ptr_array([self.state[p]["exp_avg_sq"] for p in ps]),
                  vmax=(L._P * n)(*[self.state[p]["max_exp_avg_sq"].data_ptr() if "max_exp_avg_sq" in self.state[p] else None
                                   for p in ps]))
-        self.grad_norm = torch.zeros((), device=dev)
+        # where every parameter lives in its network's fragment image (entries of the others stay empty)
+        b["pack_map"] = None
+        if self._image_nets:
+            entries = (L.DmvPackMap * n)()
+            index = {id(p): i for i, p in enumerate(ps)}
+            for net in self._image_nets:
+                for p, e in zip(net.params(), net.pack_maps()):
+                    entries[index[id(p)]] = e
+            b["pack_map"] = torch.frombuffer(bytearray(bytes(entries)), dtype=torch.uint8).to(dev)
+            b["images"] = [net._packed.data_ptr() for net in self._image_nets]
+        if self.grad_norm is None or self.grad_norm.device != dev:
+            self.grad_norm = torch.zeros((), device=dev)
         self._built = b
         return b
 
@@ -88,13 +111,22 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         b = self._built or self._build()
+        if self._image_nets:
+            for net in self._image_nets:
+                net.packed()           # entries the step does not write (padding) must be there; normally a no-op
+            if [net._packed.data_ptr() for net in self._image_nets] != b["images"]:
+                b = self._build()      # an image moved (parameters went to another device)
         self.sync_lr()
         live = [i for i, p in enumerate(b["ps"]) if p.grad is not None]
         if not live:
             return loss
         grads = [b["ps"][i].grad if b["ps"][i].grad.is_contiguous() else b["ps"][i].grad.contiguous() for i in live]
+        pack_map = None
+        self._images_written = ()
         if len(live) == b["n"]:
             n, P_, M_, V_, X_, numel, group_of = b["n"], b["p"], b["m"], b["v"], b["vmax"], b["numel"], b["group_of"]
+            if b["pack_map"] is not None:
+                pack_map, self._images_written = b["pack_map"], tuple(self._image_nets)
         else:       # parameters without a gradient are left alone (torch skips them too): tables of the others
             n = len(live)
             pick = lambda arr, ctype: (ctype * n)(*[arr[i] for i in live])
@@ -102,6 +134,6 @@ class Adam(torch.optim.Optimizer):
             numel, group_of = pick(b["numel"], C.c_int64), pick(b["group_of"], C.c_int32)
         L.check(L.lib().dmv_opt_adam_step(n, P_, L.ptr_array(grads), M_, V_, X_, numel, group_of, len(self.param_groups),
                                           b["groups"], self._clip, L.ptr(b["ws"]), b["ws_floats"], L.ptr(self.grad_norm),
-                                          L.stream_ptr()))
+                                          L.ptr(pack_map), L.stream_ptr()))
         self._clip = 0.0
         return loss

@@ -263,7 +263,8 @@ class _StepRunner:
     def _flat_gradients(self):
         """the fused networks keep their parameter gradients in one permanent buffer each (what the gradient exchange
         reduces in place); with automatic optimisation (one backward pass a step) the decoder's exchange starts under
-        the encoder's backward pass"""
+        the encoder's backward pass; the library's optimiser writes updated parameters straight into the networks'
+        MFMA fragment images"""
         self.flat_ready = True
         m = self.model
         inner = getattr(m, "model", m)
@@ -272,6 +273,8 @@ class _StepRunner:
         nets = tuple(m.engine()[1:])
         for net in nets:
             net.use_flat_grads(True)
+        if hasattr(self.opt, "attach_images"):       # the optimiser step keeps the networks' MFMA images current
+            self.opt.attach_images(nets)
         if P.world() > 1 and m.automatic_optimization:
             P.overlap_grad_exchange(nets)
 

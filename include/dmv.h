@@ -354,7 +354,19 @@ int dmv_grid_divergences(int32_t gen_dist, int32_t D, int32_t Zd, int64_t Nz, co
  * an entry NULL: no AMSGrad for that tensor); numel[i] elements each; group_of[i] in [0, n_groups).
  * groups[g].lr and .step are device scalars (float): schedulers write lr, the call increments step.
  * ws: dmv_opt_ws_floats(n, numel) floats.  norm_out (nullable device scalar) receives the gradient norm.
- * The pointers are passed to the kernels by value: a step recorded in a HIP graph replays without host copies. */
+ * The pointers are passed to the kernels by value: a step recorded in a HIP graph replays without host copies.
+ * pack_map: NULL, or n entries in device memory (dmv_mlp_pack_map fills them on the host; copy them over once): where
+ * tensor i lives in its network's fragment image.  The step then also writes every new parameter value into the
+ * image (entries with image == NULL are skipped), so a forward pass after the step needs no dmv_mlp_pack. */
+typedef struct DmvPackMap {
+  float* image;              /* the network's fragment image (dmv_mlp_pack's `packed`); NULL: not part of one */
+  int64_t fwd_off, tr_off;   /* floats: forward and transposed fragment sets of a weight; bias fragments in fwd_off */
+  int32_t N, K;              /* weight [N][K]; bias: N entries */
+  int32_t S, Sn;             /* fragment groups per 32-wide tile of the forward / transposed set */
+  int32_t is_bias, reserved;
+} DmvPackMap;
+/* entries for the 2*nb+2 weight and bias tensors of `net` whose image lives at `packed` */
+int dmv_mlp_pack_map(const DmvNet* net, float* packed, DmvPackMap* weights, DmvPackMap* biases);
 #define DMV_OPT_MAX_TENSORS 72
 #define DMV_OPT_MAX_GROUPS 4
 typedef struct DmvAdamGroup {
@@ -366,7 +378,7 @@ size_t dmv_opt_ws_floats(int32_t n, const int64_t* numel);
 int dmv_opt_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
                       const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm, float* ws,
-                      size_t ws_floats, float* norm_out, void* stream);
+                      size_t ws_floats, float* norm_out, const DmvPackMap* pack_map, void* stream);
 
 /* dmv_opt_adam_step for callers that cannot allocate device memory or bring a workspace (code running under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments
@@ -382,7 +394,7 @@ int dmv_opt_adam_step(int32_t n, float* const* params, const float* const* grads
 int dmv_opt_adam_step_static(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
                              float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
                              const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm,
-                             float* norm_out, void* stream);
+                             float* norm_out, const DmvPackMap* pack_map, void* stream);
 
 #ifdef __cplusplus
 }

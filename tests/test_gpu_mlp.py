@@ -279,6 +279,59 @@ def test_library_adam_matches_torch_adam(clip):
     assert torch.equal(mine[0].grad, gs[0])                                # gradients are not rescaled in memory
 
 
+@pytest.mark.parametrize("shape", [(16, 16, 2, 256), (5, 4, 3, 200), (43, 86, 1, 64), (7, 3, 0, 17), (12, 20, 1, 320)])
+def test_optimiser_keeps_the_fragment_images_current(shape):
+    """Adam.attach_images: the step writes every new parameter value into its network's MFMA fragment image, so no
+    packing kernel runs afterwards.  After several steps the image must equal, bit for bit, a fresh packing of the
+    updated parameters (forward and transposed fragments, bias fragments, odd widths), the next forward pass must
+    reuse it, and a parameter change from elsewhere must still trigger a re-pack - eagerly and in a replayed step."""
+    import ctypes as C
+    import demiss_vae_amd as dmv
+    import gpu_util as G
+    from demiss_vae_amd import _lib as L
+    from demiss_vae_amd.optim import Adam
+    spec = NetSpec(*shape)
+    net = G.packed_net(spec, make_params(spec, 61))
+    other = G.packed_net(NetSpec(4, 4, 1, 32), make_params(NetSpec(4, 4, 1, 32), 62))
+    opt = Adam([{"params": net.params(), "lr": 1e-2, "amsgrad": True}, {"params": other.params(), "lr": 1e-3}])
+    opt.attach_images((net, other))
+    assert net.image_kept_by_optimizer and other.image_kept_by_optimizer
+    x = make_noise(63, 100, shape[0]).cuda()
+
+    def fresh_image():
+        ref = dmv.PackedNet(net.dims, [w.detach().clone() for w in net.weights], [b.detach().clone() for b in net.biases])
+        return ref.packed().clone()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        for n, xin in ((net, x), (other, x[:, :4].contiguous())):
+            y = dmv.ResidualMLPFunction.apply(n, True, None, xin, *n.params())
+            y.square().sum().backward()
+        opt.clip_on_next_step(1.0)
+        opt.step()
+
+    for _ in range(3):
+        step()
+    image = net._packed
+    assert net._stamp == net._current_stamp()                  # current without a packing launch ...
+    assert torch.equal(image, fresh_image())                   # ... and equal to what packing would write
+    assert net.packed().data_ptr() == image.data_ptr()
+    # a change from outside the optimiser is still noticed
+    with torch.no_grad():
+        net.weights[0].mul_(1.5)
+    assert net._stamp != net._current_stamp()
+    assert torch.equal(net.packed(), fresh_image())
+    # the same inside a replayed step
+    g = dmv.GraphedStep(step, nets=(net, other), warmup=1)
+    for _ in range(3):
+        g()
+    assert torch.equal(net._packed, fresh_image())
+    with torch.no_grad():
+        net.biases[-1].add_(1.0)
+    g()
+    assert torch.equal(net._packed, fresh_image())
+
+
 @pytest.mark.parametrize("rows,hidden,nb", [(300, 64, 2), (5000, 256, 2), (20000, 256, 1), (777, 200, 3), (45, 96, 1), (200, 320, 1)])
 @pytest.mark.parametrize("p", [0.5, 0.25, 0.1])
 def test_generated_dropout_equals_its_own_masks(rows, hidden, nb, p):

@@ -112,8 +112,9 @@ def test_abi_exports_every_declared_symbol():
     per_hidden = 2 * (8 * 32 * 256) + 8 * 64
     assert l.dmv_mlp_packed_floats(ctypes.byref(net)) == (2 * 8 * 2 * 256 + 8 * 64) + 4 * per_hidden + (2 * 32 * 256 + 64)
     assert l.dmv_mlp_saved_floats(ctypes.byref(net), 100) == 128 * 32 + 5 * 128 * (256 + 8)  # rows padded to 32; 8 sign-bit words per row and layer
-    assert l.dmv_mlp_packed_floats(ctypes.byref(_lib.DmvNet(16, 16, 512, 2, 0, 0.0))) > 0    # 257..512: relu, no dropout
-    assert l.dmv_mlp_packed_floats(ctypes.byref(_lib.DmvNet(16, 16, 512, 2, 0, 0.5))) == 0
+    assert l.dmv_mlp_packed_floats(ctypes.byref(_lib.DmvNet(16, 16, 512, 2, 0, 0.0))) > 0    # 257..512: relu only
+    assert l.dmv_mlp_packed_floats(ctypes.byref(_lib.DmvNet(16, 16, 512, 2, 0, 0.5))) > 0
+    assert l.dmv_mlp_packed_floats(ctypes.byref(_lib.DmvNet(16, 16, 512, 2, 2, 0.0))) == 0
     bad = _lib.DmvNet(16, 16, 513, 2, 0, 0.0)
     assert l.dmv_mlp_packed_floats(ctypes.byref(bad)) == 0          # hidden width outside the kernels' range
 

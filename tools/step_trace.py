@@ -12,7 +12,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import demiss_vae_amd as dmv  # noqa: E402
 from bench import make_gas  # noqa: E402
-from demiss_vae_amd.optim import Adam  # noqa: E402
+from demiss_vae_amd.optim import Adam
+from demiss_vae_amd.run import _unit_gradient as unit_gradient  # noqa: E402
 
 what = sys.argv[1] if len(sys.argv) > 1 else "512"
 mode = sys.argv[2] if len(sys.argv) > 2 else "graph"
@@ -28,25 +29,25 @@ if what in ("hepmass", "miniboone"):
     dec = synth.packed_net(synth.NetShape(*ds, dropout=p), 2, "cuda")
     dims = dmv.ModelDims(D=D, Zd=Zd, q_dist="stratified_with_eps", C=5, encoder_use_mis_mask=True)
     X, M = (t.cuda() for t in synth.batch(3, B, D))
-    opt = Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True)
+    opt = Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True).attach_images((enc, dec))
 
     def step():
         ek, dk = keep_for(enc, B, True, "cuda"), keep_for(dec, B * 5, True, "cuda")      # what the model classes pass
         _, _, loss = dmv.estimate_multiple_iwelbo(dims, enc, dec, X, M, num_importance_samples_for_each_component=1, STL=True,
                                                   enc_keep=ek, dec_keep=dk, with_loss=True)
         opt.zero_grad(set_to_none=True)
-        loss.backward()
+        loss.backward(unit_gradient(loss))      # the trainer's cached root gradient: no ones-fill per step
         opt.step()
 else:
     B = int(what)
     dims, enc, dec, _, _, X, M = make_gas("cuda", B)
-    opt = Adam([{"params": dec.params(), "amsgrad": True, "lr": 1e-3}, {"params": enc.params(), "amsgrad": True, "lr": 1e-3}])
+    opt = Adam([{"params": dec.params(), "amsgrad": True, "lr": 1e-3}, {"params": enc.params(), "amsgrad": True, "lr": 1e-3}]).attach_images((enc, dec))
 
     def step():
         opt.zero_grad(set_to_none=True)
         _, _, loss = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=1, num_importance_samples=K, STL=True,
                                          with_loss=True)
-        loss.backward()
+        loss.backward(unit_gradient(loss))      # the trainer's cached root gradient: no ones-fill per step
         opt.clip_on_next_step(5.0)
         opt.step()
 

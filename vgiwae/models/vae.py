@@ -174,7 +174,7 @@ class VAE(ImputerModuleBase, PLEstimateTotalTrainSteps):
 
 
 def _adam(groups):
-    """The library's Adam (same update rule; clipping and both groups in three launches) for fp32 parameters on the
+    """The library's Adam (same update rule; clipping and both groups in two launches) for fp32 parameters on the
     GPU, torch's otherwise."""
     params = [p for g in groups for p in g["params"]]
     if params and all(p.is_cuda and p.dtype == torch.float32 for p in params) and len(params) <= 72:
