@@ -118,6 +118,7 @@ __global__ void k_opt_apply(OptTable t, OptGroups gr, int n_partials, float max_
                             float* norm_out, const DmvPackMap* __restrict__ pack_map) {
   __shared__ float red[4];
   __shared__ float sh[3];      // clip coefficient, lr / (1 - b1^t), sqrt(1 - b2^t)
+  __shared__ __attribute__((aligned(16))) float turn[kQuarter];
   const int chunk = blockIdx.x / kSub;
   const int ti = find_tensor(t, chunk);
   const int base = (chunk - t.first_chunk[ti]) * kChunk + (blockIdx.x % kSub) * kQuarter;
@@ -157,6 +158,7 @@ __global__ void k_opt_apply(OptTable t, OptGroups gr, int n_partials, float max_
   // a quarter starts at a multiple of 1024 elements: 16-byte accesses need only aligned tensor bases
   const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vm) & 15) == 0;
   const int i4 = base + 4 * (int)threadIdx.x;       // blockDim.x * 4 == kQuarter
+  const bool whole = vec && end - base == kQuarter;  // (uniform over the workgroup: every thread takes the 16-byte path)
   if (vec && i4 + 4 <= end) {
     f32x4 P = *(f32x4*)(p + i4), M = *(f32x4*)(m + i4), V = *(f32x4*)(v + i4), X;
     const f32x4 G = *(const f32x4*)(g + i4);
@@ -171,13 +173,27 @@ __global__ void k_opt_apply(OptTable t, OptGroups gr, int n_partials, float max_
     if (vm) *(f32x4*)(vm + i4) = X;
     if (pm.image) {
       if (!pm.is_bias && (pm.K & 3) == 0) {
-        // four consecutive inputs of one output row: one 16-byte store into the forward fragment, four words into
-        // the transposed one
+        // four consecutive inputs of one output row: one 16-byte store into the forward fragment
         const int n = i4 / pm.K, k = i4 - n * pm.K;
         *(f32x4*)(pm.image + pm.fwd_off + 4 * ((int64_t)((n >> 5) * pm.S + (k >> 3)) * 64 + (n & 31) + 32 * ((k >> 2) & 1))) = P;
-        float* tr = pm.image + pm.tr_off + 4 * ((int64_t)((k >> 5) * pm.Sn + (n >> 3)) * 64 + (k & 31) + 32 * ((n >> 2) & 1)) + (n & 3);
+        // The transposed fragment wants four consecutive OUTPUT rows of one input as 16 bytes.  A whole quarter that
+        // holds complete rows in multiples of four (K divides 256: every hidden-to-hidden layer) is turned through
+        // LDS, one coalesced 16-byte store per thread; anything else writes four single words.
+        const int R = kQuarter / pm.K;
+        if (whole && R * pm.K == kQuarter && (R & 3) == 0) {
+          *(f32x4*)(turn + 4 * threadIdx.x) = P;
+          __syncthreads();
+          const int kk = threadIdx.x % pm.K, q = threadIdx.x / pm.K;
+          const int n0 = base / pm.K + 4 * q;
+          f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tr[4 * e] = P[e];
+          for (int e = 0; e < 4; ++e) o[e] = turn[(4 * q + e) * pm.K + kk];
+          *(f32x4*)(pm.image + pm.tr_off + 4 * ((int64_t)((kk >> 5) * pm.Sn + (n0 >> 3)) * 64 + (kk & 31) + 32 * ((n0 >> 2) & 1))) = o;
+        } else {
+          float* tr = pm.image + pm.tr_off + 4 * ((int64_t)((k >> 5) * pm.Sn + (n >> 3)) * 64 + (k & 31) + 32 * ((n >> 2) & 1)) + (n & 3);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tr[4 * e] = P[e];
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) image_store(pm, i4 + e, P[e]);
