@@ -12,6 +12,32 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+
+# what the numbers mean for the kernels as they stand (kept with the generator so that a re-run keeps it)
+NOTES = """
+## Reading the tables
+
+Launch count of the gas training step (B = 32768, K = 5, eager, profiles/r2_training_steps.md): 16 library kernels a step -
+sample, one fused objective forward (terms + logsumexp bound + backward weights), the mean / loss kernel, two objective
+backward kernels, 2 x (MLP forward, backward chain, weight gradients, reduction), two optimiser kernels.  The first round's
+step had `k_obj_terms` + `k_obj_bound` + torch reductions in place of the one forward launch.
+
+Where the forward and backward objective kernels stand against the 60 %-of-8-TB/s mark:
+- Bernoulli-784 decoder-side backward: 70 % (HBM-bound as intended: 16-byte accesses, one pass).
+- Bernoulli-784 forward: 37 %.  One wave reads a 784-wide row as 16-byte pieces and spends the time in the two softplus
+  evaluations per pixel (exp + log on the quarter-rate transcendental unit): about 110 issue cycles per 16 bytes loaded.  It is
+  bound by instruction issue, not by memory; the PMC traffic equals the algorithmic bytes (no re-reads).
+- gas rows (D = 8, Zd = 16; 150 to 250 bytes per sample row): 19 - 42 %.  A launch moves 25 - 40 MB in 10 - 16 us.  At this
+  size the arrays of the previous kernel are still in the 256 MB Infinity Cache (the PMC traffic of the forward is above the
+  algorithmic bytes only because its 32-float decoder rows are read with their padding), and the duration is set by the
+  dependent chain load -> transcendental math -> cross-lane reduction -> store that every thread runs once, with 2.5
+  workgroups per CU: too short a kernel to cover HBM latency with more loads in flight.  What was done about it: thread-per-row
+  forward with compile-time row shapes (28.7 -> 15.1 us), LDS table of the per-datapoint q parameters, hardware
+  sine / cosine / rcp / sqrt, no 64-bit index math, batched unconditional preloads in the latent backward (17 -> 12 us),
+  per-dimension decoder backward (16.6 -> 9.2 us).  The four kernels together are 64 us of the 2.67 ms headline step (2.4 %).
+- the latent sampler (13 - 19 %) is bound by Philox + Box-Muller arithmetic: 10 rounds of 32 x 32 -> 64-bit multiplies per four
+  normals.
+"""
 KEYS = {"k_latent_sample": "k_latent_sample", "k_obj_fwd": "k_obj_fwd", "k_obj_bwd_dec": "k_obj_bwd_dec", "k_obj_bwd_latent": "k_obj_bwd_latent"}
 lines = [f"# Objective kernels under rocprofv3 ({tag})", "",
          "`bash tools/objprof.sh gas` and `bash tools/objprof.sh bern` on one MI355X: `python tools/objprof.py <shape>` under",
@@ -61,5 +87,6 @@ for shape, title in (("gas", "UCI-gas MissIWAE: 32768 datapoints x 5 samples = 1
         tr = (2 * pmc[k].get("FETCH_SIZE", 0) + pmc[k].get("WRITE_SIZE", 0)) * 1024 / 1e6
         lines.append(f"| `{name}` | {calls} | {ns / 1e3:.1f} | {b / 1e6:.1f} | {b / ns:.0f} | {b / ns / 8000 * 100:.0f} % | {tr:.1f} | {ev[k]['event_us']} |")
     lines.append("")
+lines += NOTES.strip("\n").split("\n")
 open(f"profiles/{tag}_objective_kernels.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
