@@ -103,8 +103,8 @@ SIGNATURES = {
     "dmv_grid_marginal_ws_floats": (_SZ, [_I64, _I32]),
     "dmv_grid_marginal": (C.c_int, [_I32, _I32, _I64, _P, _I64, _P, _I32, _P, _P, _P, _P, _P, _P]),
     "dmv_opt_ws_floats": (_SZ, [_I32, _P]),
-    "dmv_opt_adam_step": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _SZ, _P, _P, _P]),
-    "dmv_opt_adam_step_static": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _P, _P]),
+    "dmv_opt_adam_step": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _SZ, _P, _P, _P, _U64, _P]),
+    "dmv_opt_adam_step_static": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _P, _P, _U64, _P]),
     "dmv_mlp_pack_map": (C.c_int, [C.POINTER(DmvNet), _P, C.POINTER(DmvPackMap), C.POINTER(DmvPackMap)]),
     "dmv_grid_divergences": (C.c_int, [_I32, _I32, _I32, _I64, _P, _P, _P, _F, _I32, _P, _P, _P, _I32, _P, _P, _P, _P]),
     "dmv_lse_update": (C.c_int, [_I32, _I64, _P, _I32, _P, _P, _P]),

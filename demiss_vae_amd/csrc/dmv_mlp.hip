@@ -1139,12 +1139,18 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_coop(BwdArgs a) {
 
 static inline bool dmv_use_rows16(int64_t rows) { return (rows + 15) / 16 <= 256; }
 
-template <int NT>
+// W waves share a tile: 4, one per SIMD.  (8, two per SIMD, was measured and gains nothing - 27 against 28 us a pass at
+// 2 560 rows, hidden 256: a tile's layer is 16 x Hp x Hp MACs on ONE compute unit, whose four matrix pipes need 3.4 us
+// for it at hidden 256 however many waves feed them.)
+template <int NT, int W = 4>
 struct Rows16 {
-  static constexpr int NK = 2 * NT;                 // 16-wide tiles of the hidden width
-  static constexpr int TW = 2 * ((NT + 3) / 4);     // output tiles per wave (whole 32-wide tiles: sign-bit halfwords)
+  static constexpr int NK = 2 * NT;                       // 16-wide tiles of the hidden width
+  static constexpr int TW = 2 * ((NT + W - 1) / W);       // output tiles per wave (whole 32-wide tiles: sign-bit halfwords)
+  static constexpr int PF = W == 8 ? 4 : 2;               // input tiles a weight fragment is requested ahead of its use
   static constexpr int LDS_BYTES = NK * 1024;
 };
+template <int NT, int W> using R16Slice = f32x4[Rows16<NT, W>::TW];   // a wave's output tiles of a layer
+template <int NT> using R16Full = f32x4[2 * NT];                      // all tiles of a layer
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
@@ -1166,19 +1172,19 @@ __device__ __forceinline__ float r16_bias(__amdgpu_buffer_rsrc_t bimg, int lane,
   return lane < 16 ? v : 0.f;
 }
 
-// acc[i] (+)= W[tile t0 + i] in over the 32 NT hidden inputs; fragments two input tiles ahead
-template <int NT, bool FRESH, bool BIAS>
+// acc[i] (+)= W[tile t0 + i] in over the 32 NT hidden inputs; fragments PF input tiles ahead
+template <int NT, int W, bool FRESH, bool BIAS>
 __device__ __forceinline__ void r16_gemm(const f32x4* __restrict__ Wimg, const float* __restrict__ Bimg, int lane, int t0,
-                                         const f32x4 (&in)[Rows16<NT>::NK], f32x4 (&acc)[Rows16<NT>::TW]) {
-  constexpr int S = 4 * NT, TW = Rows16<NT>::TW, NK = Rows16<NT>::NK;
+                                         const R16Full<NT>& in, R16Slice<NT, W>& acc) {
+  constexpr int S = 4 * NT, TW = Rows16<NT, W>::TW, NK = Rows16<NT, W>::NK, PF = Rows16<NT, W>::PF;
   const uint32_t lo = r16_lane_off(lane);
   const __amdgpu_buffer_rsrc_t img = make_rsrc(Wimg, NT * S * 1024u);
   uint32_t base[TW];
 #pragma unroll
   for (int i = 0; i < TW; ++i) base[i] = r16_tile_off(t0 + i, S);   // tiles past NK fall outside the resource: zeros
-  f32x4 w[3][TW];
+  f32x4 w[PF + 1][TW];
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < PF; ++p)
 #pragma unroll
     for (int i = 0; i < TW; ++i) w[p][i] = (p < NK) ? buf_load4(img, lo, base[i] + (uint32_t)p * 2048u) : zero4();
   if (BIAS) {
@@ -1188,9 +1194,9 @@ __device__ __forceinline__ void r16_gemm(const f32x4* __restrict__ Wimg, const f
   }
 #pragma unroll
   for (int t = 0; t < NK; ++t) {
-    if (t + 2 < NK) {
+    if (t + PF < NK) {
 #pragma unroll
-      for (int i = 0; i < TW; ++i) w[(t + 2) % 3][i] = buf_load4(img, lo, base[i] + (uint32_t)(t + 2) * 2048u);
+      for (int i = 0; i < TW; ++i) w[(t + PF) % (PF + 1)][i] = buf_load4(img, lo, base[i] + (uint32_t)(t + PF) * 2048u);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1198,14 +1204,14 @@ __device__ __forceinline__ void r16_gemm(const f32x4* __restrict__ Wimg, const f
       const float b = in[t][e];
 #pragma unroll
       for (int i = 0; i < TW; ++i)
-        acc[i] = MFMA16(w[t % 3][i][e], b, (FRESH && !BIAS && t == 0 && e == 0) ? zero4() : acc[i]);
+        acc[i] = MFMA16(w[t % (PF + 1)][i][e], b, (FRESH && !BIAS && t == 0 && e == 0) ? zero4() : acc[i]);
     }
   }
 }
 
 // one output tile (fragment offset `toff`) from all hidden inputs, single accumulator
 template <int NT>
-__device__ __forceinline__ f32x4 r16_gemm1(__amdgpu_buffer_rsrc_t img, uint32_t toff, int lane, const f32x4 (&in)[Rows16<NT>::NK],
+__device__ __forceinline__ f32x4 r16_gemm1(__amdgpu_buffer_rsrc_t img, uint32_t toff, int lane, const R16Full<NT>& in,
                                            f32x4 acc) {
   constexpr int NK = Rows16<NT>::NK;
   const uint32_t lo = r16_lane_off(lane);
@@ -1220,10 +1226,10 @@ __device__ __forceinline__ f32x4 r16_gemm1(__amdgpu_buffer_rsrc_t img, uint32_t 
 }
 
 // all-gather of the waves' output slices through LDS
-template <int NT>
-__device__ __forceinline__ void r16_exchange(float* lds, int lane, int t0, const f32x4 (&slice)[Rows16<NT>::TW],
-                                             f32x4 (&full)[Rows16<NT>::NK]) {
-  constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK;
+template <int NT, int W>
+__device__ __forceinline__ void r16_exchange(float* lds, int lane, int t0, const R16Slice<NT, W>& slice,
+                                             R16Full<NT>& full) {
+  constexpr int TW = Rows16<NT, W>::TW, NK = Rows16<NT, W>::NK;
   f32x4* L4 = (f32x4*)lds;
   __syncthreads();                                   // previous readers are done with the buffer
 #pragma unroll
@@ -1234,11 +1240,11 @@ __device__ __forceinline__ void r16_exchange(float* lds, int lane, int t0, const
   for (int t = 0; t < NK; ++t) full[t] = L4[t * 64 + lane];
 }
 
-template <int NT>
-__device__ __forceinline__ void r16_own_slice(const f32x4 (&full)[Rows16<NT>::NK], int wv, f32x4 (&slice)[Rows16<NT>::TW]) {
-  constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK;
+template <int NT, int W>
+__device__ __forceinline__ void r16_own_slice(const R16Full<NT>& full, int wv, R16Slice<NT, W>& slice) {
+  constexpr int TW = Rows16<NT, W>::TW, NK = Rows16<NT, W>::NK;
 #pragma unroll
-  for (int ww = 0; ww < 4; ++ww)
+  for (int ww = 0; ww < W; ++ww)
     if (ww == wv) {
 #pragma unroll
       for (int i = 0; i < TW; ++i) slice[i] = full[ww * TW + i < NK ? ww * TW + i : NK - 1];   // past NK: never stored
@@ -1249,10 +1255,10 @@ __device__ __forceinline__ void r16_own_slice(const f32x4 (&full)[Rows16<NT>::NK
 // (row, h) mask line holds bit 4 q + e for feature 32 t + 8 q + 4 h + e: this lane owns q = 2 (ot & 1) + (g >> 1)
 // of line h = g & 1, the lane 32 further the other q of the same line.
 // DROP: inverted dropout after the relu; kb = the keep bits of this lane's (row, h = g & 1) line (drop_words).
-template <int NT, bool SAVE, bool DROP = false>
-__device__ __forceinline__ void r16_relu_save(f32x4 (&slice)[Rows16<NT>::TW], int lane, int t0, float* act_row, uint32_t* mask_line,
+template <int NT, int W, bool SAVE, bool DROP = false>
+__device__ __forceinline__ void r16_relu_save(R16Slice<NT, W>& slice, int lane, int t0, float* act_row, uint32_t* mask_line,
                                               const uint32_t* kb = nullptr, float scale = 1.f) {
-  constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK;
+  constexpr int TW = Rows16<NT, W>::TW, NK = Rows16<NT, W>::NK;
   const int g = lane >> 4;
 #pragma unroll
   for (int p = 0; p < TW / 2; ++p) {
@@ -1286,10 +1292,10 @@ __device__ __forceinline__ void r16_relu_save(f32x4 (&slice)[Rows16<NT>::TW], in
   }
 }
 
-template <int NT, bool SAVE, bool DROP>
-__global__ __launch_bounds__(256, 1) void k_mlp_fwd_rows16(FwdArgs a) {
-  constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK, Hp = 32 * NT, MW = mask_words(NT);
-  __shared__ __attribute__((aligned(16))) float lds[Rows16<NT>::LDS_BYTES / 4];
+template <int NT, bool SAVE, bool DROP, int W>
+__global__ __launch_bounds__(64 * W, 1) void k_mlp_fwd_rows16(FwdArgs a) {
+  constexpr int TW = Rows16<NT, W>::TW, NK = Rows16<NT, W>::NK, Hp = 32 * NT, MW = mask_words(NT);
+  __shared__ __attribute__((aligned(16))) float lds[Rows16<NT, W>::LDS_BYTES / 4];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t0 = wv * TW;
@@ -1334,21 +1340,21 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_rows16(FwdArgs a) {
         for (int i = 0; i < TW; ++i) acc[i] = MFMA16(w[i][e], b[e], acc[i]);
     }
   }
-  r16_relu_save<NT, SAVE>(acc, lane, t0, act_row, mask_line);
-  r16_exchange<NT>(lds, lane, t0, acc, A);
+  r16_relu_save<NT, W, SAVE>(acc, lane, t0, act_row, mask_line);
+  r16_exchange<NT, W>(lds, lane, t0, acc, A);
 
   // ---- residual blocks
   for (int blk = 0; blk < a.nb; ++blk) {
     const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
     uint32_t kb[MW];
     if (DROP) drop_words<NT>(a.drop, drop_q0, a.rows, a.hidden, blk, rl, g & 1, t0 >> 1, (t0 + TW) >> 1, kb);
-    r16_gemm<NT, true, true>((const f32x4*)(a.packed + a.L.w[l1]), a.packed + a.L.b[l1], lane, t0, A, acc);
-    r16_relu_save<NT, SAVE, DROP>(acc, lane, t0, act_row + l1 * act_stride, mask_line + l1 * mask_stride, kb, a.drop_scale);
-    r16_exchange<NT>(lds, lane, t0, acc, T);
-    r16_own_slice<NT>(A, wv, acc);                     // the residual stream is the accumulator of the second GEMM
-    r16_gemm<NT, false, true>((const f32x4*)(a.packed + a.L.w[l2]), a.packed + a.L.b[l2], lane, t0, T, acc);
-    r16_relu_save<NT, SAVE>(acc, lane, t0, act_row + l2 * act_stride, mask_line + l2 * mask_stride);
-    r16_exchange<NT>(lds, lane, t0, acc, A);
+    r16_gemm<NT, W, true, true>((const f32x4*)(a.packed + a.L.w[l1]), a.packed + a.L.b[l1], lane, t0, A, acc);
+    r16_relu_save<NT, W, SAVE, DROP>(acc, lane, t0, act_row + l1 * act_stride, mask_line + l1 * mask_stride, kb, a.drop_scale);
+    r16_exchange<NT, W>(lds, lane, t0, acc, T);
+    r16_own_slice<NT, W>(A, wv, acc);                  // the residual stream is the accumulator of the second GEMM
+    r16_gemm<NT, W, false, true>((const f32x4*)(a.packed + a.L.w[l2]), a.packed + a.L.b[l2], lane, t0, T, acc);
+    r16_relu_save<NT, W, SAVE>(acc, lane, t0, act_row + l2 * act_stride, mask_line + l2 * mask_stride);
+    r16_exchange<NT, W>(lds, lane, t0, acc, A);
   }
 
   // ---- final layer: output tiles round-robin over the waves
@@ -1357,7 +1363,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_rows16(FwdArgs a) {
     constexpr int S = 4 * NT;
     const __amdgpu_buffer_rsrc_t img = make_rsrc(a.packed + a.L.w[lf], (uint32_t)(a.L.OT * S) * 1024u);
     const __amdgpu_buffer_rsrc_t bimg = make_rsrc(a.packed + a.L.b[lf], (uint32_t)a.L.OT * 256u);
-    for (int ot = wv; ot < 2 * a.L.OT; ot += 4) {
+    for (int ot = wv; ot < 2 * a.L.OT; ot += W) {
       const f32x4 o = r16_gemm1<NT>(img, r16_tile_off(ot, S), lane, A, MFMA16(r16_bias(bimg, lane, ot), 1.f, zero4()));
       if (live) *(f32x4*)(a.y + row * a.ldy + 16 * ot + 4 * g) = o;
     }
@@ -1365,10 +1371,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_rows16(FwdArgs a) {
 }
 
 // relu backward on a slice (sign bits of that layer's saved activation), then its columns of the layer-gradient buffer
-template <int NT>
-__device__ __forceinline__ void r16_mask_store(f32x4 (&slice)[Rows16<NT>::TW], int lane, int t0, const uint32_t* mask_line,
+template <int NT, int W>
+__device__ __forceinline__ void r16_mask_store(R16Slice<NT, W>& slice, int lane, int t0, const uint32_t* mask_line,
                                                float scale, float* dact_row) {
-  constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK;
+  constexpr int TW = Rows16<NT, W>::TW, NK = Rows16<NT, W>::NK;
   const int g = lane >> 4;
 #pragma unroll
   for (int i = 0; i < TW; ++i) {
@@ -1382,10 +1388,10 @@ __device__ __forceinline__ void r16_mask_store(f32x4 (&slice)[Rows16<NT>::TW], i
   }
 }
 
-template <int NT>
-__global__ __launch_bounds__(256, 1) void k_mlp_bwd_rows16(BwdArgs a) {
-  constexpr int TW = Rows16<NT>::TW, NK = Rows16<NT>::NK, Hp = 32 * NT, MW = mask_words(NT);
-  __shared__ __attribute__((aligned(16))) float lds[Rows16<NT>::LDS_BYTES / 4];
+template <int NT, int W>
+__global__ __launch_bounds__(64 * W, 1) void k_mlp_bwd_rows16(BwdArgs a) {
+  constexpr int TW = Rows16<NT, W>::TW, NK = Rows16<NT, W>::NK, Hp = 32 * NT, MW = mask_words(NT);
+  __shared__ __attribute__((aligned(16))) float lds[Rows16<NT, W>::LDS_BYTES / 4];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t0 = wv * TW;
@@ -1427,24 +1433,24 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_rows16(BwdArgs a) {
         for (int i = 0; i < TW; ++i) acc[i] = MFMA16(w[i][e], b[e], acc[i]);
     }
   }
-  r16_mask_store<NT>(acc, lane, t0, mask_line + (lf - 1) * mask_stride, 1.f, dact_row + (lf - 1) * act_stride);
-  r16_exchange<NT>(lds, lane, t0, acc, dA);
+  r16_mask_store<NT, W>(acc, lane, t0, mask_line + (lf - 1) * mask_stride, 1.f, dact_row + (lf - 1) * act_stride);
+  r16_exchange<NT, W>(lds, lane, t0, acc, dA);
 
   for (int blk = a.nb - 1; blk >= 0; --blk) {
     const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
-    r16_gemm<NT, true, false>((const f32x4*)(a.packed + a.L.wt[l2]), nullptr, lane, t0, dA, acc);
-    r16_mask_store<NT>(acc, lane, t0, mask_line + l1 * mask_stride, dscale, dact_row + l1 * act_stride);
-    r16_exchange<NT>(lds, lane, t0, acc, dT);
-    r16_own_slice<NT>(dA, wv, acc);                                         // skip path
-    r16_gemm<NT, false, false>((const f32x4*)(a.packed + a.L.wt[l1]), nullptr, lane, t0, dT, acc);
-    r16_mask_store<NT>(acc, lane, t0, mask_line + (l1 - 1) * mask_stride, 1.f, dact_row + (l1 - 1) * act_stride);
-    r16_exchange<NT>(lds, lane, t0, acc, dA);
+    r16_gemm<NT, W, true, false>((const f32x4*)(a.packed + a.L.wt[l2]), nullptr, lane, t0, dA, acc);
+    r16_mask_store<NT, W>(acc, lane, t0, mask_line + l1 * mask_stride, dscale, dact_row + l1 * act_stride);
+    r16_exchange<NT, W>(lds, lane, t0, acc, dT);
+    r16_own_slice<NT, W>(dA, wv, acc);                                      // skip path
+    r16_gemm<NT, W, false, false>((const f32x4*)(a.packed + a.L.wt[l1]), nullptr, lane, t0, dT, acc);
+    r16_mask_store<NT, W>(acc, lane, t0, mask_line + (l1 - 1) * mask_stride, 1.f, dact_row + (l1 - 1) * act_stride);
+    r16_exchange<NT, W>(lds, lane, t0, acc, dA);
   }
 
   if (a.dx) {
     constexpr int S = 4 * NT;
     const __amdgpu_buffer_rsrc_t img = make_rsrc(a.packed + a.L.wt[0], (uint32_t)(a.L.T_in * S) * 1024u);
-    for (int it = wv; it < 2 * a.L.T_in; it += 4) {
+    for (int it = wv; it < 2 * a.L.T_in; it += W) {
       const f32x4 o = r16_gemm1<NT>(img, r16_tile_off(it, S), lane, dA, zero4());
       if (live) *(f32x4*)(a.dx + row * a.lddx + 16 * it + 4 * g) = o;
     }
@@ -1738,7 +1744,7 @@ template <int NT, bool SAVE, bool DROP>
 static void launch_fwd_family(int family, const FwdArgs& a, hipStream_t st) {
   const int64_t n = a.row_end - a.row_begin;
   if (family == FAM_ROWS16)
-    hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, SAVE, DROP>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, SAVE, DROP, 4>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, a);
   else if (family == FAM_COOP)
     hipLaunchKernelGGL((k_mlp_fwd_coop<NT, SAVE, DROP>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, a);
   else
@@ -1785,7 +1791,7 @@ static int launch_bwd(const BwdArgs& a0, hipStream_t st) {
     a.row_begin = seg[i].begin; a.row_end = seg[i].end;
     const int64_t m = a.row_end - a.row_begin;
     if (seg[i].family == FAM_ROWS16)
-      hipLaunchKernelGGL((k_mlp_bwd_rows16<NT>), dim3((unsigned)((m + 15) / 16)), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_mlp_bwd_rows16<NT, 4>), dim3((unsigned)((m + 15) / 16)), dim3(256), 0, st, a);
     else if (seg[i].family == FAM_COOP)
       hipLaunchKernelGGL((k_mlp_bwd_coop<NT>), dim3((unsigned)((m + 31) / 32)), dim3(256), 0, st, a);
     else
@@ -1803,10 +1809,10 @@ static int launch_fwd_wide(const FwdArgs& a0, hipStream_t st) {
   a.row_begin = 0; a.row_end = a.rows;
   const unsigned tiles = (unsigned)((a.rows + 15) / 16);
   const bool drop = a.drop.mode != DROP_OFF;
-  if (a.acts && drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, true>), dim3(tiles), dim3(256), 0, st, a);
-  else if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, false>), dim3(tiles), dim3(256), 0, st, a);
-  else if (drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, true>), dim3(tiles), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, false>), dim3(tiles), dim3(256), 0, st, a);
+  if (a.acts && drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, true, 4>), dim3(tiles), dim3(256), 0, st, a);
+  else if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, false, 4>), dim3(tiles), dim3(256), 0, st, a);
+  else if (drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, true, 4>), dim3(tiles), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, false, 4>), dim3(tiles), dim3(256), 0, st, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
@@ -1815,7 +1821,7 @@ template <int NT>
 static int launch_bwd_wide(const BwdArgs& a0, hipStream_t st) {
   BwdArgs a = a0;
   a.row_begin = 0; a.row_end = a.rows;
-  hipLaunchKernelGGL((k_mlp_bwd_rows16<NT>), dim3((unsigned)((a.rows + 15) / 16)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((k_mlp_bwd_rows16<NT, 4>), dim3((unsigned)((a.rows + 15) / 16)), dim3(256), 0, st, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }

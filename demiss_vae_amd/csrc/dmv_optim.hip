@@ -115,7 +115,7 @@ __device__ __forceinline__ void image_store(const DmvPackMap& pm, int i, float v
 }
 
 __global__ void k_opt_apply(OptTable t, OptGroups gr, int n_partials, float max_norm, const float* __restrict__ partial,
-                            float* norm_out, const DmvPackMap* __restrict__ pack_map) {
+                            float* norm_out, const DmvPackMap* __restrict__ pack_map, uint64_t* counter, uint64_t counter_add) {
   __shared__ float red[4];
   __shared__ float sh[3];      // clip coefficient, lr / (1 - b1^t), sqrt(1 - b2^t)
   __shared__ __attribute__((aligned(16))) float turn[kQuarter];
@@ -136,6 +136,7 @@ __global__ void k_opt_apply(OptTable t, OptGroups gr, int n_partials, float max_
         if (norm_out && blockIdx.x == 0) norm_out[0] = norm;
         coef = fminf(max_norm / (norm + 1e-6f), 1.f);
       }
+      if (counter && blockIdx.x == 0) counter[0] += counter_add;   // nothing else in this launch reads it
       const double sd = (double)gr.step[gi][0];                         // already advanced for this step
       sh[0] = coef;
       sh[1] = gr.lr[gi][0] / (float)(1.0 - pow(gr.beta1d[gi], sd));     // double, like torch's host-side scalars
@@ -224,7 +225,8 @@ extern "C" size_t dmv_opt_ws_floats(int32_t n, const int64_t* numel) {
 static int adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
                      const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm,
-                     float* ws, float* norm_out, const DmvPackMap* pack_map, void* stream) {
+                     float* ws, float* norm_out, const DmvPackMap* pack_map, uint64_t* counter, uint64_t counter_add,
+                     void* stream) {
   OptTable t;
   t.n = n;
   int chunks = 0;
@@ -261,7 +263,7 @@ static int adam_step(int32_t n, float* const* params, const float* const* grads,
   else hipLaunchKernelGGL(k_opt_tick, dim3(1), dim3(1), 0, s, gr);
   DMV_HIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_opt_apply, dim3((unsigned)(kSub * chunks)), dim3(kQuarter / 4), 0, s, t, gr, kSub * chunks, max_norm,
-                     partial, norm_out, pack_map);
+                     partial, norm_out, pack_map, counter, counter_add);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
@@ -277,13 +279,14 @@ static int check_tables(int32_t n, float* const* params, const float* const* gra
 extern "C" int dmv_opt_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
                                  float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
                                  const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm,
-                                 float* ws, size_t ws_floats, float* norm_out, const DmvPackMap* pack_map, void* stream) {
+                                 float* ws, size_t ws_floats, float* norm_out, const DmvPackMap* pack_map, uint64_t* counter,
+                                 uint64_t counter_add, void* stream) {
   const int rc = check_tables(n, params, grads, exp_avg, exp_avg_sq, numel, group_of, n_groups, groups);
   if (rc) return rc;
   if (!ws) return DMV_E_BADARG;
   if (ws_floats < dmv_opt_ws_floats(n, numel) || dmv_opt_ws_floats(n, numel) == 0) return DMV_E_WORKSPACE;
   return adam_step(n, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq, numel, group_of, n_groups, groups, max_norm,
-                   ws, norm_out, pack_map, stream);
+                   ws, norm_out, pack_map, counter, counter_add, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -323,7 +326,7 @@ extern "C" int dmv_opt_adam_step_static(int32_t n, float* const* params, const f
                                         float* const* exp_avg, float* const* exp_avg_sq, float* const* max_exp_avg_sq,
                                         const int64_t* numel, const int32_t* group_of, int32_t n_groups,
                                         const DmvAdamGroup* groups, float max_norm, float* norm_out,
-                                        const DmvPackMap* pack_map, void* stream) {
+                                        const DmvPackMap* pack_map, uint64_t* counter, uint64_t counter_add, void* stream) {
   const int rc = check_tables(n, params, grads, exp_avg, exp_avg_sq, numel, group_of, n_groups, groups);
   if (rc) return rc;
   const size_t need = dmv_opt_ws_floats(n, numel);
@@ -335,5 +338,5 @@ extern "C" int dmv_opt_adam_step_static(int32_t n, float* const* params, const f
   // nothing in the array has to start at zero: k_opt_sumsq writes every partial sum k_opt_apply reads, on the same
   // stream
   return adam_step(n, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq, numel, group_of, n_groups, groups, max_norm,
-                   ws, norm_out, pack_map, stream);
+                   ws, norm_out, pack_map, counter, counter_add, stream);
 }

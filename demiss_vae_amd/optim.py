@@ -13,6 +13,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
+from . import rng
 
 
 class Adam(torch.optim.Optimizer):
@@ -132,8 +133,11 @@ class Adam(torch.optim.Optimizer):
             pick = lambda arr, ctype: (ctype * n)(*[arr[i] for i in live])
             P_, M_, V_, X_ = (pick(b[k], L._P) for k in ("p", "m", "v", "vmax"))
             numel, group_of = pick(b["numel"], C.c_int64), pick(b["group_of"], C.c_int32)
+        # inside a recording the update kernel also advances the device-resident Philox counter by the step's draws
+        bump = rng.advance_in_kernel()
         L.check(L.lib().dmv_opt_adam_step(n, P_, L.ptr_array(grads), M_, V_, X_, numel, group_of, len(self.param_groups),
                                           b["groups"], self._clip, L.ptr(b["ws"]), b["ws_floats"], L.ptr(self.grad_norm),
-                                          L.ptr(pack_map), L.stream_ptr()))
+                                          L.ptr(pack_map), C.c_void_p(bump[0]) if bump else None, bump[1] if bump else 0,
+                                          L.stream_ptr()))
         self._clip = 0.0
         return loss

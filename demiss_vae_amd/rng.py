@@ -45,7 +45,8 @@ def next_offset(n: int):
     if _capture is not None:
         off = _capture.used
         _capture.used += n4
-        return _capture.seed(_seed), off
+        # (a kernel of the recording may already have advanced the device counter by `bumped`: see advance_in_kernel)
+        return _capture.seed(_seed), off - _capture.bumped
     off = _offset
     _offset += n4
     return _seed, off
@@ -57,11 +58,25 @@ def base_ptr():
     return _capture.counter.data_ptr() if _capture is not None else None
 
 
+def advance_in_kernel():
+    """For a kernel of the recording that can add to the device counter on the side (the optimiser's update kernel):
+    (address of the counter, amount) covering the draws recorded so far, or None outside recordings / when nothing
+    is owed.  The caller must make exactly one thread add the amount; draws recorded later are handed offsets relative
+    to the advanced counter, and leaving the recording adds only what is still owed - usually nothing, which saves the
+    step a launch."""
+    c = _capture
+    if c is None or c.used == c.bumped:
+        return None
+    owed, c.bumped = c.used - c.bumped, c.used
+    return c.counter.data_ptr(), owed
+
+
 class CaptureStream:
     def __init__(self, device):
         self.counter = torch.zeros(1, dtype=torch.int64, device=device)
         self.id = next(_ids)
         self.used = 0
+        self.bumped = 0
 
     def seed(self, base_seed):
         return (base_seed ^ (0xD1B54A32D192ED03 * self.id)) & _MASK
@@ -69,12 +84,12 @@ class CaptureStream:
     def __enter__(self):
         global _capture
         assert _capture is None, "recordings do not nest"
-        _capture, self.used = self, 0
+        _capture, self.used, self.bumped = self, 0, 0
         return self
 
     def __exit__(self, *exc):
         global _capture
         _capture = None
-        if self.used and exc[0] is None:
-            self.counter.add_(self.used)     # recorded with the step: advances on every replay
+        if self.used > self.bumped and exc[0] is None:
+            self.counter.add_(self.used - self.bumped)     # recorded with the step: advances on every replay
         return False

@@ -357,7 +357,9 @@ int dmv_grid_divergences(int32_t gen_dist, int32_t D, int32_t Zd, int64_t Nz, co
  * The pointers are passed to the kernels by value: a step recorded in a HIP graph replays without host copies.
  * pack_map: NULL, or n entries in device memory (dmv_mlp_pack_map fills them on the host; copy them over once): where
  * tensor i lives in its network's fragment image.  The step then also writes every new parameter value into the
- * image (entries with image == NULL are skipped), so a forward pass after the step needs no dmv_mlp_pack. */
+ * image (entries with image == NULL are skipped), so a forward pass after the step needs no dmv_mlp_pack.
+ * counter, counter_add: NULL / 0, or a device counter to which the step adds counter_add on the side (the Philox
+ * offset_base of a recorded step: advancing it here saves the step a launch). */
 typedef struct DmvPackMap {
   float* image;              /* the network's fragment image (dmv_mlp_pack's `packed`); NULL: not part of one */
   int64_t fwd_off, tr_off;   /* floats: forward and transposed fragment sets of a weight; bias fragments in fwd_off */
@@ -378,7 +380,8 @@ size_t dmv_opt_ws_floats(int32_t n, const int64_t* numel);
 int dmv_opt_adam_step(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
                       const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm, float* ws,
-                      size_t ws_floats, float* norm_out, const DmvPackMap* pack_map, void* stream);
+                      size_t ws_floats, float* norm_out, const DmvPackMap* pack_map, uint64_t* counter, uint64_t counter_add,
+                      void* stream);
 
 /* dmv_opt_adam_step for callers that cannot allocate device memory or bring a workspace (code running under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments
@@ -394,7 +397,8 @@ int dmv_opt_adam_step(int32_t n, float* const* params, const float* const* grads
 int dmv_opt_adam_step_static(int32_t n, float* const* params, const float* const* grads, float* const* exp_avg,
                              float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
                              const int32_t* group_of, int32_t n_groups, const DmvAdamGroup* groups, float max_norm,
-                             float* norm_out, const DmvPackMap* pack_map, void* stream);
+                             float* norm_out, const DmvPackMap* pack_map, uint64_t* counter, uint64_t counter_add,
+                             void* stream);
 
 #ifdef __cplusplus
 }

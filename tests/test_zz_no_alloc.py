@@ -36,12 +36,12 @@ def _step(static, sizes, tensors, max_norm, step0):
     X_ = L.ptr_array(xs) if xs is not None else None
     if static:
         rc = lib.dmv_opt_adam_step_static(n, L.ptr_array(ps), L.ptr_array(gs), L.ptr_array(ms), L.ptr_array(vs), X_, numel,
-                                          group_of, 2, groups, max_norm, L.ptr(norm), None, L.stream_ptr())
+                                          group_of, 2, groups, max_norm, L.ptr(norm), None, None, 0, L.stream_ptr())
     else:
         wsf = lib.dmv_opt_ws_floats(n, numel)
         ws = torch.empty(wsf, dtype=torch.float32, device="cuda")
         rc = lib.dmv_opt_adam_step(n, L.ptr_array(ps), L.ptr_array(gs), L.ptr_array(ms), L.ptr_array(vs), X_, numel,
-                                   group_of, 2, groups, max_norm, L.ptr(ws), wsf, L.ptr(norm), None, L.stream_ptr())
+                                   group_of, 2, groups, max_norm, L.ptr(ws), wsf, L.ptr(norm), None, None, 0, L.stream_ptr())
     assert rc == 0, rc
     torch.cuda.synchronize()
     return ps, ms, vs, xs, norm, step
@@ -79,6 +79,6 @@ def test_static_workspace_rejects_sizes_beyond_its_array():
     group_of = (C.c_int32 * n)(*[0] * n)
     groups = (L.DmvAdamGroup * 1)()
     groups[0] = L.DmvAdamGroup(256, 256, 0.9, 0.999, 1e-8)
-    rc = lib.dmv_opt_adam_step_static(n, fake, fake, fake, fake, None, numel, group_of, 1, groups, 1.0, None, None, None)
+    rc = lib.dmv_opt_adam_step_static(n, fake, fake, fake, fake, None, numel, group_of, 1, groups, 1.0, None, None, None, 0, None)
     assert rc == -3                              # DMV_E_WORKSPACE
     assert b"workspace" in lib.dmv_strerror(rc).lower()
