@@ -387,6 +387,64 @@ class _RunLogger:
         return self.log_dir
 
 
+class _ValRunner:
+    """Validation steps replayed from recordings like training steps, one recording per batch shape, for the model
+    classes whose validation step is just the bound of the batch (the step functions named in _PLAIN_VALIDATION: a
+    subclass that overrides validation_step - grid marginals, FID, imputation updates - runs eagerly as before).  Noise
+    stays fresh through the recording's device-resident Philox counter; the logged values are the recording's static
+    outputs, summed into the epoch means right after each replay."""
+
+    def __init__(self, model, use_graph, log=print):
+        self.model, self.log = model, log
+        self.ok = bool(use_graph) and getattr(type(model), "validation_step", None) in _plain_validation_steps()
+        self.seen, self.graphs, self.static, self.eager_keys = {}, {}, {}, set()
+        self.replays = 0
+
+    def __call__(self, batch, i):
+        m = self.model
+        if not self.ok:
+            return m.validation_step(batch, i)
+        key = tuple(batch[0].shape)
+        n = self.seen.get(key, 0)
+        self.seen[key] = n + 1
+        if n < 1 or key in self.eager_keys:
+            return m.validation_step(batch, i)
+        if key not in self.graphs:
+            from .graph import GraphedStep
+            static = tuple(t if getattr(t, "_dmv_persistent", False) else t.clone() for t in batch)
+            nets = tuple(m.engine()[1:])
+            logged = {}
+
+            def body():
+                m._logged = logged
+                logged.clear()
+                with torch.no_grad():
+                    m.validation_step(static, 0)
+            try:
+                self.graphs[key] = GraphedStep(body, nets=nets, warmup=0)
+            except Exception as e:
+                self.log(f"[run] validation step not recordable ({type(e).__name__}: {e}); runs eagerly")
+                self.eager_keys.add(key)
+                torch.cuda.synchronize()
+                return m.validation_step(batch, i)
+            self.static[key] = (static, logged)
+        static, logged = self.static[key]
+        for dst, src in zip(static, batch):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        self.graphs[key]()
+        self.replays += 1
+        m._logged = dict(logged)
+
+
+def _plain_validation_steps():
+    from vgiwae.models.vae import VAE
+    from vgiwae.models.iwae import IWAE
+    from vgiwae.models.multiple_vae import MultipleVAE
+    from vgiwae.models.multiple_iwae import MultipleIWAE
+    return {VAE.validation_step, IWAE.validation_step, MultipleVAE.validation_step, MultipleIWAE.validation_step}
+
+
 def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None, log_dir=None):
     from . import rng
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1))
@@ -414,9 +472,11 @@ def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None, log_dir=No
     use_graph = bool(trainer_cfg.get("hip_graph", True)) and getattr(inner, "fused", False) \
         and (P.world() == 1 or model.automatic_optimization or hasattr(model, "finish_manual_update"))
     run_step = _StepRunner(model, opt, sched, params, clip_val, clip_alg, use_graph, log=log)
+    run_val = _ValRunner(model, use_graph and getattr(inner, "fused", False), log=log)
     if use_graph and hasattr(train_loader, "reuse_buffers"):
         train_loader.reuse_buffers = True          # each batch is consumed by its step before the next is drawn
     model.on_train_start()
+    val_loader = None
     step, epoch, history, t0 = 0, 0, [], time.time()
     done = False
     while not done and (max_epochs in (None, -1) or epoch < max_epochs):
@@ -443,10 +503,14 @@ def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None, log_dir=No
         model.eval()
         model._logged = {}
         vmeans = _Means()
+        if val_loader is None or not run_val.ok:
+            val_loader = datamodule.val_dataloader()
+            if run_val.ok and hasattr(val_loader, "reuse_buffers"):
+                val_loader.reuse_buffers = True      # one loader for the whole run: its batch tensors are the recordings' inputs
         with torch.no_grad():
-            for i, batch in enumerate(datamodule.val_dataloader()):
+            for i, batch in enumerate(val_loader):
                 model._logged = {}
-                model.validation_step(batch, i)
+                run_val(batch, i)
                 vmeans.add(model._logged)
         model.on_validation_epoch_end()
         row = {"epoch": epoch, "step": step, "time_s": round(time.time() - t0, 2), **means.result(), **vmeans.result()}
@@ -460,7 +524,7 @@ def fit(model, datamodule, trainer_cfg, log=print, checkpointer=None, log_dir=No
     if checkpointer is not None:
         checkpointer.on_train_end(epoch, step)
     trainer.hip_graph_replays = run_step.replays
-    summary = {"steps": step, "hip_graph_replays": run_step.replays}
+    summary = {"steps": step, "hip_graph_replays": run_step.replays, "validation_replays": run_val.replays}
     if P.world() > 1:
         # replicas must hold identical parameters: largest difference between any two ranks
         import torch.distributed as dist

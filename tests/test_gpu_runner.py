@@ -496,3 +496,21 @@ def test_other_model_families_through_the_runner(workdir, family):
     assert len(history) == 3 and all(math.isfinite(v) for row in history for v in row.values())
     better = (lambda a, b: a < b) if metric.startswith("loss") else (lambda a, b: a > b)
     assert better(history[-1][metric], history[0][metric]), [r[metric] for r in history]
+
+
+def test_validation_steps_replay_and_agree_with_eager_validation(workdir):
+    """Validation steps of the plain bound classes are replayed from recordings (every batch shape runs eagerly
+    once first); the validation bound of such a run agrees with a run whose steps all execute eagerly (other noise
+    streams, same model and data: agreement to Monte-Carlo and trajectory noise)."""
+    rows = {}
+    for tag, extra in (("replayed", ()), ("eager", ("--trainer.hip_graph", "false"))):
+        text = IWAE_CONFIG.replace("logs/toy/iwae_i5", f"logs/toy/iwae_val_{tag}")
+        history, _, lines = launch(workdir, f"iwae_val_{tag}", text, *extra, min_replays=lambda steps: 0)
+        summary = [json.loads(l) for l in lines if str(l).startswith('{"steps"')][0]
+        rows[tag] = (history, summary)
+    assert rows["eager"][1]["validation_replays"] == 0 and rows["eager"][1]["hip_graph_replays"] == 0
+    epochs = len(rows["replayed"][0])
+    val_batches = math.ceil(300 / 128)              # (fewer rows after the fully-missing filter never change the count here)
+    assert rows["replayed"][1]["validation_replays"] >= (epochs - 1) * (val_batches - 1)
+    a, b = rows["replayed"][0][-1]["elbo/val"], rows["eager"][0][-1]["elbo/val"]
+    assert math.isfinite(a) and abs(a - b) < 0.3, (a, b)
