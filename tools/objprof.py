@@ -37,6 +37,15 @@ if which == "gas":
     X = rn(B, D)
     M = (torch.rand(B, D, device=dev, generator=g) < 0.5).to(torch.uint8)
     q_kind, mix_C = L.Q_OWN, 1
+elif which == "mb":
+    # MissSIWAE on UCI-miniboone shapes: stratified mixture of 5 Gaussians, one sample per component
+    B, G, I, D, Zd, ldE, ldD = 8192, 5, 1, 43, 32, 352, 96
+    gen, P = "normal_with_eps", 86
+    cfg.x_per_component = 0
+    cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, Zd, G * Zd, 2 * G * Zd
+    X = rn(B, D)
+    M = (torch.rand(B, D, device=dev, generator=g) < 0.5).to(torch.uint8)
+    q_kind, mix_C = L.Q_STRATIFIED, G
 else:
     B, G, I, D, Zd, ldE, ldD = 8192, 5, 1, 784, 50, 128, 784
     gen, P = "bern_m1_p1", 784
@@ -49,6 +58,8 @@ cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, G, 1, I, D, Zd
 cfg.gen_dist, cfg.q_eps = L.GEN[gen], 1
 N = B * G * I
 enc = rn(B * G if which == "bern" else B, ldE)
+comp_lp = torch.empty(N, G, device=dev) if which == "mb" else None
+dlogit = torch.empty(B, G, device=dev) if which == "mb" else None
 dec = rn(N, ldD)
 Z = torch.empty(N, Zd, device=dev)
 eps = torch.empty(N, Zd, device=dev)
@@ -56,6 +67,7 @@ wgt = torch.empty(N, device=dev)
 per_b = torch.empty(B, device=dev)
 mean = torch.empty((), device=dev)
 objA, objB = torch.empty(B, G, device=dev), torch.empty(B, G, device=dev)
+terms = torch.empty(5, N, device=dev) if which == "mb" else None
 d_dec = torch.empty(N, ldD, device=dev)
 ldz_pad = 32 * ((Zd + 31) // 32)
 dZ = rn(N, ldz_pad)
@@ -73,6 +85,10 @@ def forward():
     if which == "gas":
         f.kind = L.BOUND_LSE
         f.bound, f.wgt = L.addr(per_b), L.addr(wgt)
+    elif which == "mb":
+        f.kind, f.use_logpi = L.BOUND_LSE, 1
+        f.bound, f.wgt, f.comp_lp, f.dlogit = L.addr(per_b), L.addr(wgt), L.addr(comp_lp), L.addr(dlogit)
+        f.terms = L.addr(terms)
     else:
         f.kind = L.BOUND_PER_COMPONENT
         f.coefA = (C.c_float * 5)(1, 0, 1, 0, -1)
@@ -82,7 +98,7 @@ def forward():
 
 
 def bwd_dec():
-    L.check(lib.dmv_obj_backward_dec(C.byref(cfg), L.ptr(dec), ldD, L.ptr(X), L.ptr(M), L.ptr(wgt) if which == "gas" else None,
+    L.check(lib.dmv_obj_backward_dec(C.byref(cfg), L.ptr(dec), ldD, L.ptr(X), L.ptr(M), L.ptr(wgt) if which != "bern" else None,
                                      None, L.ptr(gs), 1.0 / B, 0.0, L.ptr(d_dec), ldD, st))
 
 
@@ -90,6 +106,12 @@ def bwd_latent():
     p = L.DmvLatentBwd()
     p.base_prior, p.base_qown, p.base_qmix, p.base_w, p.kl_coef = 1.0 / B, -1.0 / B, 0.0, 1.0, 0.0
     p.own_live, p.mix_live, p.use_zscale, p.mix_kind = 0, 0, 0, L.Q_OWN
+    if which == "mb":       # the MissSIWAE step with STL: prior and mixture-q terms, mixture parameters detached
+        p.base_qown, p.base_qmix, p.mix_kind = 0.0, -1.0 / B, L.Q_STRATIFIED
+        L.check(lib.dmv_obj_backward_latent(C.byref(cfg), C.byref(p), L.ptr(enc), L.ptr(Z), L.ptr(eps), Zd, L.ptr(dZ), ldz_pad,
+                                            L.ptr(wgt), None, None, L.ptr(comp_lp), L.ptr(terms[4]), L.ptr(dlogit), None, L.ptr(gs),
+                                            L.ptr(d_enc), st))
+        return
     L.check(lib.dmv_obj_backward_latent(C.byref(cfg), C.byref(p), L.ptr(enc), L.ptr(Z), L.ptr(eps), Zd, L.ptr(dZ), ldz_pad,
                                         L.ptr(wgt) if which == "gas" else None, None, None, None, None, None, None, L.ptr(gs),
                                         L.ptr(d_enc), st))
@@ -97,6 +119,8 @@ def bwd_latent():
 
 rows_enc = enc.shape[0]
 xm = X.numel() * 5
+if which == "mb":
+    sample = lambda: (Z.normal_(generator=g), eps.normal_(generator=g))      # (component-wise sampling is not what is looked at here)
 nbytes = {
     "k_latent_sample": rows_enc * 2 * Zd * 4 + 2 * N * Zd * 4,
     "k_obj_fwd": N * (P + Zd) * 4 + xm + rows_enc * 2 * Zd * 4 + (N * 4 + B * 4 if which == "gas" else 2 * B * G * 4),
