@@ -109,6 +109,7 @@ SIGNATURES = {
     "dmv_grid_divergences": (C.c_int, [_I32, _I32, _I32, _I64, _P, _P, _P, _F, _I32, _P, _P, _P, _I32, _P, _P, _P, _P]),
     "dmv_lse_update": (C.c_int, [_I32, _I64, _P, _I32, _P, _P, _P]),
     "dmv_rows_gather": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "dmv_rows_gather_multi": (C.c_int, [_I32, _P, _P, _P, _P, _I64, _P]),
     "dmv_rows_scatter": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "dmv_impute_tail": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _P, _P, _P, _U64, _U64, _P, _P, _P, _I32, _P, _P, _P, _P]),
     "dmv_categorical_draw": (C.c_int, [_I32, _I32, _I32, _P, _P, _U64, _U64, _P, _P, _P]),

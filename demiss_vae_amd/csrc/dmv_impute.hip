@@ -230,6 +230,54 @@ static inline unsigned grid_for(int64_t work, int block, unsigned cap = 8192) {
   return (unsigned)(g > cap ? cap : g);
 }
 
+// Rows `sel[i]` of up to four arrays at once (the arrays of a data split: data, mask, targets, indices), each array
+// with its own row length in bytes: what a batch of the device loader is.  One thread moves one 4-byte word (rows
+// whose length and addresses are multiples of 4) or one byte.
+struct GatherMulti {
+  int n_arrays;
+  const uint8_t* src[4];
+  uint8_t* dst[4];
+  int64_t row_bytes[4];
+  int64_t first[5];       // prefix sums of the arrays' units (words or bytes) per row
+  int word[4];            // 1: the array moves as 4-byte words
+};
+
+__global__ void k_rows_gather_multi(GatherMulti g, const int64_t* __restrict__ sel, int64_t n_rows) {
+  const int64_t per_row = g.first[g.n_arrays];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows * per_row; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / per_row, u = i - row * per_row;
+    int k = 0;
+    while (k + 1 < g.n_arrays && u >= g.first[k + 1]) ++k;
+    const int64_t off = u - g.first[k], from = sel[row];
+    if (g.word[k])
+      ((uint32_t*)(g.dst[k] + row * g.row_bytes[k]))[off] = ((const uint32_t*)(g.src[k] + from * g.row_bytes[k]))[off];
+    else
+      g.dst[k][row * g.row_bytes[k] + off] = g.src[k][from * g.row_bytes[k] + off];
+  }
+}
+
+extern "C" int dmv_rows_gather_multi(int32_t n_arrays, const void* const* src, void* const* dst, const int64_t* row_bytes,
+                                     const int64_t* sel, int64_t n_rows, void* stream) {
+  if (n_arrays < 1 || n_arrays > 4 || !src || !dst || !row_bytes || !sel || n_rows < 0) return DMV_E_BADARG;
+  if (n_rows == 0) return DMV_OK;
+  GatherMulti g;
+  g.n_arrays = n_arrays;
+  g.first[0] = 0;
+  for (int k = 0; k < 4; ++k) {
+    const bool live = k < n_arrays;
+    if (live && (!src[k] || !dst[k] || row_bytes[k] < 1)) return DMV_E_BADARG;
+    g.src[k] = live ? (const uint8_t*)src[k] : nullptr;
+    g.dst[k] = live ? (uint8_t*)dst[k] : nullptr;
+    g.row_bytes[k] = live ? row_bytes[k] : 0;
+    g.word[k] = live && (row_bytes[k] & 3) == 0 && (((uintptr_t)src[k] | (uintptr_t)dst[k]) & 3) == 0;
+    g.first[k + 1] = g.first[k] + (live ? (g.word[k] ? row_bytes[k] / 4 : row_bytes[k]) : 0);
+  }
+  hipLaunchKernelGGL(k_rows_gather_multi, dim3(grid_for(n_rows * g.first[n_arrays], 256)), dim3(256), 0, (hipStream_t)stream, g, sel,
+                     n_rows);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
 extern "C" int dmv_rows_gather(const float* src, const int64_t* idx, int64_t n, int32_t D, float* dst, void* stream) {
   if (!src || !idx || !dst || n < 0 || D < 1) return DMV_E_BADARG;
   if (n == 0) return DMV_OK;

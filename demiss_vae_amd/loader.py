@@ -33,6 +33,21 @@ class DeviceLoader:
         # asking for the next
         self.reuse_buffers = False
         self._bufs = None
+        self._row_bytes = None
+
+    def _gather(self, sel, out):
+        """rows `sel` of every array of the split into `out`: one launch for the whole batch tuple on the GPU"""
+        if not self.arrays[0].is_cuda or len(self.arrays) > 4:
+            for a, b in zip(self.arrays, out):
+                torch.index_select(a, 0, sel, out=b)
+            return
+        import ctypes as C
+        from . import _lib as L
+        if self._row_bytes is None:
+            self._row_bytes = (C.c_int64 * len(self.arrays))(*[a[0].numel() * a.element_size() for a in self.arrays])
+            self._src = L.ptr_array(self.arrays)
+        L.check(L.lib().dmv_rows_gather_multi(len(self.arrays), self._src, L.ptr_array(out), self._row_bytes, L.ptr(sel),
+                                              sel.shape[0], L.stream_ptr()))
 
     def __len__(self):
         return self.n // self.batch_size if self.drop_last else (self.n + self.batch_size - 1) // self.batch_size
@@ -49,8 +64,9 @@ class DeviceLoader:
                     self._bufs = tuple(a.new_empty((self.batch_size,) + tuple(a.shape[1:])) for a in self.arrays)
                     for b in self._bufs:
                         b._dmv_persistent = True
-                for a, b in zip(self.arrays, self._bufs):
-                    torch.index_select(a, 0, sel, out=b)
+                self._gather(sel, self._bufs)
                 yield self._bufs
             else:
-                yield tuple(a.index_select(0, sel) for a in self.arrays)
+                out = tuple(a.new_empty((sel.shape[0],) + tuple(a.shape[1:])) for a in self.arrays)
+                self._gather(sel, out)
+                yield out

@@ -301,6 +301,11 @@ int dmv_lse_update(int32_t B, int64_t Kc, const float* terms, int32_t q_term /* 
  * Persistent imputation buffer rows (vgiwae/utils/imputation_distribution.py:145-157 gather,
  * :180-187 scatter).  idx: int64 row numbers; rows are D floats.  Bit-exact copies. */
 int dmv_rows_gather(const float* src, const int64_t* idx, int64_t n, int32_t D, float* dst, void* stream);
+/* Rows sel[i] of up to four arrays at once (the arrays of a data split - data, mask, targets, indices - each with its
+ * own row length in bytes): one launch builds the whole batch tuple that the reference's DataLoader collates on the
+ * host (vgiwae/data/missing_data_module.py:289-312).  dst[k] receives n_rows rows of row_bytes[k] bytes. */
+int dmv_rows_gather_multi(int32_t n_arrays, const void* const* src, void* const* dst, const int64_t* row_bytes,
+                          const int64_t* sel, int64_t n_rows, void* stream);
 int dmv_rows_scatter(float* dst, const int64_t* idx, int64_t n, int32_t D, const float* src, void* stream);
 
 /* Sampling tail of one imputation iteration for N = B*K rows (vgiwae/shared/vae_imputation.py:38-52
