@@ -100,7 +100,7 @@ def iwae_step(device, B, I=5, *, name="UCI-gas", D=8, Zd=16, enc_shape=(16, 32, 
             "samples_per_s": round(B * I / t, 1), "step_tflops": round(flops / t / 1e12, 2)}
 
 
-def demiss_toy_step(device, B=4096, K=5):
+def demiss_toy_step(device, B=4096, K=5, parts=False):
     """toy_mog2_large DeMissVAE (configs/toy_mog2_large/compare/mis50/mvb2vae_lairdmisr0_k5_stl_mlp.yaml shapes:
     D=5, Zd=2, encoder (5,4,3,200), decoder (2,10,3,200), K=5 imputations, LAIR I=1 r=0 T=1, mvb2 + STL):
     gather from the device buffer -> LAIR update with write-back -> two objectives -> two backward calls -> Adam."""
@@ -112,24 +112,42 @@ def demiss_toy_step(device, B=4096, K=5):
     buf = imp.ImputationBuffer(X, K, device)
     Mdev = M.to(device)
     params = enc.params() + dec.params()
-    opt = Adam(params, lr=1e-3, amsgrad=True)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(0)
+    opt = Adam(params, lr=1e-3, amsgrad=True).attach_images((enc, dec))
+    # batches as the device loader hands them out: index selections of a shuffled split
+    order = torch.randperm(N, device=device, generator=torch.Generator(device=device).manual_seed(0))
+    index = torch.empty(B, dtype=torch.int64, device=device)
+    minus_one = -torch.ones((), device=device)
+    state = {"at": 0}
+
+    def next_batch():
+        at = state["at"] if state["at"] + B <= N else 0
+        index.copy_(order[at:at + B])
+        state["at"] = at + B
 
     def step():
-        index = torch.randint(0, N, (B,), device=device, generator=gen)
         Xt, idx = buf.gather(index)
         Mk = Mdev[index].unsqueeze(1).expand(B, K, 5).contiguous()
         Xt = imp.lair(dims, enc, dec, Xt, Mk, num_iterations=1, num_imp_samples=1, buf=buf, idx_imp=idx)
-        gen_obj, enc_obj = mvb2_objectives(dims, enc, dec, Xt, Mk, num_latent_samples=1, STL=True)
+        # as the model class steps (vgiwae/models/mvbvae.py, mvb2_manual_optimisation_step): the two objectives as scalar
+        # means, ascended through a cached root gradient of -1
+        gen_obj, enc_obj = mvb2_objectives(dims, enc, dec, Xt, Mk, num_latent_samples=1, STL=True, reduce_mean=True)
         opt.zero_grad(set_to_none=True)
-        (-gen_obj.mean()).backward(retain_graph=True, inputs=dec.params())
-        (-enc_obj.mean()).backward(inputs=enc.params())
+        gen_obj.backward(minus_one, retain_graph=True, inputs=dec.params())
+        enc_obj.backward(minus_one, inputs=enc.params())
         opt.step()
 
-    t = _sync_time(step, 20, 5)
-    return {"workload": f"toy_mog2_large DeMissVAE mvb2 step incl. LAIR update, B={B}, K={K}", "ms_per_step": round(t * 1e3, 4),
-            "samples_per_s": round(B * K / t, 1)}
+    def eager():
+        next_batch()
+        step()
+
+    if parts:       # for tracing tools: the step itself
+        return step, next_batch, (enc, dec)
+    t_eager = _sync_time(eager, 20, 5)
+    from .graph import GraphedStep
+    replay = GraphedStep(step, refresh=next_batch, nets=(enc, dec))
+    t = _sync_time(replay, 100, 10)
+    return {"workload": f"toy_mog2_large DeMissVAE mvb2 step incl. LAIR update, B={B}, K={K}, HIP-graph replay",
+            "ms_per_step": round(t * 1e3, 4), "samples_per_s": round(B * K / t, 1), "eager_ms_per_step": round(t_eager * 1e3, 4)}
 
 
 def loglik_eval_rate(device, B=50, K=50000, batches=4, name="gas", D=8, Zd=16, enc_shape=(16, 32, 2, 256),

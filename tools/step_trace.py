@@ -19,7 +19,13 @@ what = sys.argv[1] if len(sys.argv) > 1 else "512"
 mode = sys.argv[2] if len(sys.argv) > 2 else "graph"
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 K = 5
-if what in ("hepmass", "miniboone"):
+refresh = None
+if what == "toy":
+    # toy_mog2_large DeMissVAE: LAIR update + two objectives + two backward passes + Adam, B = 4096, K = 5
+    from demiss_vae_amd.bench_extra import demiss_toy_step
+    step, refresh, (enc, dec) = demiss_toy_step(torch.device("cuda"), parts=True)
+    B = 4096
+elif what in ("hepmass", "miniboone"):
     # MissSIWAE (stratified mixture of 5, one sample per component): configs/uci_hepmass, configs/uci_miniboone shapes
     from demiss_vae_amd import synth
     from demiss_vae_amd.imputation import _keep as keep_for
@@ -52,7 +58,7 @@ else:
         opt.step()
 
 
-fn = dmv.GraphedStep(step, nets=(enc, dec)) if mode == "graph" else step
+fn = dmv.GraphedStep(step, refresh=refresh, nets=(enc, dec)) if mode == "graph" else (step if refresh is None else (lambda: (refresh(), step())))
 for _ in range(20):
     fn()
 torch.cuda.synchronize()
