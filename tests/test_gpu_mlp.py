@@ -429,3 +429,31 @@ def test_batches_cut_into_launches_of_different_kernel_families(rows):
         assert torch.equal(y.detach()[:whole], y2[:whole]) and torch.equal(x.grad[:whole], dx2[:whole])
     for a, b in zip(net.params(), net2.params()):
         torch.testing.assert_close(a.grad, b.grad, rtol=2e-4, atol=2e-4 * float(b.grad.abs().max()))
+
+
+def test_groups_with_equal_rates_share_a_device_scalar_until_they_part():
+    """two parameter groups with the same learning rate read one device scalar (one write per scheduled step); when a
+    group's rate is changed on its own, both get their own scalar and the update follows torch's"""
+    from demiss_vae_amd.optim import Adam
+    torch.manual_seed(3)
+    mine = [torch.randn(300, device="cuda").requires_grad_(), torch.randn(70, 9, device="cuda").requires_grad_()]
+    ref = [p.detach().clone().requires_grad_() for p in mine]
+    groups = lambda ps: [{"params": [ps[0]], "lr": 1e-2}, {"params": [ps[1]], "lr": 1e-2}]
+    a, b = Adam(groups(mine)), torch.optim.Adam(groups(ref))
+    for step in range(6):
+        for p, q in zip(mine, ref):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        if step == 2:                       # a schedule moves both rates together: still one scalar
+            for o in (a, b):
+                for grp in o.param_groups:
+                    grp["lr"] = 5e-3
+        if step == 4:                       # one group on its own
+            for o in (a, b):
+                o.param_groups[1]["lr"] = 1e-3
+        a.step(), b.step()
+        shared = a._lr_dev[0] is a._lr_dev[1]
+        assert shared == (step < 4)
+        for p, q in zip(mine, ref):
+            torch.testing.assert_close(p, q, rtol=1e-5, atol=5e-7)
+    assert float(a.state_dict()["state"][0]["step"]) == 6
