@@ -515,3 +515,37 @@ def test_validation_steps_replay_and_agree_with_eager_validation(workdir):
     a, b = rows["replayed"][0][-1]["elbo/val"], rows["eager"][0][-1]["elbo/val"]
     print("validation bound, replayed vs eager:", a, b)
     assert math.isfinite(a) and abs(a - b) < 0.3, (a, b)
+
+
+def _bench(args, env_extra, launcher=()):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, *launcher, os.path.join(root, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=115, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # ONE json line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_line_under_torchrun_with_two_ranks():
+    """`bench.py --gpus 2` launched as the driver launches it (torchrun, one rank per GPU; here both ranks on the one
+    GPU with gloo collectives): one JSON line, n_gpus = 2, whole-job value = 2 x batch x K / step time"""
+    row = _bench(["--gpus", "2", "--steps", "5", "--warmup", "2", "--batch", "4096", "--no-cpu"],
+                 {"DMV_BENCH_BACKEND": "gloo"},
+                 launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29537"))
+    assert row["n_gpus"] == 2 and row["steps"] == 5 and row["scaling"] == "weak" and row["config"]["parallelism"] == "dp2"
+    assert abs(row["value"] - 2 * 4096 * 5 / (row["ms_per_step"] * 1e-3)) < 1e-3 * row["value"]
+    assert row["extra"]["loglik_eval_K50000"]["samples_per_s"] > 0
+
+
+def test_bench_step_through_rccl_with_one_rank():
+    """the data-parallel step as it runs on several GPUs - gradient slabs, the decoder's all-reduce launched
+    asynchronously from inside the backward pass, RCCL's averaging reduction - rehearsed with a world of one rank"""
+    row = _bench(["--steps", "5", "--warmup", "2", "--batch", "4096", "--no-cpu", "--no-extra"],
+                 {"DMV_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29539", "RANK": "0", "WORLD_SIZE": "1",
+                  "LOCAL_RANK": "0"})
+    assert row["n_gpus"] == 1 and row["value"] > 0
