@@ -1,18 +1,20 @@
 #!/bin/bash
-# rocprofv3 passes over the small-batch MLP kernels (tools/kbench.py at 2560 and 512 rows, gas decoder shapes):
-# kernel trace and one PMC pass, each a run of its own.
+# rocprofv3 passes over the small- and mid-batch MLP kernels (tools/kbench.py, gas decoder shapes; rows from the
+# arguments, default 2560 and 512): kernel trace and one PMC pass, each a run of its own.
 set -u
+ROWS="${*:-2560 512}"
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_s
 rm -rf $OUT; mkdir -p $OUT
-for rows in 2560 512; do
+for rows in $ROWS; do
   timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace$rows -- python tools/kbench.py $rows > $OUT/trace$rows.log 2>&1 || exit 1
   timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc$rows -- python tools/kbench.py $rows > $OUT/pmc$rows.log 2>&1 || exit 1
 done
-python - <<'PY'
-import collections, csv, glob, os
-out = ["# rocprofv3 summary: small-batch MLP kernels (`python tools/kbench.py <rows>`, gas decoder 16-256x4-16)", ""]
-for rows in (2560, 512):
+python - $ROWS <<'PY'
+import collections, csv, glob, os, sys
+out = ["# rocprofv3 summary: small- and mid-batch MLP kernels (`python tools/kbench.py <rows>`, gas decoder 16-256x4-16)", "",
+       "`bash tools/prof_small.sh <rows ...>`: per row count one `rocprofv3 --kernel-trace --stats` run and one `--pmc` run.", ""]
+for rows in [int(v) for v in sys.argv[1:]]:
     newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
     out += [f"## {rows} rows", "", "| kernel | calls | avg us | min us |", "|---|---|---|---|"]
     for r in csv.DictReader(open(newest(f"gpurun_out/prof_s/trace{rows}/*/*_kernel_stats.csv"))):
