@@ -34,7 +34,9 @@ trace; 20 warm-up steps are part of every trace (launches / step = calls / (step
 script itself measured under the profiler (profiling slows small steps down; bench.py reports the unprofiled times).  The
 raw per-kernel statistics are the `r2_step_*_kernel_stats.csv` and `r2_runner_epoch_kernel_stats.csv` files next to this
 note.  `profiles/r1_bench_step_kernel_stats.csv` of the first round mixed batch sizes in one trace and is gone; these traces
-replace it.
+replace it.  Up to 49 152 decoder rows the decoder's weight-gradient kernels run on a second stream beside the latent-side
+kernel and the encoder's backward pass; kernels that share the chip stretch each other, so in those traces the sum of the
+kernel times exceeds the wall time of the step.
 
 What changed in the step since the first round's traces, kernel by kernel (B = 512 replayed step, 33 launches then):
 - `k_obj_terms` + `k_obj_bound` + three torch reductions / negations -> one `k_obj_fwd*` launch (terms, logsumexp bound,
