@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Benchmark of the vgiwae hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU: either a launcher started the ranks (torch.distributed.run sets WORLD_SIZE; it must
+equal N), or this process starts them itself as a child `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+before it touches the GPU, relays the child's one JSON line and exits with the child's code.
 
 A step = one data-parallel training step of the UCI-gas MissIWAE model (K=5 importance samples, STL,
 mask-concat encoder (16,32,2,256), decoder (16,16,2,256)): fused objective forward + backward over one
@@ -41,6 +45,7 @@ def parse():
     ap.add_argument("--torch-optim", action="store_true",
                     help="clip_grad_norm_ + torch.optim.Adam(fused) instead of the library's clip + Adam step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the main CPU baseline")
     ap.add_argument("--kernels-only", action="store_true",
                     help="only launch the decoder MLP kernels of the roofline record (for rocprofv3 runs)")
     return ap.parse_args()
@@ -88,7 +93,29 @@ def event_time(fn, reps):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-PROFILE_MD = "profiles/r2_decoder_kernels.md"   # written by tools/prof.sh + tools/summarize_prof.py from `bench.py --kernels-only`
+def shader_clock_ghz(fn, launches, watch_ms=20.0):
+    """Shader clock held while fn() runs back to back: a one-wave watcher on a side stream stamps the shader-cycle
+    counter and the constant-rate counter `watch_ms` apart (dmv_clock_watch) while `launches` calls of fn keep the
+    chip busy on the current stream (not a timed pass: the watcher takes one wave slot)."""
+    import ctypes as C
+    from demiss_vae_amd import _lib as L
+    lib = L.lib()
+    khz = C.c_int32(0)
+    L.check(lib.dmv_wall_clock_khz(C.byref(khz)))
+    out = torch.zeros(4, dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        fn()
+    L.check(lib.dmv_clock_watch(int(watch_ms * 1e-3 * khz.value * 1e3), L.ptr(out), C.c_void_p(side.cuda_stream)))
+    for _ in range(launches):
+        fn()
+    torch.cuda.synchronize()
+    c0, r0, c1, r1 = out.tolist()
+    return (c1 - c0) / max(1, r1 - r0) * khz.value * 1e3 / 1e9
+
+
+PROFILE_MD = "profiles/r3_decoder_kernels.md"   # written by tools/prof.sh + tools/summarize_prof.py from `bench.py --kernels-only`
 
 
 def profiled_traffic(rows, kernel):
@@ -109,9 +136,11 @@ def profiled_traffic(rows, kernel):
         m = re.search(r"HBM read bytes[^=]*=[^=]*= ([\d.,]+) MB; written = ([\d.,]+) MB", sec)
         trace = re.search(r"^\| [^|]*" + {"k_mlp_fwd": "k_mlp_fwd<", "k_mlp_bwd": "k_mlp_bwd<"}.get(kernel, "k_mlp_wgrad") +
                           r"[^|]*\| \d+ \| ([\d.]+) \|", text, re.M)
+        made = re.search(r"^Collected: (.*)$", text, re.M)
         return {"traffic": sum(float(m.group(i).replace(",", "")) for i in (1, 2)) * 1e6, "traffic_unit": "bytes per launch",
                 "traffic_source": f"{PROFILE_MD} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {rows} rows)",
-                "profile_avg_us": float(trace.group(1)) if trace else None}
+                "profile_avg_us": float(trace.group(1)) if trace else None,
+                "profile_collected": made.group(1) if made else None}
     except Exception:
         return {"traffic": None}
 
@@ -157,17 +186,27 @@ def kernel_roofline(dec, dec_s, rows, device):
     }
     name = max(parts, key=lambda k: parts[k]["ms"])
     ach = parts[name]["tflops"]
+    prof = profiled_traffic(rows, name)
+    # the same fraction from the committed rocprofv3 kernel trace of this command (another box, another day: the
+    # spread between the two is box to box and profiled against unprofiled)
+    frac_prof = (round(flops / (prof["profile_avg_us"] * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+                 if prof.get("profile_avg_us") else None)
+    launches = max(30, int(0.03 / max(t_f, 1e-5)))      # >= 30 ms of back-to-back launches around a 20 ms watch
+    ghz = shader_clock_ghz({"k_mlp_fwd": fwd, "k_mlp_bwd": chain}.get(name, chain_wgrad), launches)
     roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), **profiled_traffic(rows, name),
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "frac_in_run": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            "frac_from_profile": frac_prof, **prof,
             "flops_per_launch": flops, "ms_per_launch": round(parts[name]["ms"], 4),
+            "shader_clock_ghz": round(ghz, 3), "peak_clock_ghz": 2.4,
+            "frac_of_peak_at_observed_clock": round(ach / (PEAK_FP32_MFMA_TFLOPS * ghz / 2.4), 4) if ghz > 0.5 else None,
             "all_kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in parts.items()}}
     return roof
 
 
-def cpu_baseline(budget_s=15.0, threads=None):
-    """The CPU oracle (stock PyTorch ops + autograd, the op sequence the reference issues) on the yaml batch
-    (B=512, K=5) of the same workload, repeated for about `budget_s` seconds on `threads` of this host's cores
-    (default: the box's CPU share, 16)."""
+def cpu_baseline(budget_s=15.0, threads=None, B=512):
+    """The CPU oracle (stock PyTorch ops + autograd, the op sequence the reference issues) on the same workload
+    (B datapoints, K=5), repeated for about `budget_s` seconds on `threads` of this host's cores (default: the box's
+    CPU share, 16)."""
     from oracle import core
     from oracle.recipes import NetSpec, make_params, make_batch, make_noise
     threads = min(16, os.cpu_count() or 1) if threads is None else threads
@@ -176,7 +215,7 @@ def cpu_baseline(budget_s=15.0, threads=None):
     spec = core.ModelSpec(D=8, Zd=16, enc=enc_s, dec=dec_s, encoder_use_mis_mask=True)
     ep = {k: v.requires_grad_(True) for k, v in make_params(enc_s, 1).items()}
     dp = {k: v.requires_grad_(True) for k, v in make_params(dec_s, 2).items()}
-    B, K = 512, 5
+    K = 5
     X, M = make_batch(3, B, 8)
 
     def step():
@@ -186,7 +225,7 @@ def cpu_baseline(budget_s=15.0, threads=None):
         for p in list(ep.values()) + list(dp.values()):
             p.grad = None
 
-    for _ in range(3):
+    for _ in range(3 if B <= 4096 else 1):
         step()
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
@@ -194,7 +233,7 @@ def cpu_baseline(budget_s=15.0, threads=None):
         n += 1
     dt = (time.perf_counter() - t0) / n
     return {"value": round(B * K / dt, 1), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"{n} fwd+bwd steps of B=512, K=5 (the yaml batch) in {budget_s:.0f} s; CPU oracle = stock PyTorch ops"}
+            "sample": f"{n} fwd+bwd steps of B={B}, K=5 in {time.perf_counter() - t0:.0f} s; CPU oracle = stock PyTorch ops"}
 
 
 def dbg(msg):
@@ -212,18 +251,44 @@ def _claim_stdout():
     return real
 
 
+def launch_ranks(args):
+    """`--gpus N` without a launcher: N ranks as a child process (torch.distributed.run, one rank per GPU), started
+    before this process has touched the GPU.  The child's rank 0 prints the JSON line on the inherited stdout; the
+    child's exit code is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     out_stream = _claim_stdout()
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr, flush=True)
+        sys.exit(2)
     dist = world > 1 or bool(os.environ.get("DMV_BENCH_FORCE_DIST"))   # the latter: one-rank rehearsal of the RCCL calls
+    backend = None
     if dist:
         import torch.distributed as td
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         ndev = torch.cuda.device_count()
         backend = os.environ.get("DMV_BENCH_BACKEND", "nccl")   # "gloo" lets two ranks share one GPU in rehearsals
+        if backend == "nccl" and world > ndev:
+            print(f"bench.py: {world} ranks need {world} GPUs, this node shows {ndev} (RCCL wants one GPU per rank)",
+                  file=sys.stderr, flush=True)
+            sys.exit(2)
         torch.cuda.set_device(local % ndev)
         if backend == "nccl":
             td.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
@@ -259,6 +324,13 @@ def main():
         if dist:
             td.barrier()
 
+    def max_over_ranks(seconds):
+        if not dist:
+            return seconds
+        t = torch.tensor([seconds], device=device, dtype=torch.float64)
+        all_reduce(t, td.ReduceOp.MAX)
+        return t.item()
+
     def fwd_bwd():
         # the loss (minus the bound) comes out of the library with the bound, as in the model classes' training_step
         _, _, loss = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=1, num_importance_samples=K, STL=True,
@@ -277,15 +349,13 @@ def main():
         opt.step()
 
     dbg("model built")
-    dt = timed(step, args.steps, args.warmup, barrier)
+    dt = max_over_ranks(timed(step, args.steps, args.warmup, barrier))
     dbg(f"timed {dt}")
-    if dist:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        all_reduce(t, td.ReduceOp.MAX)
-        dt = t.item()
 
-    # K = 50 000 log-likelihood estimation: test points sharded over ranks, rates summed
-    ll = None
+    # K = 50 000 log-likelihood estimation: (a) test points dealt to the ranks, every rank all K samples of its points,
+    # rates summed; (b) N > 1: the K samples of the SAME points split over the ranks, (max, sum-exp) states combined
+    # with the logsumexp all-reduce, whole-job rate = points x K / slowest rank's time
+    ll, ll_k = None, None
     if not args.no_extra:
         from demiss_vae_amd.bench_extra import loglik_eval_rate
         barrier()
@@ -297,6 +367,11 @@ def main():
             all_reduce(t, td.ReduceOp.SUM)
             ll["samples_per_s"] = round(t.item(), 1)
             ll["workload"] += f", {world} ranks each on its own test points"
+        if world > 1:
+            barrier()
+            ll_k = loglik_eval_rate(device, k_shard=(rank, world), barrier=barrier)
+            ll_k["ms_per_batch"] = round(max_over_ranks(ll_k["ms_per_batch"]), 3)
+            ll_k["samples_per_s"] = round(50 * 50000 / (ll_k["ms_per_batch"] * 1e-3), 1)
 
     out = None
     if rank == 0:
@@ -305,56 +380,64 @@ def main():
         out = {
             "metric": "IWAE fwd+bwd samples/sec (batch x K)", "value": round(value, 1), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded normal data, uniform 50 % masks, nn.Linear-style random weights; latent noise and "
+                    "dropout from the library's device Philox streams: checked statistically, not against torch's streams)",
             "config": {"workload": f"UCI-gas MissIWAE K=5 STL training step (fwd+bwd+allreduce+clip+Adam), "
                                    f"B={B} per GPU, enc (16,32,2,256) mask-concat, dec (16,16,2,256), D=8, Zd=16",
                        "global_batch": world * B, "K": K, "parallelism": f"dp{world}"},
             "step_tflops": round(value * flops_per_sample / 1e12, 2),
             "step_frac_of_fp32_mfma_peak": round(value * flops_per_sample / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
         }
-    if rank == 0 and world == 1:
+        if dist:
+            out["rccl_ranks"] = td.get_world_size()
+            out["collective_backend"] = "rccl" if backend == "nccl" else backend
+        # rank 0's GPU, after the timed region (the other ranks wait at the closing barrier)
         out["roofline"] = kernel_roofline(dec, dec_s, B * K, device)
-        if not args.no_extra:
-            extra = {}
-            t_fb = timed(lambda: (opt.zero_grad(set_to_none=True), fwd_bwd()), max(5, args.steps // 2), 2, barrier)
-            extra["fwd_bwd_only_samples_per_s"] = round(B * K / t_fb, 1)
-            # the yaml batch size (configs/uci_gas/compare/mis50/iwae_i5_encm_stl.yaml: batch_size 512)
-            d2 = make_gas(device, 512)
-            dims2, enc2, dec2, X2, M2 = d2[0], d2[1], d2[2], d2[5], d2[6]
-            p2 = enc2.params() + dec2.params()
-            from demiss_vae_amd.optim import Adam as LibAdam
-            opt2 = LibAdam(p2, lr=1e-3, amsgrad=True).attach_images((enc2, dec2))
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra = {}
+        t_fb = timed(lambda: (opt.zero_grad(set_to_none=True), fwd_bwd()), max(5, args.steps // 2), 2, barrier)
+        extra["fwd_bwd_only_samples_per_s"] = round(B * K / t_fb, 1)
+        # the yaml batch size (configs/uci_gas/compare/mis50/iwae_i5_encm_stl.yaml: batch_size 512)
+        d2 = make_gas(device, 512)
+        dims2, enc2, dec2, X2, M2 = d2[0], d2[1], d2[2], d2[5], d2[6]
+        p2 = enc2.params() + dec2.params()
+        from demiss_vae_amd.optim import Adam as LibAdam
+        opt2 = LibAdam(p2, lr=1e-3, amsgrad=True).attach_images((enc2, dec2))
 
-            def step512():
-                opt2.zero_grad(set_to_none=True)
-                _, _, loss = dmv.estimate_iwelbo(dims2, enc2, dec2, X2, M2, num_latent_samples=1, num_importance_samples=K,
-                                                 STL=True, with_loss=True)
-                loss.backward(unit_gradient(loss))      # the trainer's cached root gradient: no ones-fill per step
-                opt2.clip_on_next_step(5.0)
-                opt2.step()
+        def step512():
+            opt2.zero_grad(set_to_none=True)
+            _, _, loss = dmv.estimate_iwelbo(dims2, enc2, dec2, X2, M2, num_latent_samples=1, num_importance_samples=K,
+                                             STL=True, with_loss=True)
+            loss.backward(unit_gradient(loss))      # the trainer's cached root gradient: no ones-fill per step
+            opt2.clip_on_next_step(5.0)
+            opt2.step()
 
-            t512 = timed(step512, 50, 10, barrier)
-            extra["yaml_batch_512"] = {"ms_per_step": round(t512 * 1e3, 4), "samples_per_s": round(512 * K / t512, 1)}
-            # the same step recorded once in a HIP graph (library noise: fresh on every replay)
-            g512 = dmv.GraphedStep(step512, nets=(enc2, dec2))
-            tg = timed(g512, 200, 20, barrier)
-            extra["yaml_batch_512_hip_graph"] = {"ms_per_step": round(tg * 1e3, 4), "samples_per_s": round(512 * K / tg, 1)}
-            from demiss_vae_amd.bench_extra import demiss_toy_step, missiwae_step
-            extra["demiss_toy_mvb2"] = demiss_toy_step(device)
-            extra["hepmass_missiwae"] = missiwae_step(device, "UCI-hepmass", 4096, 21, 16, (42, 165, 2, 256), (16, 42, 2, 256))
-            extra["miniboone_missiwae"] = missiwae_step(device, "UCI-miniboone", 8192, 43, 32, (86, 325, 5, 256),
-                                                        (32, 86, 2, 256), dropout=0.5)
-            extra["loglik_eval_K50000"] = ll
-            if args.with_conv:
-                from demiss_vae_amd.bench_extra import mnist_demiss_step
-                extra["mnist_demiss_mvb2"] = mnist_demiss_step(device)
-            out["extra"] = extra
-        if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline()
-            out.setdefault("extra", {})["cpu_baseline_single_thread"] = cpu_baseline(budget_s=6.0, threads=1)
-    if rank == 0 and world > 1 and ll is not None:
-        out["extra"] = {"loglik_eval_K50000": ll}
+        t512 = timed(step512, 50, 10, barrier)
+        extra["yaml_batch_512"] = {"ms_per_step": round(t512 * 1e3, 4), "samples_per_s": round(512 * K / t512, 1)}
+        # the same step recorded once in a HIP graph (library noise: fresh on every replay)
+        g512 = dmv.GraphedStep(step512, nets=(enc2, dec2))
+        tg = timed(g512, 200, 20, barrier)
+        extra["yaml_batch_512_hip_graph"] = {"ms_per_step": round(tg * 1e3, 4), "samples_per_s": round(512 * K / tg, 1)}
+        from demiss_vae_amd.bench_extra import demiss_toy_step, missiwae_step
+        extra["demiss_toy_mvb2"] = demiss_toy_step(device)
+        extra["hepmass_missiwae"] = missiwae_step(device, "UCI-hepmass", 4096, 21, 16, (42, 165, 2, 256), (16, 42, 2, 256))
+        extra["miniboone_missiwae"] = missiwae_step(device, "UCI-miniboone", 8192, 43, 32, (86, 325, 5, 256),
+                                                    (32, 86, 2, 256), dropout=0.5)
+        if args.with_conv:
+            from demiss_vae_amd.bench_extra import mnist_demiss_step
+            extra["mnist_demiss_mvb2"] = mnist_demiss_step(device)
+        out["extra"] = extra
     if rank == 0:
+        if ll is not None:
+            out.setdefault("extra", {})["loglik_eval_K50000"] = ll
+        if ll_k is not None:
+            out["extra"]["loglik_eval_K50000_samples_sharded"] = ll_k
+        if not args.no_cpu:
+            # the headline workload itself (same B, a few steps), then the yaml batch on all cores and on one
+            out["cpu_baseline"] = cpu_baseline(budget_s=args.cpu_budget, B=B)
+            out.setdefault("extra", {})["cpu_baseline_yaml_batch"] = cpu_baseline(budget_s=args.cpu_budget * 0.6, B=512)
+            out["extra"]["cpu_baseline_single_thread"] = cpu_baseline(budget_s=args.cpu_budget * 0.5, threads=1, B=512)
         print(json.dumps(out), file=out_stream, flush=True)
     if dist:
         td.barrier()

@@ -115,6 +115,8 @@ SIGNATURES = {
     "dmv_categorical_draw": (C.c_int, [_I32, _I32, _I32, _P, _P, _U64, _U64, _P, _P, _P]),
     "dmv_lair_row_map": (C.c_int, [_I32, _I32, _I32, _P, _P, _P]),
     "dmv_dropout_masks": (C.c_int, [_P, _I64, _F, _U64, _U64, _P, _P]),
+    "dmv_clock_watch": (C.c_int, [_I64, _P, _P]),
+    "dmv_wall_clock_khz": (C.c_int, [C.POINTER(_I32)]),
 }
 
 

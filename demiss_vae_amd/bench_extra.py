@@ -151,24 +151,34 @@ def demiss_toy_step(device, B=4096, K=5, parts=False):
 
 
 def loglik_eval_rate(device, B=50, K=50000, batches=4, name="gas", D=8, Zd=16, enc_shape=(16, 32, 2, 256),
-                     dec_shape=(16, 16, 2, 256), C=1):
+                     dec_shape=(16, 16, 2, 256), C=1, k_shard=None, barrier=None):
     """Refit test step (UCI-gas shapes by default): B=50 test points x K=50 000 importance samples per batch; C > 1:
     a stratified-mixture encoder sampled as a plain mixture.  Under data parallelism every rank takes its own
-    batches of test points (no exchange until the final mean)."""
+    batches of test points (no exchange until the final mean); with k_shard = (rank, world) every rank takes the SAME
+    points and its contiguous share of the K samples, and the ranks' (max, sum-exp) states are combined by the
+    logsumexp all-reduce inside every batch (the returned time is this rank's; the caller takes the maximum)."""
     enc_s, dec_s = NetSpec(*enc_shape), NetSpec(*dec_shape)
     enc, dec = _packed(device, enc_s, 1, False), _packed(device, dec_s, 2, False)
     dims = ModelDims(D=D, Zd=Zd, encoder_use_mis_mask=True, q_dist="stratified_with_eps" if C > 1 else "normal_with_eps", C=C)
-    X, _ = make_batch(5 + P.rank(), B, D)
+    X, _ = make_batch(5 + (P.rank() if k_shard is None else 0), B, D)
     X = X.to(device)
     M = torch.ones_like(X, dtype=torch.bool)
 
     def run():
         for _ in range(batches):
-            imp.estimate_loglik(dims, enc, dec, X, M, num_importance_samples=K, chunk=8192)
+            imp.estimate_loglik(dims, enc, dec, X, M, num_importance_samples=K, chunk=8192, k_shard=k_shard)
 
-    t = _sync_time(run, 2, 1)
-    return {"workload": f"refit test_step, {name} shapes, B={B} x K={K} per batch", "ms_per_batch": round(t / batches * 1e3, 3),
-            "samples_per_s": round(batches * B * K / t, 1)}
+    if k_shard is None:
+        t = _sync_time(run, 2, 1)
+    else:
+        run()
+        barrier()
+        t = _sync_time(run, 2, 0)
+    out = {"workload": f"refit test_step, {name} shapes, B={B} x K={K} per batch", "ms_per_batch": round(t / batches * 1e3, 3),
+           "samples_per_s": round(batches * B * K / t, 1)}
+    if k_shard is not None:
+        out["workload"] += f", the K samples of every point split over {k_shard[1]} ranks (logsumexp all-reduce per batch)"
+    return out
 
 
 def mnist_demiss_step(device, B=200, K=5):

@@ -405,6 +405,14 @@ int dmv_opt_adam_step_static(int32_t n, float* const* params, const float* const
                              float* norm_out, const DmvPackMap* pack_map, uint64_t* counter, uint64_t counter_add,
                              void* stream);
 
+/* Measurement aid (no counterpart in the reference): the shader clock the chip holds under a load.  dmv_clock_watch
+ * enqueues one wave that stamps the shader-cycle counter and the constant-rate counter, naps until the latter has
+ * advanced by `ticks` (1 .. 2^28; the wave also leaves after a fixed number of naps), and stamps again:
+ * out4 = {cycles0, ticks0, cycles1, ticks1} (device memory).  Launch it on a side stream while the kernels of interest
+ * run on another; clock = (cycles1 - cycles0) / (ticks1 - ticks0) x dmv_wall_clock_khz(). */
+int dmv_clock_watch(int64_t ticks, uint64_t* out4, void* stream);
+int dmv_wall_clock_khz(int32_t* khz);
+
 #ifdef __cplusplus
 }
 #endif

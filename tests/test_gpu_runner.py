@@ -523,7 +523,7 @@ def _bench(args, env_extra, launcher=()):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, **env_extra)
     out = subprocess.run([sys.executable, *launcher, os.path.join(root, "bench.py"), *args], capture_output=True, text=True,
-                         timeout=115, env=env, cwd=root)
+                         timeout=170, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]          # ONE json line, from rank 0
@@ -540,6 +540,34 @@ def test_bench_line_under_torchrun_with_two_ranks():
     assert row["n_gpus"] == 2 and row["steps"] == 5 and row["scaling"] == "weak" and row["config"]["parallelism"] == "dp2"
     assert abs(row["value"] - 2 * 4096 * 5 / (row["ms_per_step"] * 1e-3)) < 1e-3 * row["value"]
     assert row["extra"]["loglik_eval_K50000"]["samples_per_s"] > 0
+
+
+def test_bench_starts_its_own_ranks_for_gpus_2():
+    """`python bench.py --gpus 2` with NO launcher around it: the script starts two ranks itself (a torch.distributed.run
+    child, before it touches the GPU; here both ranks on the one GPU with gloo collectives) and relays rank 0's one
+    line, which carries every record of the one-GPU line plus the rank count the collective library saw and the
+    log-likelihood rate with the K samples split over the ranks"""
+    row = _bench(["--gpus", "2", "--steps", "5", "--warmup", "2", "--batch", "4096", "--cpu-budget", "2"],
+                 {"DMV_BENCH_BACKEND": "gloo"})
+    assert row["n_gpus"] == 2 and row["rccl_ranks"] == 2 and row["config"]["parallelism"] == "dp2"
+    assert abs(row["value"] - 2 * 4096 * 5 / (row["ms_per_step"] * 1e-3)) < 1e-3 * row["value"]
+    r = row["roofline"]
+    assert r["bound"] == "mfma" and 0.05 < r["frac"] < 1.0 and r["frac"] == r["frac_in_run"] and "frac_from_profile" in r
+    assert 1.0 < r["shader_clock_ghz"] < 2.6, r["shader_clock_ghz"]
+    assert row["cpu_baseline"]["value"] > 0 and row["cpu_baseline"]["kind"] == "port" and "B=4096" in row["cpu_baseline"]["sample"]
+    assert row["extra"]["loglik_eval_K50000"]["samples_per_s"] > 0
+    assert row["extra"]["loglik_eval_K50000_samples_sharded"]["samples_per_s"] > 0
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """a launcher that started another number of ranks than --gpus names: non-zero exit, no line"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
+                         text=True, timeout=60, env=env, cwd=root)
+    assert out.returncode != 0 and not out.stdout.strip() and "--gpus 2" in out.stderr
 
 
 def test_bench_step_through_rccl_with_one_rank():

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes over the objective kernels (tools/objprof.py): kernel trace, then FETCH_SIZE and WRITE_SIZE each in
-# a run of its own.  Usage: bash tools/objprof.sh <gas|bern>
+# a run of its own.  Usage: bash tools/objprof.sh <gas|bern|mb|hep>
 set -u
 W=${1:-gas}
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"

@@ -12,7 +12,13 @@ src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof_k"
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
 stats = newest(f"{src}/trace/vm/*_kernel_stats.csv")
 shutil.copy(stats, f"profiles/{tag}_decoder_kernels_kernel_stats.csv")
+import datetime
+import subprocess
+head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = "+uncommitted" if subprocess.run(["git", "status", "--porcelain", "demiss_vae_amd", "bench.py"], capture_output=True,
+                                         text=True).stdout.strip() else ""
 lines = [f"# rocprofv3 summary ({tag}): `python bench.py --kernels-only` (decoder MLP kernels, 163840 rows)", "",
+         f"Collected: {datetime.date.today().isoformat()}, tree at {head}{dirty}, one MI355X (tools/prof.sh)", "",
          "## --kernel-trace --stats", "", "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
 dur = {}
 for r in csv.DictReader(open(stats)):
@@ -34,6 +40,9 @@ for k, v in agg.items():
         lines.append(f"- {c}: {x:,.0f}")
     if "GRBM_GUI_ACTIVE" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
         cyc = m["GRBM_GUI_ACTIVE"] / 8
+        if k in dur:
+            lines.append(f"- derived: effective shader clock = GRBM_GUI_ACTIVE / 8 / traced duration = {cyc / dur[k]:.3f} GHz "
+                         f"(counter pass and trace pass are separate runs)")
         lines.append(f"- derived: cycles per XCD {cyc:,.0f}; MFMA busy / (1024 SIMDs x cycles) = {m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):.3f}; "
                      f"waitcnt-parked share SQ_WAIT_ANY/SQ_WAVE_CYCLES = {m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.3f}")
     if "FETCH_SIZE" in m:
