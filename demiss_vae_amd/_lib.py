@@ -17,6 +17,7 @@ IN_PLAIN, IN_MASKED, IN_CONCAT, IN_CONCAT_MASKED = 0, 1, 2, 3
 GEN = {"normal": 0, "normal_with_eps": 1, "bern": 2, "bern_m1_p1": 3}
 Q_OWN, Q_STRATIFIED, Q_IMPUTATION = 0, 1, 2
 BOUND_LSE, BOUND_WEIGHTED, BOUND_PER_COMPONENT, TERMS_ONLY = 0, 1, 2, -1
+E_BADARG, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 
 
 class DmvDropRng(C.Structure):
@@ -87,6 +88,12 @@ SIGNATURES = {
                                    C.POINTER(_P), C.POINTER(_P), _F, _P, _SZ, _P]),
     "dmv_mlp_backward_wgrad": (C.c_int, [C.POINTER(DmvNet), _P, _P, _I64, _I64, _P, _P, _F, _P, _SZ, _P]),
     "dmv_latent_sample": (C.c_int, [C.POINTER(DmvObjCfg), _P, _P, _U64, _U64, _P, _I64, _P, _P, _P, _P]),
+    "dmv_vae_forward_fits": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), C.POINTER(DmvNet)]),
+    "dmv_vae_forward": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), _P, _I32, _P, _P, C.POINTER(DmvNet), _P, _P, _U64, _U64,
+                                  _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "dmv_vae_backward_fits": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), C.POINTER(DmvNet)]),
+    "dmv_vae_backward": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvLatentBwd), C.POINTER(DmvNet), _P, _P, _P, _P, _I64, _P, _SZ,
+                                   C.POINTER(DmvNet), _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "dmv_obj_terms": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "dmv_obj_bound": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmv_obj_combine": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(_F), _P, _P, _P, _P]),

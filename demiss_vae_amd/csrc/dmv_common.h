@@ -99,11 +99,16 @@ __device__ __forceinline__ float dmv_act_grad(float y, int act) {
 
 // Transcendentals of the HBM-bound row kernels go through the hardware exp2 / log2 units (about 1 ulp; the
 // argument scaling adds |x| * 6e-8 relative): a libm-grade expf + log1pf pair per element made those kernels
-// ALU-bound.  log1p keeps its accuracy for small arguments through the series.
+// ALU-bound.
 __device__ __forceinline__ float dmv_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float dmv_log(float x) { return __logf(x); }
-__device__ __forceinline__ float dmv_log1p_pos(float t) {   // t >= 0
-  return t < 0x1p-10f ? t * (1.f - t * (0.5f - t * (1.f / 3.f))) : __logf(1.f + t);
+// log1p for t >= 0, relative accuracy of a few ulp over the whole range (softplus of a strongly negative argument, i.e.
+// a standard deviation of 1e-3, must not lose digits: 1 + t rounds t to 6e-8 absolute).  Small t: the series (relative
+// truncation error t^5 / 6 < 2e-10); otherwise log(u) t / (u - 1) with u = fl(1 + t), in which the rounding of u cancels.
+__device__ __forceinline__ float dmv_log1p_pos(float t) {
+  if (t < 0x1p-6f) return t * (1.f - t * (0.5f - t * (1.f / 3.f - t * (0.25f - t * 0.2f))));
+  const float u = 1.f + t;
+  return __logf(u) * (t * __frcp_rn(u - 1.f));
 }
 // torch.nn.functional.softplus, beta = 1, threshold = 20
 __device__ __forceinline__ float dmv_softplus(float x) { return x > 20.f ? x : dmv_log1p_pos(dmv_exp(x)); }

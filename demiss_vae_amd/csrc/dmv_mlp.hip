@@ -16,6 +16,7 @@
 // one wave per SIMD with two 32*NT-register activation sets keeps the matrix pipe busy.
 #include "dmv_common.h"
 #include "dmv_rng.h"
+#include "dmv_objmath.h"
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -1255,9 +1256,11 @@ __device__ __forceinline__ void r16_own_slice(const R16Full<NT>& full, int wv, R
 // (row, h) mask line holds bit 4 q + e for feature 32 t + 8 q + 4 h + e: this lane owns q = 2 (ot & 1) + (g >> 1)
 // of line h = g & 1, the lane 32 further the other q of the same line.
 // DROP: inverted dropout after the relu; kb = the keep bits of this lane's (row, h = g & 1) line (drop_words).
+// st: whether this lane's row stores what it saves (a tile of the fused encoder-decoder kernel holds an encoder row once
+// per sample row that uses it; one of the copies stores).
 template <int NT, int W, bool SAVE, bool DROP = false>
 __device__ __forceinline__ void r16_relu_save(R16Slice<NT, W>& slice, int lane, int t0, float* act_row, uint32_t* mask_line,
-                                              const uint32_t* kb = nullptr, float scale = 1.f) {
+                                              const uint32_t* kb = nullptr, float scale = 1.f, bool st = true) {
   constexpr int TW = Rows16<NT, W>::TW, NK = Rows16<NT, W>::NK;
   const int g = lane >> 4;
 #pragma unroll
@@ -1283,26 +1286,25 @@ __device__ __forceinline__ void r16_relu_save(R16Slice<NT, W>& slice, int lane, 
         nib |= (slice[i][e] > 0.f ? 1u : 0u) << e;
       }
       part |= nib << (8 * j + 4 * (g >> 1));
-      if (SAVE && t0 + i < NK) *(f32x4*)(act_row + 16 * (t0 + i)) = slice[i];
+      if (SAVE && st && t0 + i < NK) *(f32x4*)(act_row + 16 * (t0 + i)) = slice[i];
     }
     if (SAVE) {
       part |= (uint32_t)__shfl_xor((int)part, 32);
-      if (g < 2 && t0 + 2 * p < NK) ((uint16_t*)mask_line)[(t0 >> 1) + p] = (uint16_t)part;
+      if (g < 2 && st && t0 + 2 * p < NK) ((uint16_t*)mask_line)[(t0 >> 1) + p] = (uint16_t)part;
     }
   }
 }
 
-template <int NT, bool SAVE, bool DROP, int W>
-__global__ __launch_bounds__(64 * W, 1) void k_mlp_fwd_rows16(FwdArgs a) {
+// One 16-row tile through a whole network.  `row` addresses the saved buffers and `rl` (a valid row) the dropout
+// stream; `st` predicates the stores of what is saved; in4(k0) returns columns k0 .. k0+3 of this lane's row of the
+// network input, out4(ot, o) receives output columns 16 ot + 4 g .. + 3 of this lane's row (output tiles go round-robin
+// over the waves).
+template <int NT, bool SAVE, bool DROP, int W, class In4, class Out4>
+__device__ __forceinline__ void r16_forward_chain(const FwdArgs& a, float* lds, int lane, int wv, int64_t row, int64_t rl,
+                                                  bool st, In4 in4, Out4 out4) {
   constexpr int TW = Rows16<NT, W>::TW, NK = Rows16<NT, W>::NK, Hp = 32 * NT, MW = mask_words(NT);
-  __shared__ __attribute__((aligned(16))) float lds[Rows16<NT, W>::LDS_BYTES / 4];
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t0 = wv * TW;
-  const int m = lane & 15, g = lane >> 4;
-  const int64_t row = a.row_begin + (int64_t)blockIdx.x * 16 + m;
-  const bool live = row < a.rows;
-  const int64_t rl = live ? row : a.rows - 1;
+  const int g = lane >> 4;
   const int64_t rp = (a.rows + 31) & ~(int64_t)31;
   const int64_t act_stride = rp * Hp, mask_stride = rp * 2 * MW;
   float* act_row = SAVE ? a.acts + row * Hp + 4 * g : nullptr;                    // layer 0; + l * act_stride
@@ -1326,8 +1328,8 @@ __global__ __launch_bounds__(64 * W, 1) void k_mlp_fwd_rows16(FwdArgs a) {
     float* xs_row = SAVE ? a.xs + row * (32 * a.L.T_in) + 4 * g : nullptr;
     for (int t = 0; 2 * t < S; ++t) {
       const bool in_image = 2 * t + (g >> 1) < S;      // an odd group count leaves the last half tile empty
-      const f32x4 b = first_layer_input4(a, rl, 16 * t + 4 * g);
-      if (SAVE && wv == 0 && in_image) *(f32x4*)(xs_row + 16 * t) = b;
+      const f32x4 b = in4(16 * t + 4 * g);
+      if (SAVE && st && wv == 0 && in_image) *(f32x4*)(xs_row + 16 * t) = b;
       f32x4 w[TW];
 #pragma unroll
       for (int i = 0; i < TW; ++i) {
@@ -1340,7 +1342,7 @@ __global__ __launch_bounds__(64 * W, 1) void k_mlp_fwd_rows16(FwdArgs a) {
         for (int i = 0; i < TW; ++i) acc[i] = MFMA16(w[i][e], b[e], acc[i]);
     }
   }
-  r16_relu_save<NT, W, SAVE>(acc, lane, t0, act_row, mask_line);
+  r16_relu_save<NT, W, SAVE>(acc, lane, t0, act_row, mask_line, nullptr, 1.f, st);
   r16_exchange<NT, W>(lds, lane, t0, acc, A);
 
   // ---- residual blocks
@@ -1349,11 +1351,11 @@ __global__ __launch_bounds__(64 * W, 1) void k_mlp_fwd_rows16(FwdArgs a) {
     uint32_t kb[MW];
     if (DROP) drop_words<NT>(a.drop, drop_q0, a.rows, a.hidden, blk, rl, g & 1, t0 >> 1, (t0 + TW) >> 1, kb);
     r16_gemm<NT, W, true, true>((const f32x4*)(a.packed + a.L.w[l1]), a.packed + a.L.b[l1], lane, t0, A, acc);
-    r16_relu_save<NT, W, SAVE, DROP>(acc, lane, t0, act_row + l1 * act_stride, mask_line + l1 * mask_stride, kb, a.drop_scale);
+    r16_relu_save<NT, W, SAVE, DROP>(acc, lane, t0, act_row + l1 * act_stride, mask_line + l1 * mask_stride, kb, a.drop_scale, st);
     r16_exchange<NT, W>(lds, lane, t0, acc, T);
     r16_own_slice<NT, W>(A, wv, acc);                  // the residual stream is the accumulator of the second GEMM
     r16_gemm<NT, W, false, true>((const f32x4*)(a.packed + a.L.w[l2]), a.packed + a.L.b[l2], lane, t0, T, acc);
-    r16_relu_save<NT, W, SAVE>(acc, lane, t0, act_row + l2 * act_stride, mask_line + l2 * mask_stride);
+    r16_relu_save<NT, W, SAVE>(acc, lane, t0, act_row + l2 * act_stride, mask_line + l2 * mask_stride, nullptr, 1.f, st);
     r16_exchange<NT, W>(lds, lane, t0, acc, A);
   }
 
@@ -1363,17 +1365,118 @@ __global__ __launch_bounds__(64 * W, 1) void k_mlp_fwd_rows16(FwdArgs a) {
     constexpr int S = 4 * NT;
     const __amdgpu_buffer_rsrc_t img = make_rsrc(a.packed + a.L.w[lf], (uint32_t)(a.L.OT * S) * 1024u);
     const __amdgpu_buffer_rsrc_t bimg = make_rsrc(a.packed + a.L.b[lf], (uint32_t)a.L.OT * 256u);
-    for (int ot = wv; ot < 2 * a.L.OT; ot += W) {
-      const f32x4 o = r16_gemm1<NT>(img, r16_tile_off(ot, S), lane, A, MFMA16(r16_bias(bimg, lane, ot), 1.f, zero4()));
-      if (live) *(f32x4*)(a.y + row * a.ldy + 16 * ot + 4 * g) = o;
+    for (int ot = wv; ot < 2 * a.L.OT; ot += W)
+      out4(ot, r16_gemm1<NT>(img, r16_tile_off(ot, S), lane, A, MFMA16(r16_bias(bimg, lane, ot), 1.f, zero4())));
+  }
+}
+
+template <int NT, bool SAVE, bool DROP, int W>
+__global__ __launch_bounds__(64 * W, 1) void k_mlp_fwd_rows16(FwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[Rows16<NT, W>::LDS_BYTES / 4];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int64_t row = a.row_begin + (int64_t)blockIdx.x * 16 + m;
+  const bool live = row < a.rows;
+  const int64_t rl = live ? row : a.rows - 1;
+  // (the saved buffers hold whole 32-row tiles, so rows past the batch store too)
+  r16_forward_chain<NT, SAVE, DROP, W>(
+      a, lds, lane, wv, row, rl, true, [&](int k0) { return first_layer_input4(a, rl, k0); },
+      [&](int ot, f32x4 o) { if (live) *(f32x4*)(a.y + row * a.ldy + 16 * ot + 4 * g) = o; });
+}
+
+// ------------------------------------------------------------------------------------------
+// Encoder -> latent sample -> decoder of a small batch in one launch (vgiwae/models/vae.py:285-318: vae_forward's
+// predict_var_latent_params, rsample and generator_network calls).  A workgroup owns 16 consecutive sample rows
+// n = (s B + b) G + g.  It first runs the ENCODER on the encoder rows those samples draw from (row b, or row b G + g when
+// every imputation has an encoder row of its own; a row needed by several of the tile's samples is simply held several
+// times), keeps the 16 output rows in LDS, forms z = mu + sigma eps there, and runs the decoder on it: no round trip of
+// the encoder outputs or the latents through HBM and one launch instead of three.  The encoder is recomputed by every
+// tile that needs a row (S times over the batch), on compute units a 512-row encoder pass would leave idle.  All
+// buffers the three separate launches produce are written with the same values (encoder outputs and saved activations
+// by the tile that holds a row's first sample), so everything downstream - objective kernels, backward passes - is
+// unchanged.
+// ------------------------------------------------------------------------------------------
+struct VaeFwdArgs {
+  FwdArgs enc, dec;
+  int64_t N;                  // sample rows
+  int B, G, Zd;
+  int rows_per_b;             // encoder rows per datapoint: G (one per imputation) or 1
+  QAddr q;
+  const float* eps;           // [N][ldz] or null (Philox)
+  float* eps_out;             // nullable
+  float* Z;                   // [N][ldz]
+  int64_t ldz;
+  uint64_t seed, offset;
+  const uint64_t* offset_base;
+  int ZP;                     // latent width rounded up to 16: pitch of the latent tile in LDS
+};
+
+template <int NT, bool SAVE>
+__global__ __launch_bounds__(256, 1) void k_vae_fwd_rows16(VaeFwdArgs a) {
+  constexpr int W = 4;
+  __shared__ __attribute__((aligned(16))) float lds[Rows16<NT, W>::LDS_BYTES / 4];
+  __shared__ int par_off[16];                                  // where a row's (mu | raw sigma) start inside its encoder row
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [16][ldE] encoder outputs, then [16][ZP] latents
+  const int ldE = (int)a.enc.ldy;
+  float* et = tile;
+  float* zt = tile + 16 * ldE;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int64_t n = (int64_t)blockIdx.x * 16 + m;
+  const bool live = n < a.N;
+  const int nl = (int)(live ? n : a.N - 1);                    // N <= 4096 rows here
+  const int BG = a.B * a.G;
+  const int bg = nl % BG;
+  const int b = bg / a.G, comp = bg - b * a.G;
+  const int er = a.rows_per_b == 1 ? b : bg;                   // encoder row of this sample
+  // the first sample of an encoder row stores what the encoder pass saves and the row's outputs
+  const bool owner = live && nl < BG && (a.rows_per_b != 1 || comp == 0);
+  if (wv == 0 && g == 0) par_off[m] = (int)((int64_t)b * a.q.sb + (int64_t)comp * a.q.sg - (int64_t)er * ldE);
+
+  r16_forward_chain<NT, SAVE, false, W>(
+      a.enc, lds, lane, wv, er, er, owner, [&](int k0) { return first_layer_input4(a.enc, er, k0); },
+      [&](int ot, f32x4 o) {
+        *(f32x4*)(et + m * ldE + 16 * ot + 4 * g) = o;
+        if (owner) *(f32x4*)(a.enc.y + (int64_t)er * ldE + 16 * ot + 4 * g) = o;
+      });
+  __syncthreads();
+
+  // ---- z = mu + sigma eps for the tile's rows, into LDS (the decoder's input) and out to Z / eps_out
+  {
+    const uint64_t off = a.offset + (a.offset_base ? a.offset_base[0] : 0ull);
+    const int JW = a.ZP > (int)a.ldz ? a.ZP : (int)a.ldz;
+    for (int idx = threadIdx.x; idx < 16 * JW; idx += 256) {
+      const int mm = idx / JW, j = idx - mm * JW;
+      const int64_t n2 = (int64_t)blockIdx.x * 16 + mm;
+      float z = 0.f, e = 0.f;
+      if (j < a.Zd) {
+        const float* pr = et + mm * ldE + par_off[mm];
+        const float mu = pr[j];
+        const float sg = dmv_softplus(pr[a.q.raw_off + j]) + a.q.eps;
+        const int64_t i = (n2 < a.N ? n2 : a.N - 1) * a.ldz + j;
+        e = a.eps ? a.eps[i] : dmv_philox_normal(a.seed, off + (uint64_t)i);
+        z = mu + sg * e;
+      }
+      if (j < a.ZP) zt[mm * a.ZP + j] = z;
+      if (n2 < a.N && j < (int)a.ldz) {
+        a.Z[n2 * a.ldz + j] = z;
+        if (a.eps_out) a.eps_out[n2 * a.ldz + j] = e;
+      }
     }
   }
+  __syncthreads();
+
+  r16_forward_chain<NT, SAVE, false, W>(
+      a.dec, lds, lane, wv, n, nl, true, [&](int k0) { return *(const f32x4*)(zt + m * a.ZP + k0); },
+      [&](int ot, f32x4 o) { if (live) *(f32x4*)(a.dec.y + n * a.dec.ldy + 16 * ot + 4 * g) = o; });
 }
 
 // relu backward on a slice (sign bits of that layer's saved activation), then its columns of the layer-gradient buffer
 template <int NT, int W>
 __device__ __forceinline__ void r16_mask_store(R16Slice<NT, W>& slice, int lane, int t0, const uint32_t* mask_line,
-                                               float scale, float* dact_row) {
+                                               float scale, float* dact_row, bool st = true) {
   constexpr int TW = Rows16<NT, W>::TW, NK = Rows16<NT, W>::NK;
   const int g = lane >> 4;
 #pragma unroll
@@ -1384,21 +1487,20 @@ __device__ __forceinline__ void r16_mask_store(R16Slice<NT, W>& slice, int lane,
     const uint32_t nib = half >> (8 * (i & 1) + 4 * (g >> 1));        // t0 is even: parity of the tile = parity of i
 #pragma unroll
     for (int e = 0; e < 4; ++e) slice[i][e] = ((nib >> e) & 1u) ? slice[i][e] * scale : 0.f;
-    if (t0 + i < NK) *(f32x4*)(dact_row + 16 * (t0 + i)) = slice[i];
+    if (st && t0 + i < NK) *(f32x4*)(dact_row + 16 * (t0 + i)) = slice[i];
   }
 }
 
-template <int NT, int W>
-__global__ __launch_bounds__(64 * W, 1) void k_mlp_bwd_rows16(BwdArgs a) {
+// One 16-row tile back through a whole network.  `row` (a valid row of the padded buffers for every lane) addresses
+// the saved sign bits and the per-layer gradient buffer, `st` predicates the stores into the latter; gy4(k0) returns
+// columns k0 .. k0+3 of this lane's row of the output gradient (zeros for a row that is not there); with want_dx,
+// dx4(it, o) receives input-gradient columns 16 it + 4 g .. + 3 of this lane's row.
+template <int NT, int W, class Gy4, class Dx4>
+__device__ __forceinline__ void r16_backward_chain(const BwdArgs& a, float* lds, int lane, int wv, int64_t row, bool st,
+                                                   bool want_dx, Gy4 gy4, Dx4 dx4) {
   constexpr int TW = Rows16<NT, W>::TW, NK = Rows16<NT, W>::NK, Hp = 32 * NT, MW = mask_words(NT);
-  __shared__ __attribute__((aligned(16))) float lds[Rows16<NT, W>::LDS_BYTES / 4];
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t0 = wv * TW;
-  const int m = lane & 15, g = lane >> 4;
-  const int64_t row = a.row_begin + (int64_t)blockIdx.x * 16 + m;
-  const bool live = row < a.rows;
-  const int64_t rl = live ? row : a.rows - 1;
+  const int g = lane >> 4;
   const int64_t rp = (a.rows + 31) & ~(int64_t)31;
   const int64_t act_stride = rp * Hp, mask_stride = rp * 2 * MW;
   const int lf = a.L.nl - 1;
@@ -1412,15 +1514,14 @@ __global__ __launch_bounds__(64 * W, 1) void k_mlp_bwd_rows16(BwdArgs a) {
   {
     const int S = a.L.S_out;
     const __amdgpu_buffer_rsrc_t img = make_rsrc(a.packed + a.L.wt[lf], (uint32_t)(NT * S) * 1024u);
-    const float* gyr = a.gy + rl * a.ldgy + 4 * g;
     uint32_t base[TW];
 #pragma unroll
     for (int i = 0; i < TW; ++i) { base[i] = r16_tile_off(t0 + i, S); acc[i] = zero4(); }
     for (int t = 0; 2 * t < S; ++t) {
       const bool in_image = 2 * t + (g >> 1) < S;
       // gy rows are pitched to a multiple of 32 columns, so the half tile past an odd group count is readable
-      f32x4 b = *(const f32x4*)(gyr + 16 * t);
-      if (!live || !in_image) b = zero4();
+      f32x4 b = gy4(16 * t + 4 * g);
+      if (!in_image) b = zero4();
       f32x4 w[TW];
 #pragma unroll
       for (int i = 0; i < TW; ++i) {
@@ -1433,27 +1534,151 @@ __global__ __launch_bounds__(64 * W, 1) void k_mlp_bwd_rows16(BwdArgs a) {
         for (int i = 0; i < TW; ++i) acc[i] = MFMA16(w[i][e], b[e], acc[i]);
     }
   }
-  r16_mask_store<NT, W>(acc, lane, t0, mask_line + (lf - 1) * mask_stride, 1.f, dact_row + (lf - 1) * act_stride);
+  r16_mask_store<NT, W>(acc, lane, t0, mask_line + (lf - 1) * mask_stride, 1.f, dact_row + (lf - 1) * act_stride, st);
   r16_exchange<NT, W>(lds, lane, t0, acc, dA);
 
   for (int blk = a.nb - 1; blk >= 0; --blk) {
     const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
     r16_gemm<NT, W, true, false>((const f32x4*)(a.packed + a.L.wt[l2]), nullptr, lane, t0, dA, acc);
-    r16_mask_store<NT, W>(acc, lane, t0, mask_line + l1 * mask_stride, dscale, dact_row + l1 * act_stride);
+    r16_mask_store<NT, W>(acc, lane, t0, mask_line + l1 * mask_stride, dscale, dact_row + l1 * act_stride, st);
     r16_exchange<NT, W>(lds, lane, t0, acc, dT);
     r16_own_slice<NT, W>(dA, wv, acc);                                      // skip path
     r16_gemm<NT, W, false, false>((const f32x4*)(a.packed + a.L.wt[l1]), nullptr, lane, t0, dT, acc);
-    r16_mask_store<NT, W>(acc, lane, t0, mask_line + (l1 - 1) * mask_stride, 1.f, dact_row + (l1 - 1) * act_stride);
+    r16_mask_store<NT, W>(acc, lane, t0, mask_line + (l1 - 1) * mask_stride, 1.f, dact_row + (l1 - 1) * act_stride, st);
     r16_exchange<NT, W>(lds, lane, t0, acc, dA);
   }
 
-  if (a.dx) {
+  if (want_dx) {
     constexpr int S = 4 * NT;
     const __amdgpu_buffer_rsrc_t img = make_rsrc(a.packed + a.L.wt[0], (uint32_t)(a.L.T_in * S) * 1024u);
-    for (int it = wv; it < 2 * a.L.T_in; it += W) {
-      const f32x4 o = r16_gemm1<NT>(img, r16_tile_off(it, S), lane, dA, zero4());
-      if (live) *(f32x4*)(a.dx + row * a.lddx + 16 * it + 4 * g) = o;
+    for (int it = wv; it < 2 * a.L.T_in; it += W) dx4(it, r16_gemm1<NT>(img, r16_tile_off(it, S), lane, dA, zero4()));
+  }
+}
+
+template <int NT, int W>
+__global__ __launch_bounds__(64 * W, 1) void k_mlp_bwd_rows16(BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[Rows16<NT, W>::LDS_BYTES / 4];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int64_t row = a.row_begin + (int64_t)blockIdx.x * 16 + m;
+  const bool live = row < a.rows;
+  const int64_t rl = live ? row : a.rows - 1;
+  // (the per-layer gradient buffer holds whole 32-row tiles, so rows past the batch store too: zeros)
+  r16_backward_chain<NT, W>(
+      a, lds, lane, wv, row, true, a.dx != nullptr,
+      [&](int k0) { const f32x4 b = *(const f32x4*)(a.gy + rl * a.ldgy + k0); return live ? b : zero4(); },
+      [&](int it, f32x4 o) { if (live) *(f32x4*)(a.dx + row * a.lddx + 16 * it + 4 * g) = o; });
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward of a small batch from the decoder outputs' gradient to the encoder's first layer in one launch:
+// decoder input-gradient chain -> gradient w.r.t. the encoder outputs (mu, raw sigma) -> encoder input-gradient chain
+// (what dmv_mlp_backward(dec), dmv_obj_backward_latent and dmv_mlp_backward(enc) do in three launches with two round
+// trips through HBM between them).  For posteriors without a mixture term: every encoder row e (a datapoint, or one of
+// its imputations) owns S sample rows n = s BG + e.  A workgroup takes Q = 16 / S encoder rows and their Q S sample rows
+// as its decoder tile (row q S + s), so the sum over a row's samples that the latent-side gradient needs stays inside
+// the workgroup: the decoder's input gradients go to LDS, the latent-side gradient is formed there (same terms, in the
+// same order over s, as the own-Gaussian branch of k_obj_bwd_latent), and its Q rows are the encoder chain's tile (the
+// other 16 - Q rows of that tile are idle; the encoder pass costs what a 16-row pass costs either way).  Per-layer
+// gradients of both networks go to their workspaces for the weight-gradient GEMMs, which follow as separate launches.
+// ------------------------------------------------------------------------------------------
+struct VaeBwdArgs {
+  BwdArgs dec, enc;
+  int BG, S, Zd, Q, G;         // encoder rows, samples per row, latent width, encoder rows per tile, rows per datapoint
+  int ldE, raw_off, ZP;
+  float q_eps;
+  float base_prior, base_qown, kl_coef;
+  int own_live, use_zscale;
+  const float* enc_out;        // [BG][ldE]
+  const float* Z;              // [S BG][ldz]
+  const float* eps;
+  int64_t ldz;
+  const float* wgt;            // nullable [S BG]
+  const float* gb;             // nullable [BG / G]
+  const float* zscale;         // nullable [S BG]
+  const float* kl_wgt;         // nullable [BG]
+  const float* gscale;         // nullable device scalar
+  float* d_enc;                // [BG][ldE], every entry written
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k_vae_bwd_rows16(VaeBwdArgs a) {
+  constexpr int W = 4;
+  __shared__ __attribute__((aligned(16))) float lds[Rows16<NT, W>::LDS_BYTES / 4];
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [16][ZP] decoder input gradients, [16][ldE] encoder output gradients
+  float* dzt = tile;
+  float* det = tile + 16 * a.ZP;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int e0 = blockIdx.x * a.Q;
+
+  // ---- decoder chain on the rows (q, s) -> n = s BG + e0 + q
+  {
+    const int qd = m / a.S, sd = m - qd * a.S;
+    const bool live = qd < a.Q && e0 + qd < a.BG;
+    const int64_t n = live ? (int64_t)sd * a.BG + e0 + qd : 0;
+    r16_backward_chain<NT, W>(
+        a.dec, lds, lane, wv, n, live, true,
+        [&](int k0) { const f32x4 b = *(const f32x4*)(a.dec.gy + n * a.dec.ldgy + k0); return live ? b : zero4(); },
+        [&](int it, f32x4 o) { if (16 * it + 4 * g < a.ZP) *(f32x4*)(dzt + m * a.ZP + 16 * it + 4 * g) = o; });
+  }
+  for (int i = threadIdx.x; i < 16 * a.ldE; i += 256) det[i] = 0.f;
+  __syncthreads();
+
+  // ---- gradient w.r.t. (mu, raw sigma) of the tile's encoder rows
+  {
+    const float gs = a.gscale ? a.gscale[0] : 1.f;
+    const bool zs_on = a.use_zscale && a.zscale;
+    for (int i = threadIdx.x; i < a.Q * a.Zd; i += 256) {
+      const int qq = i / a.Zd, j = i - qq * a.Zd;
+      const int e = e0 + qq;
+      if (e >= a.BG) continue;
+      const float gbb = gs * (a.gb ? a.gb[e / a.G] : 1.f);
+      const float mu = a.enc_out[(int64_t)e * a.ldE + j];
+      const float raw = a.enc_out[(int64_t)e * a.ldE + a.raw_off + j];
+      const float sg = dmv_softplus(raw) + a.q_eps;
+      float acc_mu = 0.f, acc_sg = 0.f;
+      for (int s = 0; s < a.S; ++s) {
+        const int64_t n = (int64_t)s * a.BG + e;
+        const float w = gbb * (a.wgt ? a.wgt[n] : 1.f);
+        const float z = a.Z[n * a.ldz + j];
+        float dz = dzt[(qq * a.S + s) * a.ZP + j];
+        dz += a.base_prior * w * (-z);
+        if (a.base_qown != 0.f) dz += a.base_qown * w * (-(z - mu) / (sg * sg));
+        if (zs_on) dz *= a.zscale[n];
+        acc_mu += dz;
+        acc_sg += dz * a.eps[n * a.ldz + j];
+        if (a.own_live && a.base_qown != 0.f) {
+          const float df = z - mu;
+          acc_mu += a.base_qown * w * (df / (sg * sg));
+          acc_sg += a.base_qown * w * (df * df / (sg * sg * sg) - 1.f / sg);
+        }
+      }
+      if (a.kl_coef != 0.f) {
+        const float kc = a.kl_coef * gs * (a.kl_wgt ? a.kl_wgt[e] : 1.f);
+        acc_mu += kc * mu;
+        acc_sg += kc * (sg - 1.f / sg);
+      }
+      det[qq * a.ldE + j] = acc_mu;
+      det[qq * a.ldE + a.raw_off + j] = acc_sg * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.Q * a.ldE; i += 256) {
+    const int qq = i / a.ldE;
+    if (e0 + qq < a.BG) a.d_enc[(int64_t)e0 * a.ldE + i] = det[i];
+  }
+
+  // ---- encoder chain on the tile's encoder rows (lanes m >= Q idle)
+  {
+    const bool live = m < a.Q && e0 + m < a.BG;
+    const int64_t row = live ? e0 + m : 0;
+    r16_backward_chain<NT, W>(
+        a.enc, lds, lane, wv, row, live, false,
+        [&](int k0) { const f32x4 b = *(const f32x4*)(det + m * a.ldE + k0); return live ? b : zero4(); },
+        [&](int, f32x4) {});
   }
 }
 
@@ -1963,6 +2188,82 @@ extern "C" int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t i
   DMV_DISPATCH_NT(a.L.NT, launch_fwd, a, (hipStream_t)stream);
 }
 
+// ---- encoder -> sample -> decoder in one launch
+template <int NT>
+static int launch_vae_fwd(const VaeFwdArgs& a, size_t dyn_bytes, hipStream_t st) {
+  const unsigned tiles = (unsigned)((a.N + 15) / 16);
+  if (a.dec.acts) hipLaunchKernelGGL((k_vae_fwd_rows16<NT, true>), dim3(tiles), dim3(256), dyn_bytes, st, a);
+  else hipLaunchKernelGGL((k_vae_fwd_rows16<NT, false>), dim3(tiles), dim3(256), dyn_bytes, st, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+static bool vae_forward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec) {
+  if (!cfg || dmv_check_net(enc) != DMV_OK || dmv_check_net(dec) != DMV_OK) return false;
+  if (cfg->B < 1 || cfg->G < 1 || cfg->nz < 1 || cfg->I < 1 || cfg->Zd < 1) return false;
+  const int64_t N = (int64_t)cfg->nz * cfg->I * cfg->B * cfg->G;
+  if (N > 4096) return false;                                     // one round of 16-row tiles
+  if (enc->act != DMV_ACT_RELU || dec->act != DMV_ACT_RELU) return false;
+  const int NTe = dmv_ceil_div(enc->hidden, 32), NTd = dmv_ceil_div(dec->hidden, 32);
+  if (NTe != NTd || NTe > 8) return false;                        // one tile shape for both chains
+  if (dec->in_dim != cfg->Zd || cfg->Zd > 256) return false;
+  const size_t dyn = sizeof(float) * 16 * ((size_t)dmv_pad32(enc->out_dim) + 16 * (size_t)dmv_ceil_div(cfg->Zd, 16));
+  return dyn + (size_t)NTe * 2048 + 64 <= 65536;
+}
+
+extern "C" int dmv_vae_forward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec) {
+  return vae_forward_fits(cfg, enc, dec) ? 1 : 0;
+}
+
+extern "C" int dmv_vae_forward(const DmvObjCfg* cfg, const DmvNet* enc, const float* enc_packed, int32_t in_mode,
+                               const float* X, const uint8_t* M, const DmvNet* dec, const float* dec_packed,
+                               const float* eps, uint64_t seed, uint64_t offset, const uint64_t* offset_base,
+                               float* enc_out, float* enc_saved, float* Z, int64_t ldz, float* eps_out, float* dec_out,
+                               float* dec_saved, void* stream) {
+  if (!vae_forward_fits(cfg, enc, dec)) return DMV_E_UNSUPPORTED;
+  if (!enc_packed || !dec_packed || !X || !enc_out || !Z || !dec_out || ldz < cfg->Zd) return DMV_E_BADARG;
+  if (in_mode < DMV_IN_PLAIN || in_mode > DMV_IN_CONCAT_MASKED) return DMV_E_UNSUPPORTED;
+  if (in_mode != DMV_IN_PLAIN && !M) return DMV_E_BADARG;
+  if (((in_mode >= DMV_IN_CONCAT) ? 2 * cfg->D : cfg->D) != enc->in_dim) return DMV_E_BADARG;
+  if ((enc_saved != nullptr) != (dec_saved != nullptr)) return DMV_E_BADARG;
+  // a training pass (activations saved) of networks with dropout draws keep decisions: the separate launches do that
+  if (enc_saved && ((enc->dropout_p > 0.f && enc->nb > 0) || (dec->dropout_p > 0.f && dec->nb > 0))) return DMV_E_UNSUPPORTED;
+  if ((((uintptr_t)enc_out | (uintptr_t)dec_out) & 15) != 0) return DMV_E_BADARG;
+  const int64_t ldE = dmv_pad32(enc->out_dim);
+  const int rows_per_b = cfg->x_per_component ? cfg->G : 1;
+  // the addressing of (mu, raw sigma) must stay inside the encoder row that serves a sample
+  const int64_t last = (rows_per_b == 1 ? (int64_t)(cfg->G - 1) * cfg->enc_sg : 0) + cfg->raw_off + cfg->Zd;
+  if (cfg->enc_sb != rows_per_b * ldE || (rows_per_b != 1 && cfg->enc_sg != ldE) || last > ldE || cfg->raw_off < cfg->Zd)
+    return DMV_E_BADARG;
+  VaeFwdArgs a;
+  auto fill = [](FwdArgs& f, const DmvNet* net, const float* packed, int64_t rows, float* y, float* saved) {
+    f.drop.mode = DROP_OFF; f.drop.bits = 0; f.drop.thresh = 0; f.drop.keep = nullptr; f.drop.seed = 0; f.drop.q0 = 0;
+    f.drop.offset_base = nullptr;
+    f.L = dmv_layout(net);
+    f.packed = packed;
+    f.nb = net->nb; f.in_dim = net->in_dim; f.hidden = net->hidden; f.act = net->act;
+    f.drop_scale = 1.f;
+    f.rows = rows; f.row_begin = 0; f.row_end = rows;
+    f.y = y; f.ldy = dmv_pad32(net->out_dim);
+    f.xs = saved;
+    const int64_t rp = (rows + 31) & ~(int64_t)31;
+    f.acts = saved ? saved + rp * dmv_pad32(net->in_dim) : nullptr;
+    f.masks = saved ? (uint32_t*)(f.acts + (2 * net->nb + 1) * rp * dmv_pad32(net->hidden)) : nullptr;
+  };
+  a.N = (int64_t)cfg->nz * cfg->I * cfg->B * cfg->G;
+  fill(a.enc, enc, enc_packed, (int64_t)cfg->B * rows_per_b, enc_out, enc_saved);
+  a.enc.in_mode = in_mode; a.enc.D = cfg->D; a.enc.x = X; a.enc.ldx = cfg->D; a.enc.m = M; a.enc.ldm = cfg->D;
+  fill(a.dec, dec, dec_packed, a.N, dec_out, dec_saved);
+  a.dec.in_mode = DMV_IN_PLAIN; a.dec.D = cfg->Zd; a.dec.x = Z; a.dec.ldx = ldz; a.dec.m = nullptr; a.dec.ldm = 0;
+  a.B = cfg->B; a.G = cfg->G; a.Zd = cfg->Zd; a.rows_per_b = rows_per_b;
+  a.q.sb = cfg->enc_sb; a.q.sg = cfg->enc_sg; a.q.raw_off = cfg->raw_off; a.q.logit_off = cfg->logit_off;
+  a.q.eps = cfg->q_eps ? DMV_EPSILON : 0.f;
+  a.eps = eps; a.eps_out = eps_out; a.Z = Z; a.ldz = ldz; a.seed = seed; a.offset = offset; a.offset_base = offset_base;
+  a.ZP = 16 * dmv_ceil_div(cfg->Zd, 16);
+  const size_t dyn = sizeof(float) * 16 * ((size_t)ldE + (size_t)a.ZP);
+  DMV_DISPATCH_NT(a.enc.L.NT, launch_vae_fwd, a, dyn, (hipStream_t)stream);
+}
+
 // ---- backward host side
 // Work decomposition of the weight-gradient GEMMs.  A wave owns one block (up to bt x bt tiles) of one layer over
 // one row slice; slices are sized so that every wave issues about the same number of MFMAs (a layer whose
@@ -2127,4 +2428,77 @@ extern "C" int dmv_mlp_backward_wgrad(const DmvNet* net, const float* saved, con
   if (!grad_w || !grad_b) return DMV_E_BADARG;
   return mlp_backward_impl(net, nullptr, saved, nullptr, gy, ldgy, rows, nullptr, 0, grad_w, grad_b, beta, ws, ws_bytes,
                            stream, false);
+}
+
+// ---- decoder chain -> latent-side gradient -> encoder chain in one launch
+template <int NT>
+static int launch_vae_bwd(const VaeBwdArgs& a, size_t dyn_bytes, hipStream_t st) {
+  const unsigned tiles = (unsigned)((a.BG + a.Q - 1) / a.Q);
+  hipLaunchKernelGGL((k_vae_bwd_rows16<NT>), dim3(tiles), dim3(256), dyn_bytes, st, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+static bool vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec) {
+  if (!vae_forward_fits(cfg, enc, dec)) return false;
+  const int S = cfg->nz * cfg->I;
+  if (S > 16) return false;                                       // a row's samples share a tile
+  if (!cfg->x_per_component && cfg->G != 1) return false;         // one Gaussian per encoder row
+  return true;
+}
+
+extern "C" int dmv_vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec) {
+  return vae_backward_fits(cfg, enc, dec) ? 1 : 0;
+}
+
+extern "C" int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, const DmvNet* dec, const float* dec_packed,
+                                const float* dec_saved, const uint8_t* dec_drop_keep, const float* d_dec, int64_t ld_ddec,
+                                void* dec_ws, size_t dec_ws_bytes, const DmvNet* enc, const float* enc_packed,
+                                const float* enc_saved, const uint8_t* enc_drop_keep, float* d_enc, void* enc_ws,
+                                size_t enc_ws_bytes, const float* enc_out, const float* Z, const float* eps, int64_t ldz,
+                                const float* wgt, const float* gb, const float* zscale, const float* kl_wgt,
+                                const float* gscale, void* stream) {
+  if (!vae_backward_fits(cfg, enc, dec)) return DMV_E_UNSUPPORTED;
+  if (!p || p->base_qmix != 0.f) return DMV_E_UNSUPPORTED;        // mixture terms: the separate launches
+  if (!dec_packed || !dec_saved || !d_dec || !dec_ws || !enc_packed || !enc_saved || !d_enc || !enc_ws || !enc_out || !Z || !eps)
+    return DMV_E_BADARG;
+  const int64_t ldE = dmv_pad32(enc->out_dim);
+  const int rows_per_b = cfg->x_per_component ? cfg->G : 1;
+  const int64_t BG = (int64_t)cfg->B * rows_per_b, N = (int64_t)cfg->nz * cfg->I * cfg->B * cfg->G;
+  if (ldz < cfg->Zd || ld_ddec < dmv_pad32(dec->out_dim) || (ld_ddec & 3) || ((uintptr_t)d_dec & 15) || ((uintptr_t)d_enc & 15))
+    return DMV_E_BADARG;
+  if (cfg->enc_sb != rows_per_b * ldE || (rows_per_b != 1 && cfg->enc_sg != ldE) || cfg->raw_off < cfg->Zd ||
+      cfg->raw_off + cfg->Zd > ldE)
+    return DMV_E_BADARG;
+  if ((dec->dropout_p > 0.f && dec->nb > 0 && !dec_drop_keep) || (enc->dropout_p > 0.f && enc->nb > 0 && !enc_drop_keep))
+    return DMV_E_BADARG;
+  if (dec_ws_bytes < dmv_mlp_backward_ws_bytes(dec, N) || enc_ws_bytes < dmv_mlp_backward_ws_bytes(enc, BG)) return DMV_E_WORKSPACE;
+  if (((uintptr_t)dec_ws | (uintptr_t)enc_ws) & 15) return DMV_E_BADARG;
+  VaeBwdArgs a;
+  auto fill = [](BwdArgs& b, const DmvNet* net, const float* packed, const float* saved, const uint8_t* keep, int64_t rows,
+                 void* ws) {
+    const int64_t Hp = dmv_pad32(net->hidden), Ip = dmv_pad32(net->in_dim);
+    const int64_t rp = (rows + 31) & ~(int64_t)31;
+    b.L = dmv_layout(net);
+    b.packed = packed;
+    b.nb = net->nb; b.hidden = net->hidden; b.act = net->act;
+    b.drop_scale = 1.f / (1.f - net->dropout_p);
+    b.acts = saved + rp * Ip; b.drop_keep = keep;
+    b.masks = (const uint32_t*)(b.acts + (2 * net->nb + 1) * rp * Hp);
+    b.gy = nullptr; b.ldgy = 0; b.rows = rows; b.row_begin = 0; b.row_end = rows;
+    b.dacts = (float*)ws; b.dx = nullptr; b.lddx = 0;
+  };
+  fill(a.dec, dec, dec_packed, dec_saved, dec_drop_keep, N, dec_ws);
+  a.dec.gy = d_dec; a.dec.ldgy = ld_ddec;
+  fill(a.enc, enc, enc_packed, enc_saved, enc_drop_keep, BG, enc_ws);
+  a.enc.gy = d_enc; a.enc.ldgy = ldE;
+  a.BG = (int)BG; a.S = cfg->nz * cfg->I; a.Zd = cfg->Zd; a.Q = 16 / a.S; a.G = rows_per_b;
+  a.ldE = (int)ldE; a.raw_off = (int)cfg->raw_off; a.ZP = 16 * dmv_ceil_div(cfg->Zd, 16);
+  a.q_eps = cfg->q_eps ? DMV_EPSILON : 0.f;
+  a.base_prior = p->base_prior; a.base_qown = p->base_qown; a.kl_coef = p->kl_coef;
+  a.own_live = p->own_live; a.use_zscale = p->use_zscale;
+  a.enc_out = enc_out; a.Z = Z; a.eps = eps; a.ldz = ldz;
+  a.wgt = wgt; a.gb = gb; a.zscale = zscale; a.kl_wgt = kl_wgt; a.gscale = gscale; a.d_enc = d_enc;
+  const size_t dyn = sizeof(float) * 16 * ((size_t)ldE + (size_t)a.ZP);
+  DMV_DISPATCH_NT(a.dec.L.NT, launch_vae_bwd, a, dyn, (hipStream_t)stream);
 }

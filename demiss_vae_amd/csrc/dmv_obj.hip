@@ -653,6 +653,144 @@ __global__ void k_obj_bwd_latent(BwdLatArgs a) {
   a.d_enc[b * a.q.sb + gp * a.q.sg + a.q.raw_off + j] = acc_sg * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
 }
 
+// The same gradient when a mixture term is present (stratified mixture: shared/iwae.py:102-118,
+// models/multiple_iwae.py:124-140; imputation mixture: shared/iwae.py:119-132, models/mvbvae.py:95-109), for
+// datapoints with G * Zd <= 1024.  A workgroup owns nb consecutive datapoints, one thread per (datapoint, g', j).
+// What the G * Zd threads of a datapoint share is computed once and exchanged through LDS: the components' mu and
+// 1 / sigma^2, the normalised log mixture weights, and per sample group s the latent samples z[g][j], the mixture
+// term's row weights and the responsibilities r[g][c] = pi_c N_c(z_g) / q_mix(z_g).  All global operands of a sample
+// group are requested before the first barrier, so a thread waits for memory twice per group (operands, then the
+// component log-densities of responsibilities beyond the first per thread), not once per (sample, component).
+// Same terms in the same order as the mixture branch of k_obj_bwd_latent, which stays for larger datapoints.
+template <bool STRAT>
+__global__ __launch_bounds__(1024) void k_obj_bwd_latent_mix(BwdLatArgs a, int nb, int per_b) {
+  extern __shared__ float lds[];
+  const int G = a.G, Zd = a.Zd;
+  const int stride = 3 * per_b + 2 * G + G * G;
+  const int lb = (int)threadIdx.x / per_b;
+  const int e = (int)threadIdx.x - lb * per_b;
+  const int64_t b = (int64_t)blockIdx.x * nb + lb;
+  const bool active = lb < nb && b < a.B;
+  float* smu = lds + (active ? lb : 0) * stride;      // [G][Zd]
+  float* sis2 = smu + per_b;                          // [G][Zd]  1 / sigma^2
+  float* sz = sis2 + per_b;                           // [G][Zd]  samples of the current group
+  float* slp = sz + per_b;                            // [G]      log pi
+  float* sw = slp + G;                                // [G]      base_qmix * upstream * row weight of the mixture term
+  float* sr = sw + G;                                 // [G][G]   responsibilities of the current group
+  const int gp = e / Zd, j = e - gp * Zd;
+  const int GG = G * G;
+  const float gs = a.gscale ? a.gscale[0] : 1.f;
+  float gbb = gs, mu = 0.f, raw = 0.f, sg = 1.f, is2 = 1.f, isg = 1.f;
+  float acc_mu = 0.f, acc_sg = 0.f, acc_lg = 0.f;
+  for (int s = 0; s < a.S; ++s) {
+    // ---- requests of this sample group
+    float z = 0.f, dzv = 0.f, ep = 0.f, wv = 1.f, wov = 1.f, zs = 1.f, wq = 1.f, clp = 0.f, qm = 0.f;
+    if (active) {
+      const int64_t n = ((int64_t)s * a.B + b) * G + gp;
+      z = a.Z[n * a.ldz + j];
+      ep = a.eps[n * a.ldz + j];
+      if (a.dZ) dzv = a.dZ[n * a.ld_dz + j];
+      if (a.wgt) wv = a.wgt[n];
+      wov = a.wgt_qown ? a.wgt_qown[n] : wv;
+      if (a.use_zscale && a.zscale) zs = a.zscale[n];
+      if (e < G) {
+        const int64_t ng = ((int64_t)s * a.B + b) * G + e;
+        wq = a.wgt_qmix ? a.wgt_qmix[ng] : a.wgt ? a.wgt[ng] : 1.f;
+      }
+      if (e < GG) {
+        const int g = e / G;
+        const int64_t ng = ((int64_t)s * a.B + b) * G + g;
+        clp = a.comp_lp[ng * G + (e - g * G)];
+        qm = a.qmix[ng];
+      }
+    }
+    if (s == 0 && active) {
+      // ---- once per datapoint: its padding entries, parameters and log mixture weights
+      if (a.gb) gbb = gs * a.gb[b];
+      const int pad = a.zf_len - a.zf_used;
+      for (int k = e; k < a.zf_nseg * pad; k += per_b) {
+        const int seg = k / pad;
+        a.d_enc[b * a.q.sb + (int64_t)seg * a.zf_len + a.zf_used + (k - seg * pad)] = 0.f;
+      }
+      mu = q_mu(a.enc, a.q, b, gp, j);
+      raw = a.enc[b * a.q.sb + gp * a.q.sg + a.q.raw_off + j];
+      sg = dmv_softplus(raw) + a.q.eps;
+      isg = 1.f / sg;
+      is2 = 1.f / (sg * sg);
+      smu[e] = mu;
+      sis2[e] = is2;
+      if (e < G) {
+        if (STRAT) {
+          const float* lg = a.enc + b * a.q.sb + a.q.logit_off;
+          float lm = -INFINITY;
+          for (int c = 0; c < G; ++c) lm = fmaxf(lm, lg[c]);
+          float ss = 0.f;
+          for (int c = 0; c < G; ++c) ss += expf(lg[c] - lm);
+          slp[e] = lg[e] - (lm + logf(ss));
+          if (a.dlogit) acc_lg = a.base_w * gbb * a.dlogit[b * G + e];
+        } else {
+          slp[e] = -logf((float)G);
+        }
+      }
+    }
+    if (active) {
+      sz[e] = z;
+      if (e < G) sw[e] = a.base_qmix * gbb * wq;
+    }
+    __syncthreads();
+    if (active) {
+      if (e < GG) sr[e] = expf(slp[e - (e / G) * G] + clp - qm);
+      for (int k = e + per_b; k < GG; k += per_b) {
+        const int g = k / G, c = k - g * G;
+        const int64_t ng = ((int64_t)s * a.B + b) * G + g;
+        sr[k] = expf(slp[c] + a.comp_lp[ng * G + c] - a.qmix[ng]);
+      }
+    }
+    __syncthreads();
+    if (active) {
+      // (1) reparameterised path: only samples drawn from component gp depend on (mu, sigma)_{gp}
+      const float w = gbb * wv, wo = gbb * wov;
+      float dz = dzv + a.base_prior * w * (-z);
+      if (a.base_qown != 0.f) dz += a.base_qown * wo * (-(z - mu) * is2);
+      float t = 0.f;
+      for (int c = 0; c < G; ++c) t += sr[gp * G + c] * (-(z - smu[c * Zd + j]) * sis2[c * Zd + j]);
+      dz += sw[gp] * t;
+      dz *= zs;
+      acc_mu += dz;
+      acc_sg += dz * ep;
+      // (2) direct dependence of log q_own on its parameters
+      if (a.own_live && a.base_qown != 0.f) {
+        const float df = z - mu;
+        acc_mu += a.base_qown * wo * (df * is2);
+        acc_sg += a.base_qown * wo * (df * df * is2 * isg - isg);
+      }
+      // (3) direct dependence of log q_mix (evaluated at every sample of the datapoint) on component gp
+      if (a.mix_live) {
+        for (int g = 0; g < G; ++g) {
+          const float wr = sw[g] * sr[g * G + gp];
+          const float df = sz[g * Zd + j] - mu;
+          acc_mu += wr * (df * is2);
+          acc_sg += wr * (df * df * is2 * isg - isg);
+        }
+        if (STRAT && e < G) {
+          const float pi = expf(slp[e]);
+          for (int g = 0; g < G; ++g) acc_lg += sw[g] * (sr[g * G + e] - pi);
+        }
+      }
+    }
+    if (s + 1 < a.S) __syncthreads();
+  }
+  if (!active) return;
+  if (a.kl_coef != 0.f) {
+    const float kc = a.kl_coef * gs * (a.kl_wgt ? a.kl_wgt[b * G + gp] : 1.f);
+    acc_mu += kc * mu;
+    acc_sg += kc * (sg - isg);
+  }
+  a.d_enc[b * a.q.sb + gp * a.q.sg + j] = acc_mu;
+  a.d_enc[b * a.q.sb + gp * a.q.sg + a.q.raw_off + j] = acc_sg * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
+  if (STRAT && e < G) a.d_enc[b * a.q.sb + a.q.logit_off + e] = acc_lg;
+}
+
 // ------------------------------------------------------------------------------------------
 // Implicit reparameterisation gradients of mixture samples
 // (vgiwae/shared/reparametrized_mixture_same_family.py:27-191).  z ~ sum_k pi_k N(mu_k, diag sigma_k^2) is drawn
@@ -1257,6 +1395,23 @@ static int backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const fl
     a.zf_used = p->mix_kind == DMV_Q_STRATIFIED ? (int)cfg->logit_off + cfg->G : (int)cfg->raw_off + cfg->G * cfg->Zd;
   }
   if (a.zf_used > a.zf_len) return DMV_E_BADARG;
+  const int per_b = cfg->G * cfg->Zd;
+  if (p->base_qmix != 0.f && per_b <= 1024) {
+    // datapoints per workgroup: about 256 threads, at most 48 KB of LDS (one datapoint needs at most 29 KB)
+    const size_t dp_bytes = (size_t)(3 * per_b + 2 * cfg->G + cfg->G * cfg->G) * sizeof(float);
+    int nb = per_b >= 256 ? 1 : 256 / per_b;
+    if ((size_t)nb * dp_bytes > 49152) nb = (int)(49152 / dp_bytes);
+    if (nb < 1) nb = 1;
+    if (nb > cfg->B) nb = cfg->B;
+    const unsigned threads = (unsigned)((nb * per_b + 63) / 64 * 64);
+    const unsigned blocks = (unsigned)((cfg->B + nb - 1) / nb);
+    if (p->mix_kind == DMV_Q_STRATIFIED)
+      hipLaunchKernelGGL(k_obj_bwd_latent_mix<true>, dim3(blocks), dim3(threads), nb * dp_bytes, (hipStream_t)stream, a, nb, per_b);
+    else
+      hipLaunchKernelGGL(k_obj_bwd_latent_mix<false>, dim3(blocks), dim3(threads), nb * dp_bytes, (hipStream_t)stream, a, nb, per_b);
+    DMV_HIP_CHECK_LAUNCH();
+    return DMV_OK;
+  }
   hipLaunchKernelGGL(k_obj_bwd_latent, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;

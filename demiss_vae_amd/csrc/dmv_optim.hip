@@ -330,8 +330,8 @@ extern "C" int dmv_opt_adam_step_static(int32_t n, float* const* params, const f
   const int rc = check_tables(n, params, grads, exp_avg, exp_avg_sq, numel, group_of, n_groups, groups);
   if (rc) return rc;
   const size_t need = dmv_opt_ws_floats(n, numel);
-  if (need == 0) return DMV_E_BADARG;
-  if (need > (size_t)DMV_OPT_STATIC_WS_FLOATS) return DMV_E_WORKSPACE;   // more parameters than the static array serves
+  // a size table dmv_opt_ws_floats cannot size (negative or > 2^31 elements) gets the code dmv_opt_adam_step gives it
+  if (need == 0 || need > (size_t)DMV_OPT_STATIC_WS_FLOATS) return DMV_E_WORKSPACE;   // more parameters than the static array serves
   float* ws = nullptr;
   const int rs = scratch_address(&ws);
   if (rs) return rs;

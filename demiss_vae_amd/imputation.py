@@ -113,6 +113,23 @@ def _sample_cfg(dims: ModelDims, rows: int, I: int, ld_enc: int):
     return cfg
 
 
+def _one_launch_pass(dims: ModelDims, enc, dec, X2, M2, rows: int, I: int, eps2, training: bool):
+    """Encoder on `rows` rows, I latent draws per row and the decoder on them in one launch when the library takes the
+    shapes (objectives.fused_forward), no gradient bookkeeping: (enc_out, Z, cfg, dec_out) or None."""
+    from .objectives import fused_forward
+    if not (isinstance(enc, PackedNet) and isinstance(dec, PackedNet)):
+        return None
+    if training and ((enc.dims.dropout > 0 and enc.dims.nb > 0) or (dec.dims.dropout > 0 and dec.dims.nb > 0)):
+        return None             # training-mode dropout inside the sampler's passes: separate launches draw the masks
+    cfg = _sample_cfg(dims, rows, I, pad32(enc.dims.out_dim))
+    in_mode = L.IN_CONCAT if dims.encoder_use_mis_mask else L.IN_PLAIN
+    out = fused_forward(cfg, enc, dec, in_mode, X2, M2, eps2, False, False)
+    if out is None:
+        return None
+    enc_out, _, Z, _, dec_out, _ = out
+    return enc_out, Z, cfg, dec_out
+
+
 def _tail(dims, dec_out, row_map, X_old, M, noise, clip_min, clip_max, clip_after_blend, buf, idx_imp):
     N, D = X_old.shape[0] * X_old.shape[1], dims.D
     X_out = torch.empty_like(X_old)
@@ -159,19 +176,23 @@ def pseudo_gibbs(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_i
     cmax = clip_max.to(dev).float().contiguous() if clip_max is not None else None
     N = B * K
     for t in range(num_iterations):
-        enc_out = _encode_rows(dims, enc, Xc.reshape(N, D), Mu.reshape(N, D), _keep(enc, N, training, dev))
-        cfg = _sample_cfg(dims, N, 1, enc_out.shape[1])
-        Z = torch.empty((N, dims.Zd), dtype=torch.float32, device=dev)
-        if eps_z is not None:
-            e = eps_z[t].reshape(N, dims.Zd).contiguous().float()
-            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(e), 0, 0, None, dims.Zd, None, L.ptr(Z), None, st))
+        e = eps_z[t].reshape(N, dims.Zd).contiguous().float() if eps_z is not None else None
+        one = _one_launch_pass(dims, enc, dec, Xc.reshape(N, D), Mu.reshape(N, D), N, 1, e, training)
+        if one is None:
+            enc_out = _encode_rows(dims, enc, Xc.reshape(N, D), Mu.reshape(N, D), _keep(enc, N, training, dev))
+            cfg = _sample_cfg(dims, N, 1, enc_out.shape[1])
+            Z = torch.empty((N, dims.Zd), dtype=torch.float32, device=dev)
+            if e is not None:
+                L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(e), 0, 0, None, dims.Zd, None, L.ptr(Z), None, st))
+            else:
+                seed, off = rng.next_offset(N * dims.Zd)
+                L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, rng.base_ptr(), dims.Zd, None, L.ptr(Z), None, st))
+            if isinstance(dec, PackedNet):
+                dec_out, _ = mlp_forward(dec, Z, dims.Zd, N, save=False, drop_keep=_keep(dec, N, training, dev))
+            else:
+                dec_out = dec(Z).reshape(N, -1).contiguous().float()
         else:
-            seed, off = rng.next_offset(N * dims.Zd)
-            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, rng.base_ptr(), dims.Zd, None, L.ptr(Z), None, st))
-        if isinstance(dec, PackedNet):
-            dec_out, _ = mlp_forward(dec, Z, dims.Zd, N, save=False, drop_keep=_keep(dec, N, training, dev))
-        else:
-            dec_out = dec(Z).reshape(N, -1).contiguous().float()
+            dec_out = one[3]
         last = t == num_iterations - 1
         Xc = _tail(dims, dec_out, None, Xc, Mu, noise_x[t] if noise_x is not None else None, cmin, cmax, False,
                    buf if last else None, idx_imp.reshape(-1).contiguous() if (last and idx_imp is not None) else None)
@@ -209,23 +230,29 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
         rep[:, :, Zd:2 * Zd] = float(softplus_inverse(torch.tensor(1.0 - (1e-5 if dims.q_eps else 0.0), dtype=torch.float32)))
         Me = torch.cat([Mu, Mu[:, :1].expand(B, r, D)], dim=1).contiguous()
     for t in range(num_iterations):
-        enc_out = _encode_rows(dims, enc, Xc.reshape(B * K, D), Mu.reshape(B * K, D), _keep(enc, B * K, training, dev))
-        ldE = enc_out.shape[1]
-        Xe = Xc
-        if r > 0:
-            enc_out = torch.cat([enc_out.reshape(B, K, ldE), rep], dim=1).reshape(B * Kp, ldE).contiguous()
-            Xe = torch.cat([Xc, Xc[:, :1].expand(B, r, D)], dim=1).contiguous()
-        # proposals z[i, b, k] ~ q(. | component (b, k))
         N = I * B * Kp
-        scfg = _sample_cfg(dims, B * Kp, I, ldE)
-        Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
-        if eps_z is not None:
-            e = eps_z[t].reshape(N, Zd).contiguous().float()
-            L.check(lib.dmv_latent_sample(C.byref(scfg), L.ptr(enc_out), L.ptr(e), 0, 0, None, Zd, None, L.ptr(Z), None, st))
+        e = eps_z[t].reshape(N, Zd).contiguous().float() if eps_z is not None else None
+        one = _one_launch_pass(dims, enc, dec, Xc.reshape(B * K, D), Mu.reshape(B * K, D), B * K, I, e, training) if r == 0 else None
+        if one is not None:
+            enc_out, Z, _, dec_out = one
+            ldE = enc_out.shape[1]
+            Xe = Xc
         else:
-            seed, off = rng.next_offset(N * Zd)
-            L.check(lib.dmv_latent_sample(C.byref(scfg), L.ptr(enc_out), None, seed, off, rng.base_ptr(), Zd, None, L.ptr(Z), None, st))
-        dec_out, _ = mlp_forward(dec, Z, Zd, N, save=False, drop_keep=_keep(dec, N, training, dev))
+            enc_out = _encode_rows(dims, enc, Xc.reshape(B * K, D), Mu.reshape(B * K, D), _keep(enc, B * K, training, dev))
+            ldE = enc_out.shape[1]
+            Xe = Xc
+            if r > 0:
+                enc_out = torch.cat([enc_out.reshape(B, K, ldE), rep], dim=1).reshape(B * Kp, ldE).contiguous()
+                Xe = torch.cat([Xc, Xc[:, :1].expand(B, r, D)], dim=1).contiguous()
+            # proposals z[i, b, k] ~ q(. | component (b, k))
+            scfg = _sample_cfg(dims, B * Kp, I, ldE)
+            Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
+            if e is not None:
+                L.check(lib.dmv_latent_sample(C.byref(scfg), L.ptr(enc_out), L.ptr(e), 0, 0, None, Zd, None, L.ptr(Z), None, st))
+            else:
+                seed, off = rng.next_offset(N * Zd)
+                L.check(lib.dmv_latent_sample(C.byref(scfg), L.ptr(enc_out), None, seed, off, rng.base_ptr(), Zd, None, L.ptr(Z), None, st))
+            dec_out, _ = mlp_forward(dec, Z, Zd, N, save=False, drop_keep=_keep(dec, N, training, dev))
         # DMIS log-weights: uniform mixture over the K+r components of the datapoint (shared/iwae.py:57-100)
         cfg = L.DmvObjCfg()
         cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, Kp, 1, I, D, Zd
@@ -237,8 +264,17 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
         f = L.DmvObjFwd()
         f.q_kind, f.mix_C, f.kind = L.Q_IMPUTATION, Kp, L.BOUND_LSE
         f.log_w, f.bound = L.addr(log_w), L.addr(per_b)
-        L.check(lib.dmv_obj_forward(C.byref(cfg), C.byref(f), L.ptr(dec_out), dec_out.shape[1], L.ptr(Xe), L.ptr(Me),
-                                    L.ptr(Z), Zd, L.ptr(enc_out), st))
+        rc = lib.dmv_obj_forward(C.byref(cfg), C.byref(f), L.ptr(dec_out), dec_out.shape[1], L.ptr(Xe), L.ptr(Me),
+                                 L.ptr(Z), Zd, L.ptr(enc_out), st)
+        if rc == L.E_UNSUPPORTED and I * Kp > 1024:
+            # more proposals per datapoint than the one-launch kernel stages in LDS: terms, then the looping bound kernel
+            terms = torch.empty((5, N), dtype=torch.float32, device=dev)
+            L.check(lib.dmv_obj_terms(C.byref(cfg), L.Q_IMPUTATION, Kp, L.ptr(dec_out), dec_out.shape[1], L.ptr(Xe), L.ptr(Me),
+                                      L.ptr(Z), Zd, L.ptr(enc_out), L.ptr(terms), None, st))
+            L.check(lib.dmv_obj_bound(C.byref(cfg), L.BOUND_LSE, L.Q_IMPUTATION, 0, 0, L.ptr(enc_out), L.ptr(terms),
+                                      L.ptr(log_w), L.ptr(per_b), None, None, None, None, st))
+        else:
+            L.check(rc)
         logits = log_w.reshape(I, B, Kp).permute(1, 0, 2).reshape(B, I * Kp).contiguous()   # 'i b k -> b (i k)'
         if idx is not None:
             draw = idx[t].to(dev, torch.int64).t().contiguous()                 # [B, K+r]

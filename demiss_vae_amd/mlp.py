@@ -122,6 +122,15 @@ class PackedNet:
                 return None
         return [slab[o:o + t.numel()].view(t.shape) for o, t in zip(self._slab_offsets, ps)]
 
+    def refuse_pass_during_exchange(self):
+        """A backward pass that produces parameter gradients while this network's overlapped exchange is in flight
+        would accumulate into the buffer the collective is reducing, and its contribution would never be exchanged:
+        refuse it (overlap_grad_exchange allows one backward pass per step; accumulate without the overlap instead)."""
+        if self.pending_exchange is not None:
+            raise RuntimeError("a backward pass reached this network's parameters while the exchange of its gradients "
+                               "from an earlier pass is in flight: with overlap_grad_exchange a step has one backward "
+                               "pass per network (call allreduce_grads first, or do not overlap)")
+
     def grads_live_in_slab(self) -> bool:
         """every parameter's .grad is the slab's view of it (autograd kept the tensors the backward pass returned)"""
         if self._slab is None:
@@ -267,6 +276,7 @@ def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: in
     gw_arr = gb_arr = None
     in_slab = False
     if need_param_grads:
+        net.refuse_pass_during_exchange()
         views = net.grad_views() if net.flat_grads else None
         if views is not None:
             gws, gbs, in_slab = views[0::2], views[1::2], True
@@ -304,6 +314,33 @@ def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: in
         if complete and in_slab and net.on_grads_ready is not None:
             net.on_grads_ready(net)
     return dx, grads
+
+
+def mlp_wgrad(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: int, ws: torch.Tensor, nbytes: int, *,
+              stream: Optional[torch.cuda.Stream] = None, complete: bool = False):
+    """The weight-gradient half of a backward pass whose input-gradient chain already left the per-layer gradients in
+    `ws` (dmv_mlp_backward with grad_w = NULL, or dmv_vae_backward): [gW0, gb0, gW1, ...], into the network's permanent
+    gradient buffer when it has one.  stream: run there (the caller has made it wait for the chain and joins it before
+    the gradients are used); complete: as in mlp_backward."""
+    net.refuse_pass_during_exchange()
+    views = net.grad_views() if net.flat_grads else None
+    if views is not None:
+        gws, gbs, in_slab = views[0::2], views[1::2], True
+    else:
+        gws, gbs, in_slab = [torch.empty_like(w) for w in net.weights], [torch.empty_like(b) for b in net.biases], False
+    st = C.c_void_p(stream.cuda_stream) if stream is not None else L.stream_ptr()
+    L.check(L.lib().dmv_mlp_backward_wgrad(C.byref(net.c), L.ptr(saved), L.ptr(gy), gy.shape[1], rows, L.ptr_array(gws),
+                                           L.ptr_array(gbs), 0.0, L.ptr(ws), nbytes, st))
+    if complete and in_slab and net.on_grads_ready is not None:
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                net.on_grads_ready(net)
+        else:
+            net.on_grads_ready(net)
+    grads = []
+    for w, b in zip(gws, gbs):
+        grads += [w, b]
+    return grads
 
 
 def make_keep_masks(dims: NetDims, rows: int, device, generator: Optional[torch.Generator] = None):

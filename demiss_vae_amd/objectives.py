@@ -23,7 +23,7 @@ import torch
 
 from . import _lib as L
 from . import rng
-from .mlp import PackedNet, mlp_forward, mlp_backward, pad32, side_stream, overlap_pays
+from .mlp import PackedNet, GeneratedDropout, mlp_forward, mlp_backward, mlp_wgrad, pad32, side_stream, overlap_pays
 
 
 @dataclass(frozen=True)
@@ -76,6 +76,38 @@ class _Ctx:
     pass
 
 
+FUSE_SMALL_FORWARD = True      # tests switch it off to compare with the three separate launches
+
+
+def fused_forward(cfg, enc: PackedNet, dec: PackedNet, in_mode, X2, M2, eps2, save: bool, keep_eps: bool):
+    """Encoder -> z = mu + sigma eps -> decoder in one launch (dmv_vae_forward) when the shapes allow it, else None.
+    X2 / M2 [enc_rows, D]; eps2 [N, Zd] or None (device Philox).  Returns (enc_out, enc_saved, Z, eps_used, dec_out,
+    dec_saved) exactly as the separate launches leave them."""
+    lib = L.lib()
+    if not FUSE_SMALL_FORWARD or not lib.dmv_vae_forward_fits(C.byref(cfg), C.byref(enc.c), C.byref(dec.c)):
+        return None
+    if save and ((enc.dims.dropout > 0 and enc.dims.nb > 0) or (dec.dims.dropout > 0 and dec.dims.nb > 0)):
+        return None
+    dev = X2.device
+    Zd = cfg.Zd
+    enc_rows = cfg.B * (cfg.G if cfg.x_per_component else 1)
+    N = cfg.nz * cfg.I * cfg.B * cfg.G
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    enc_out, dec_out, Z = new(enc_rows, pad32(enc.dims.out_dim)), new(N, pad32(dec.dims.out_dim)), new(N, Zd)
+    enc_saved = new(lib.dmv_mlp_saved_floats(C.byref(enc.c), enc_rows)) if save else None
+    dec_saved = new(lib.dmv_mlp_saved_floats(C.byref(dec.c), N)) if save else None
+    if eps2 is not None:
+        eps_used, seed, off, base = eps2, 0, 0, None
+    else:
+        eps_used = new(N, Zd) if keep_eps else None
+        seed, off = rng.next_offset(N * Zd)
+        base = rng.base_ptr()
+    L.check(lib.dmv_vae_forward(C.byref(cfg), C.byref(enc.c), L.ptr(enc.packed()), in_mode, L.ptr(X2), L.ptr(M2), C.byref(dec.c),
+                                L.ptr(dec.packed()), L.ptr(eps2), seed, off, base, L.ptr(enc_out), L.ptr(enc_saved), L.ptr(Z),
+                                Zd, L.ptr(eps_used) if eps2 is None else None, L.ptr(dec_out), L.ptr(dec_saved), L.stream_ptr()))
+    return enc_out, enc_saved, Z, eps_used, dec_out, dec_saved
+
+
 def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, X, M, eps, enc_keep, dec_keep,
                   training: bool, comp_idx=None):
     """Runs the forward pipeline; returns a context holding every buffer the backward needs."""
@@ -103,9 +135,7 @@ def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, 
         in_mode = L.IN_CONCAT if demiss else L.IN_CONCAT_MASKED
     else:
         in_mode = L.IN_PLAIN if demiss else L.IN_MASKED
-    enc_out, enc_saved = mlp_forward(enc, Xc, D, enc_rows, in_mode=in_mode, D=D, m=Mu, ldm=D, save=training,
-                                     drop_keep=enc_keep)
-    ldE = enc_out.shape[1]
+    ldE = pad32(enc.dims.out_dim)
 
     cfg = L.DmvObjCfg()
     cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, G, nz, I, D, Zd
@@ -117,23 +147,33 @@ def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, 
         cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, Zd, dims.C * Zd, 2 * dims.C * Zd
     else:
         cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = ldE, 0, Zd, 0
-    if dims.q_is_reparam:
-        comp_idx, eps = reparam_components(dims, cfg, enc_out, comp_idx, eps)
-
-    # ---- z = mu + sigma * eps
-    Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
-    if eps is not None:
-        eps_used = eps.reshape(N, Zd).contiguous().float()
-        L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(eps_used), 0, 0, None, Zd, L.ptr(comp_idx),
-                                      L.ptr(Z), None, st))
+    fused = None
+    if not dims.q_is_reparam and comp_idx is None and enc_keep is None and dec_keep is None:
+        # small batches: encoder, sampling and decoder in one launch
+        fused = fused_forward(cfg, enc, dec, in_mode, Xc.reshape(enc_rows, D), Mu.reshape(enc_rows, D),
+                              eps.reshape(N, Zd).contiguous().float() if eps is not None else None, training, training)
+    if fused is not None:
+        enc_out, enc_saved, Z, eps_used, dec_out, dec_saved = fused
     else:
-        eps_used = torch.empty((N, Zd), dtype=torch.float32, device=dev) if training else None
-        seed, off = rng.next_offset(N * Zd)
-        L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, rng.base_ptr(), Zd, L.ptr(comp_idx),
-                                      L.ptr(Z), L.ptr(eps_used), st))
+        enc_out, enc_saved = mlp_forward(enc, Xc, D, enc_rows, in_mode=in_mode, D=D, m=Mu, ldm=D, save=training,
+                                         drop_keep=enc_keep)
+        if dims.q_is_reparam:
+            comp_idx, eps = reparam_components(dims, cfg, enc_out, comp_idx, eps)
 
-    # ---- decoder
-    dec_out, dec_saved = mlp_forward(dec, Z, Zd, N, save=training, drop_keep=dec_keep)
+        # ---- z = mu + sigma * eps
+        Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
+        if eps is not None:
+            eps_used = eps.reshape(N, Zd).contiguous().float()
+            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), L.ptr(eps_used), 0, 0, None, Zd, L.ptr(comp_idx),
+                                          L.ptr(Z), None, st))
+        else:
+            eps_used = torch.empty((N, Zd), dtype=torch.float32, device=dev) if training else None
+            seed, off = rng.next_offset(N * Zd)
+            L.check(lib.dmv_latent_sample(C.byref(cfg), L.ptr(enc_out), None, seed, off, rng.base_ptr(), Zd, L.ptr(comp_idx),
+                                          L.ptr(Z), L.ptr(eps_used), st))
+
+        # ---- decoder
+        dec_out, dec_saved = mlp_forward(dec, Z, Zd, N, save=training, drop_keep=dec_keep)
 
     if demiss:
         q_kind, mix_C = L.Q_IMPUTATION, K
@@ -192,9 +232,35 @@ def _objective_forward(c, plan: _Plan, training: bool, *, kind, use_logpi=False,
         f.coefB = (C.c_float * 5)(*(coefB if coefB is not None else (0, 0, 0, 0, 0)))
         f.objA, f.objB, f.meanA_out, f.meanB_out = L.addr(objA), L.addr(objB), L.addr(mA), L.addr(mB)
         out = (objA, objB, mA, mB)
-    L.check(lib.dmv_obj_forward(C.byref(c.cfg), C.byref(f), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
-                                L.ptr(c.Z), c.Z.shape[1], L.ptr(c.enc_out), st))
+    rc = lib.dmv_obj_forward(C.byref(c.cfg), C.byref(f), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
+                             L.ptr(c.Z), c.Z.shape[1], L.ptr(c.enc_out), st)
+    if rc == L.E_UNSUPPORTED and c.cfg.nz * c.cfg.I * c.G > 1024:
+        # more samples per datapoint than the one-launch kernel stages in LDS (about 15 000): separate launches for
+        # the per-sample terms and for the bound / objectives over them, which loop over the samples
+        return _objective_unfused(c, plan, training, kind, coefA, coefB, want_means, need_comp)
+    L.check(rc)
     return out if out is not None else c.terms
+
+
+def _objective_unfused(c, plan: _Plan, training: bool, kind, coefA, coefB, want_means, need_comp):
+    """What _objective_forward returns, from dmv_obj_terms followed by dmv_obj_bound / dmv_obj_combine."""
+    lib, st = L.lib(), L.stream_ptr()
+    dev = c.dec_out.device
+    c.terms = torch.empty((5, c.N), dtype=torch.float32, device=dev)
+    c.comp_lp = torch.empty((c.N, c.mix_C), dtype=torch.float32, device=dev) if need_comp else None
+    L.check(lib.dmv_obj_terms(C.byref(c.cfg), c.q_kind, c.mix_C, L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
+                              L.ptr(c.Z), c.Z.shape[1], L.ptr(c.enc_out), L.ptr(c.terms), L.ptr(c.comp_lp), st))
+    if kind in (L.BOUND_LSE, L.BOUND_WEIGHTED):
+        per_b = _bound(c, plan, training)
+        mean = per_b.mean()
+        return per_b, mean, -mean
+    if kind == L.BOUND_PER_COMPONENT:
+        objA = _combine(c, coefA)
+        objB = _combine(c, coefB) if coefB is not None else None
+        mA = objA.mean() if want_means else None
+        mB = objB.mean() if (want_means and objB is not None) else None
+        return objA, objB, mA, mB
+    return c.terms
 
 
 def reparam_components(dims: ModelDims, cfg, enc_out, comp_idx, eps):
@@ -284,6 +350,47 @@ def _enc_side(c, enc: PackedNet, p: L.DmvLatentBwd, dZ, wgt, zscale, dlogit, kl_
     _, grads = mlp_backward(enc, c.enc_saved, d_enc, c.enc_rows, need_dx=False, need_param_grads=True,
                             drop_keep=c.enc_keep)
     return grads
+
+
+FUSE_SMALL_BACKWARD = True     # tests switch it off to compare with the separate launches
+
+
+def _one_launch_backward(c, enc: PackedNet, dec: PackedNet, p: L.DmvLatentBwd, wgt_dec, base_m, base_f, wgt, zscale, kl_wgt,
+                         gb_dec, gb_lat, gscale, dec_param_grads: bool, complete: bool = False):
+    """Decoder-side gradient, then the decoder's chain, the latent-side gradient and the encoder's chain in one launch
+    (dmv_vae_backward), then the weight gradients of both networks side by side on two streams.  For posteriors
+    without a mixture term on batches small enough for the 16-row kernels; returns (decoder parameter gradients or
+    None, encoder parameter gradients), or None when the library does not take the case."""
+    lib, st = L.lib(), L.stream_ptr()
+    if not FUSE_SMALL_BACKWARD or p.base_qmix != 0.0 or c.reparam:
+        return None
+    if not lib.dmv_vae_backward_fits(C.byref(c.cfg), C.byref(enc.c), C.byref(dec.c)):
+        return None
+    dev = c.dec_out.device
+    d_dec = torch.empty_like(c.dec_out)
+    L.check(lib.dmv_obj_backward_dec(C.byref(c.cfg), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
+                                     L.ptr(wgt_dec), L.ptr(gb_dec), L.ptr(gscale), base_m, base_f, L.ptr(d_dec), d_dec.shape[1], st))
+    d_enc = torch.empty_like(c.enc_out)
+    nb_dec = lib.dmv_mlp_backward_ws_bytes(C.byref(dec.c), c.N)
+    nb_enc = lib.dmv_mlp_backward_ws_bytes(C.byref(enc.c), c.enc_rows)
+    ws_dec = torch.empty((nb_dec + 3) // 4, dtype=torch.float32, device=dev)
+    ws_enc = torch.empty((nb_enc + 3) // 4, dtype=torch.float32, device=dev)
+    keep = lambda k: L.DROP_GENERATED if isinstance(k, GeneratedDropout) else L.ptr(k)
+    L.check(lib.dmv_vae_backward(
+        C.byref(c.cfg), C.byref(p), C.byref(dec.c), L.ptr(dec.packed()), L.ptr(c.dec_saved), keep(c.dec_keep), L.ptr(d_dec),
+        d_dec.shape[1], L.ptr(ws_dec), nb_dec, C.byref(enc.c), L.ptr(enc.packed()), L.ptr(c.enc_saved), keep(c.enc_keep),
+        L.ptr(d_enc), L.ptr(ws_enc), nb_enc, L.ptr(c.enc_out), L.ptr(c.Z), L.ptr(c.eps), c.Z.shape[1], L.ptr(wgt), L.ptr(gb_lat),
+        L.ptr(zscale), L.ptr(kl_wgt), L.ptr(gscale), st))
+    g_dec = None
+    side = None
+    if dec_param_grads:
+        side = side_stream(dev)
+        side.wait_stream(torch.cuda.current_stream())
+        g_dec = mlp_wgrad(dec, c.dec_saved, d_dec, c.N, ws_dec, nb_dec, stream=side, complete=complete)
+    g_enc = mlp_wgrad(enc, c.enc_saved, d_enc, c.enc_rows, ws_enc, nb_enc)
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
+    return g_dec, g_enc
 
 
 def _implicit_d_enc(c, dZ, wgt, base_prior, base_qmix):
@@ -391,6 +498,11 @@ class _FusedObjective(torch.autograd.Function):
 
         if k in ("iwae", "miwae") and any(g is not None for g in gouts):
             gb, gs, f = upstream(*gouts)
+            if c.q_kind == L.Q_OWN and not c.reparam:
+                p = _latent_params(prior=f, qown=-f, w=f, own_live=not (plan.STL or plan.DREG), use_zscale=plan.DREG)
+                one = _one_launch_backward(c, enc, dec, p, c.wgt, f, 0.0, c.wgt, c.zscale, None, gb, gb, gs, True, complete=True)
+                if one is not None:
+                    return (None,) * 10 + tuple(one[1]) + tuple(one[0])
             pending = []
             # (the decoder's gradients are whole here: one backward pass per step for these objectives)
             dZ, g_dec_params = _dec_side(c, dec, c.wgt, f, 0.0, True, True, overlap=pending, gb=gb, gscale=gs, complete=True)
@@ -409,10 +521,13 @@ class _FusedObjective(torch.autograd.Function):
             _join(pending)
         elif k == "elbo_analytic" and any(g is not None for g in gouts):
             gb, gs, f = upstream(*gouts)
+            p = _latent_params(kl=-f)
+            one = _one_launch_backward(c, enc, dec, p, None, f / nz, 0.0, None, None, gb, gb, None, gs, True, complete=True)
+            if one is not None:
+                return (None,) * 10 + tuple(one[1]) + tuple(one[0])
             pending = []
             dZ, g_dec_params = _dec_side(c, dec, None, f / nz, 0.0, True, True, overlap=pending, gb=gb, gscale=gs,
                                          complete=True)
-            p = _latent_params(kl=-f)
             g_enc_params = _enc_side(c, enc, p, dZ, None, None, None, gb.reshape(B, 1) if gb is not None else None, gscale=gs)
             _join(pending)
         elif k == "cvi" and gouts[0] is not None:
@@ -424,6 +539,14 @@ class _FusedObjective(torch.autograd.Function):
             _join(pending)
         elif k == "mvb" and gouts[0] is not None:
             wt = per_sample(gouts[0])
+            if plan.kl_analytic:
+                one = _one_launch_backward(c, enc, dec, _latent_params(kl=-1.0), wt, 0.0, 1.0, wt, None,
+                                           gouts[0].float().contiguous(), None, None, None, True)
+            else:
+                one = _one_launch_backward(c, enc, dec, _latent_params(prior=1.0, qown=-1.0, own_live=not plan.STL), wt, 0.0, 1.0,
+                                           wt, None, None, None, None, None, True)
+            if one is not None:
+                return (None,) * 10 + tuple(one[1]) + tuple(one[0])
             pending = []
             dZ, g_dec_params = _dec_side(c, dec, wt, 0.0, 1.0, True, True, overlap=pending)
             if plan.kl_analytic:
@@ -444,24 +567,31 @@ class _FusedObjective(torch.autograd.Function):
                     _, g_dec_params = _dec_side(c, dec, None, f, 0.0, False, True, gscale=g_gen.float())
                 if g_enc is not None:
                     gs = g_enc.float()
-                    dZ, _ = _dec_side(c, dec, None, 0.0, f, True, False, gscale=gs)
                     if plan.kl_analytic:
                         p = _latent_params(kl=-1.0 / (B * G))
                     else:
                         p = _latent_params(prior=f, qown=-f, own_live=not plan.STL)
-                    g_enc_params = _enc_side(c, enc, p, dZ, None, None, None, None, gscale=gs)
+                    one = _one_launch_backward(c, enc, dec, p, None, 0.0, f, None, None, None, None, None, gs, False)
+                    if one is not None:
+                        g_enc_params = one[1]
+                    else:
+                        dZ, _ = _dec_side(c, dec, None, 0.0, f, True, False, gscale=gs)
+                        g_enc_params = _enc_side(c, enc, p, dZ, None, None, None, None, gscale=gs)
             else:
                 if g_gen is not None:
                     _, g_dec_params = _dec_side(c, dec, per_sample(g_gen), 1.0, 0.0, False, True)
                 if g_enc is not None:
                     wt = per_sample(g_enc)
-                    dZ, _ = _dec_side(c, dec, wt, 0.0, 1.0, True, False)
                     if plan.kl_analytic:
-                        p = _latent_params(kl=-1.0)
-                        g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, g_enc.float().contiguous())
+                        p, klw = _latent_params(kl=-1.0), g_enc.float().contiguous()
                     else:
-                        p = _latent_params(prior=1.0, qown=-1.0, own_live=not plan.STL)
-                        g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, None)
+                        p, klw = _latent_params(prior=1.0, qown=-1.0, own_live=not plan.STL), None
+                    one = _one_launch_backward(c, enc, dec, p, wt, 0.0, 1.0, wt, None, klw, None, None, None, False)
+                    if one is not None:
+                        g_enc_params = one[1]
+                    else:
+                        dZ, _ = _dec_side(c, dec, wt, 0.0, 1.0, True, False)
+                        g_enc_params = _enc_side(c, enc, p, dZ, wt, None, None, klw)
         return (None,) * 10 + tuple(g_enc_params) + tuple(g_dec_params)
 
 

@@ -52,12 +52,9 @@ class Adam(torch.optim.Optimizer):
         if len(ps) > 72:
             raise NotImplementedError("more than 72 parameter tensors")
         group_of = []
-        # groups that start with the same rate share one device scalar (one write per step under a schedule instead
-        # of one per group); sync_lr gives a group its own scalar again the moment its rate differs
-        self._lr_dev = []
-        for gi, g in enumerate(self.param_groups):
-            same = [gj for gj in range(gi) if float(self.param_groups[gj]["lr"]) == float(g["lr"])]
-            self._lr_dev.append(self._lr_dev[same[0]] if same else torch.tensor(float(g["lr"]), device=dev))
+        # one device scalar per group, kept for the optimiser's lifetime: a step recorded in a HIP graph holds these
+        # addresses, so they are only ever written in place
+        self._lr_dev = [torch.tensor(float(g["lr"]), device=dev) for g in self.param_groups]
         self._step_dev = [torch.zeros((), device=dev) for _ in self.param_groups]
         self._lr_written = [float(g["lr"]) for g in self.param_groups]
         for gi, g in enumerate(self.param_groups):
@@ -104,19 +101,10 @@ class Adam(torch.optim.Optimizer):
         """write the groups' (host) learning rates to their device mirrors where they changed"""
         if self._built is None:
             return
-        rates = [float(g["lr"]) for g in self.param_groups]
-        for gi in range(len(rates)):
-            for gj in range(gi):
-                if self._lr_dev[gi] is self._lr_dev[gj] and rates[gi] != rates[gj]:
-                    self._built = None           # rates that were equal have parted: separate scalars, new tables
-                    self._build()
-                    return
-        written = set()
-        for gi, lr in enumerate(rates):
+        for gi, g in enumerate(self.param_groups):
+            lr = float(g["lr"])
             if lr != self._lr_written[gi]:
-                if id(self._lr_dev[gi]) not in written:
-                    self._lr_dev[gi].fill_(lr)
-                    written.add(id(self._lr_dev[gi]))
+                self._lr_dev[gi].fill_(lr)
                 self._lr_written[gi] = lr
 
     @torch.no_grad()
@@ -132,7 +120,6 @@ class Adam(torch.optim.Optimizer):
             if [net._packed.data_ptr() for net in self._image_nets] != b["images"]:
                 b = self._build()      # an image moved (parameters went to another device)
         self.sync_lr()
-        b = self._built                # (sync_lr rebuilds the tables when groups' rates part ways)
         live = [i for i, p in enumerate(b["ps"]) if p.grad is not None]
         if not live:
             return loss

@@ -169,6 +169,44 @@ int dmv_latent_sample(const DmvObjCfg* cfg, const float* enc, const float* eps, 
                       const uint64_t* offset_base, int64_t ldz, const int64_t* comp_idx, float* Z, float* eps_out,
                       void* stream);
 
+/* Encoder -> latent sample -> decoder of a small batch in ONE launch (vgiwae/models/vae.py:285-318, vae_forward:
+ * predict_var_latent_params :80-91, rsample :303, generator_network :309; shared/neural_nets.py:127-133).  Equivalent to
+ * dmv_mlp_forward(enc) + dmv_latent_sample + dmv_mlp_forward(dec) and writes the same buffers with the same values:
+ * enc_out [enc_rows][pad32(enc out_dim)], Z / eps_out [N][ldz], dec_out [N][pad32(dec out_dim)], and - when both are
+ * given - the saved activations of the two networks (dmv_mlp_saved_floats each).  enc_rows = B (cfg->x_per_component
+ * == 0: one encoder row per datapoint, X / M [B][D]) or B*G (x_per_component == 1: one per imputation, X / M [B][G][D]);
+ * N = nz*I*B*G <= 4096 sample rows.  cfg's encoder-output addressing must be that of a row-major
+ * [enc_rows][pad32(out_dim)] array.  Each 16-row tile of samples recomputes the encoder rows it draws from, so the
+ * encoder outputs and the latents never leave the compute unit between the three stages.
+ * dmv_vae_forward_fits: 1 when the shapes qualify (relu networks of equal hidden tile count <= 8, N <= 4096,
+ * Zd <= 256), else 0; dmv_vae_forward returns DMV_E_UNSUPPORTED for shapes that do not, and for a training pass
+ * (saved activations requested) of networks with dropout, whose keep decisions the separate launches draw. */
+int dmv_vae_forward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec);
+int dmv_vae_forward(const DmvObjCfg* cfg, const DmvNet* enc, const float* enc_packed, int32_t in_mode, const float* X,
+                    const uint8_t* M, const DmvNet* dec, const float* dec_packed, const float* eps, uint64_t seed,
+                    uint64_t offset, const uint64_t* offset_base, float* enc_out, float* enc_saved, float* Z,
+                    int64_t ldz, float* eps_out, float* dec_out, float* dec_saved, void* stream);
+
+/* The input-gradient half of a small batch's backward pass in ONE launch (the backward of vae_forward,
+ * vgiwae/models/vae.py:285-318, that autograd builds for the reference): decoder chain -> gradient w.r.t. the encoder
+ * outputs -> encoder chain, equivalent to dmv_mlp_backward(dec, grad_w = NULL) + dmv_obj_backward_latent +
+ * dmv_mlp_backward(enc, grad_w = NULL).  d_dec [N][ld_ddec] is the gradient w.r.t. the decoder outputs
+ * (dmv_obj_backward_dec); d_enc [enc_rows][pad32(enc out_dim)] receives the gradient w.r.t. the encoder outputs (every
+ * entry written); dec_ws / enc_ws (dmv_mlp_backward_ws_bytes each) receive the per-layer gradients, after which
+ * dmv_mlp_backward_wgrad(dec, ..., d_dec, ..., dec_ws) and dmv_mlp_backward_wgrad(enc, ..., d_enc, ..., enc_ws) form the
+ * weight gradients.  p, wgt, gb, zscale, kl_wgt, gscale as in dmv_obj_backward_latent; posteriors without a mixture
+ * term only (p->base_qmix == 0), one Gaussian per encoder row (cfg->G == 1 or cfg->x_per_component == 1), at most 16
+ * samples per encoder row (nz*I <= 16: a row's samples share a 16-row tile) and the shapes dmv_vae_forward takes:
+ * dmv_vae_backward_fits tells (the mixture-term condition aside); otherwise DMV_E_UNSUPPORTED. */
+int dmv_vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec);
+int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, const DmvNet* dec, const float* dec_packed,
+                     const float* dec_saved, const uint8_t* dec_drop_keep, const float* d_dec, int64_t ld_ddec,
+                     void* dec_ws, size_t dec_ws_bytes, const DmvNet* enc, const float* enc_packed,
+                     const float* enc_saved, const uint8_t* enc_drop_keep, float* d_enc, void* enc_ws,
+                     size_t enc_ws_bytes, const float* enc_out, const float* Z, const float* eps, int64_t ldz,
+                     const float* wgt, const float* gb, const float* zscale, const float* kl_wgt, const float* gscale,
+                     void* stream);
+
 /* Per-sample terms (vgiwae/shared/iwae.py:17-45, 66-90, 102-132; models/mvbvae.py:83-137):
  *   terms[0][n] = sum_d M_d log p(x_d|z)      terms[1][n] = sum_d log p(x_d|z)
  *   terms[2][n] = sum_j log N(z_j;0,1)        terms[3][n] = log q_own(z)   terms[4][n] = log q_mix(z)

@@ -15,3 +15,22 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Leave the gradient-parity margins of this session (tests/golden_util.py:MARGINS) where a GPU run's results are
+    collected; tools/parity_margins.py renders them."""
+    import json
+    try:
+        import golden_util as gu
+    except Exception:
+        return
+    if not gu.MARGINS:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_margins.json"), "w") as f:
+            json.dump(gu.MARGINS, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

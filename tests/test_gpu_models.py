@@ -144,8 +144,20 @@ def test_conv_trunk_demissvae_matches_reference(tag):
     torch.testing.assert_close(enc_obj.cpu(), torch.from_numpy(g["enc_obj"]), rtol=2e-4, atol=2e-3)
     (-gen_obj.mean()).backward(retain_graph=True, inputs=list(dec.parameters()))
     (-enc_obj.mean()).backward(inputs=list(enc.parameters()))
-    assert gu.check_grads(g, "genc", {k: v.grad for k, v in enc.named_parameters() if v.grad is not None}, 5e-3, 1e-5, floor=2e-3) > 5
-    assert gu.check_grads(g, "gdec", {k: v.grad for k, v in dec.named_parameters() if v.grad is not None}, 5e-3, 1e-5, floor=2e-3) > 5
+    # Conditioning of the two fixtures, measured with the reference itself on the CPU (float32 against float64, same
+    # weights and noise; objectives agree to 6e-8 in both): the gradients of the `encm` case differ norm-wise by
+    # 4e-3 .. 6e-3 in every encoder tensor and by 3e-4 .. 5e-3 in the decoder's (binary images and masks through
+    # 3x3 convolutions give exact ties at the relu / max-pool kinks, which rounding breaks either way); those of
+    # `noencm` by 1e-5.  So `encm` pins an fp32 implementation to about 1 % of a tensor's largest entry and no better
+    # (elementwise floor 1e-2, most entries lean on it, plus a norm-wise bound); `noencm` keeps the tight floor.
+    floor, share = (1e-2, 1.0) if use_mask else (2e-3, gu.FLOOR_FRACTION_MAX)
+    for prefix, net in (("genc", enc), ("gdec", dec)):
+        grads = {k: v.grad for k, v in net.named_parameters() if v.grad is not None}
+        assert gu.check_grads(g, prefix, grads, 5e-3, 1e-5, floor=floor, floor_fraction_max=share) > 5
+        for k, v in grads.items():
+            if f"{prefix}.{k}.full" in g:
+                ref = torch.from_numpy(g[f"{prefix}.{k}.full"]).double()
+                assert float((v.cpu().double() - ref).norm() / ref.norm()) < (2e-2 if use_mask else 5e-4), (prefix, k)
 
 
 @pytest.mark.parametrize("name", gu.names("marginal_"))

