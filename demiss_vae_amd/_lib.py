@@ -46,13 +46,18 @@ class DmvLatentBwd(C.Structure):
                 ("mix_kind", C.c_int32)]
 
 
+class DmvDecGrad(C.Structure):
+    _fields_ = [("dec", C.c_void_p), ("ld_dec", C.c_int64), ("X", C.c_void_p), ("M", C.c_void_p), ("wgt", C.c_void_p),
+                ("gb", C.c_void_p), ("base_m", C.c_float), ("base_f", C.c_float)]
+
+
 class DmvObjFwd(C.Structure):
     _fields_ = [("q_kind", C.c_int32), ("mix_C", C.c_int32), ("kind", C.c_int32), ("use_logpi", C.c_int32), ("dreg", C.c_int32),
                 ("coefA", C.c_float * 5), ("coefB", C.c_float * 5),
                 ("terms", C.c_void_p), ("comp_lp", C.c_void_p), ("log_w", C.c_void_p),
                 ("bound", C.c_void_p), ("mean_out", C.c_void_p), ("wgt", C.c_void_p), ("zscale", C.c_void_p), ("dlogit", C.c_void_p),
                 ("objA", C.c_void_p), ("objB", C.c_void_p), ("meanA_out", C.c_void_p), ("meanB_out", C.c_void_p),
-                ("neg_mean_out", C.c_void_p)]
+                ("neg_mean_out", C.c_void_p), ("ticket", C.c_void_p)]
 
 
 class DmvPackMap(C.Structure):
@@ -90,9 +95,10 @@ SIGNATURES = {
     "dmv_latent_sample": (C.c_int, [C.POINTER(DmvObjCfg), _P, _P, _U64, _U64, _P, _I64, _P, _P, _P, _P]),
     "dmv_vae_forward_fits": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), C.POINTER(DmvNet)]),
     "dmv_vae_forward": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), _P, _I32, _P, _P, C.POINTER(DmvNet), _P, _P, _U64, _U64,
-                                  _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+                                  _P, _I32, _F, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "dmv_categorical_draw_grouped": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _U64, _U64, _P, _P, _P, _I32, _P]),
     "dmv_vae_backward_fits": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), C.POINTER(DmvNet)]),
-    "dmv_vae_backward": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvLatentBwd), C.POINTER(DmvNet), _P, _P, _P, _P, _I64, _P, _SZ,
+    "dmv_vae_backward": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvLatentBwd), C.POINTER(DmvDecGrad), C.POINTER(DmvNet), _P, _P, _P, _P, _I64, _P, _SZ,
                                    C.POINTER(DmvNet), _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "dmv_obj_terms": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "dmv_obj_bound": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -151,6 +157,30 @@ def lib():
 def check(rc):
     if rc != 0:
         raise RuntimeError(f"libdmv error {rc}: {lib().dmv_strerror(rc).decode()}")
+
+
+_TICKETS = {}       # device index -> (zeroed int32 tensor of slots, {stream address: slot})
+
+
+def ticket_ptr():
+    """Address of the current stream's ticket counter for dmv_obj_forward (the launch then forms the batch means
+    itself instead of launching a second kernel), or None when none can be had without allocating inside a stream
+    capture.  Streams get a slot each, so launches on different streams never share a counter."""
+    import torch
+    dev = torch.cuda.current_device()
+    stream = torch.cuda.current_stream().cuda_stream
+    pool = _TICKETS.get(dev)
+    if pool is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        pool = _TICKETS[dev] = (torch.zeros(64, dtype=torch.int32, device=f"cuda:{dev}"), {})
+    slots, owner = pool
+    slot = owner.get(stream)
+    if slot is None:
+        if len(owner) >= slots.numel():
+            return None
+        slot = owner[stream] = len(owner)
+    return slots.data_ptr() + 4 * slot
 
 
 def ptr(t):

@@ -152,7 +152,11 @@ __global__ void k_impute_tail4(TailArgs a) {
 // ------------------------------------------------------------------------------------------
 struct DrawArgs {
   int B, P, K;
-  const float* logits;  // [B][P]
+  int inner;            // logit p of datapoint b sits at logits[(p / inner) * group_stride + b * inner + p % inner]:
+  int64_t group_stride; //   inner == P: plain [B][P] rows; inner < P: a [P / inner][B][inner] array (proposals (t i) b k)
+  int64_t* rows;        // nullable [B][rows_keep]: that position itself for the first rows_keep draws of a datapoint
+  int rows_keep;        //   (= the row of the picked proposal in arrays laid out like the logits)
+  const float* logits;
   const float* u;       // nullable [B][K] in [0,1)
   uint64_t seed, offset;
   const uint64_t* offset_base;  // nullable device counter added to offset
@@ -169,15 +173,16 @@ __global__ void k_categorical_draw(DrawArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.x * (blockDim.x >> 6) + wv;
   if (b >= a.B) return;
-  const float* lw = a.logits + (int64_t)b * a.P;
+  const float* lw0 = a.logits + (int64_t)b * a.inner;
+  auto pos = [&](int p) { const int grp = p / a.inner; return (int64_t)grp * a.group_stride + (p - grp * a.inner); };
   const bool staged = a.P <= kDrawStage;
   float mx = -INFINITY;
-  for (int p = lane; p < a.P; p += 64) mx = fmaxf(mx, lw[p]);
+  for (int p = lane; p < a.P; p += 64) mx = fmaxf(mx, lw0[pos(p)]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   float se = 0.f;
   for (int p = lane; p < a.P; p += 64) {
-    const float e = expf(lw[p] - mx);
+    const float e = expf(lw0[pos(p)] - mx);
     if (staged) stage[wv][p] = e;
     se += e;
   }
@@ -198,11 +203,12 @@ __global__ void k_categorical_draw(DrawArgs a) {
       }
     } else {
       for (int p = 0; p < a.P; ++p) {
-        c += expf(lw[p] - mx);
+        c += expf(lw0[pos(p)] - mx);
         if (c > target) { pick = p; break; }
       }
     }
-    a.idx[(int64_t)b * a.K + k] = pick;
+    if (a.idx) a.idx[(int64_t)b * a.K + k] = pick;
+    if (a.rows && k < a.rows_keep) a.rows[(int64_t)b * a.rows_keep + k] = (int64_t)b * a.inner + pos(pick);
   }
 }
 
@@ -338,6 +344,22 @@ extern "C" int dmv_categorical_draw(int32_t B, int32_t P, int32_t K, const float
   if (B < 1 || P < 1 || K < 1 || !logits || !idx) return DMV_E_BADARG;
   DrawArgs a;
   a.B = B; a.P = P; a.K = K; a.logits = logits; a.u = u; a.seed = seed; a.offset = offset; a.offset_base = offset_base; a.idx = idx;
+  a.inner = P; a.group_stride = 0; a.rows = nullptr; a.rows_keep = 0;
+  hipLaunchKernelGGL(k_categorical_draw, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+extern "C" int dmv_categorical_draw_grouped(int32_t B, int32_t groups, int32_t inner, int32_t K, const float* logits,
+                                            const float* u, uint64_t seed, uint64_t offset, const uint64_t* offset_base,
+                                            int64_t* idx, int64_t* rows, int32_t rows_keep, void* stream) {
+  if (B < 1 || groups < 1 || inner < 1 || K < 1 || !logits || (!idx && !rows)) return DMV_E_BADARG;
+  if (rows && (rows_keep < 1 || rows_keep > K)) return DMV_E_BADARG;
+  if ((int64_t)groups * inner > 0x7fffffff) return DMV_E_UNSUPPORTED;
+  DrawArgs a;
+  a.B = B; a.P = groups * inner; a.K = K; a.logits = logits; a.u = u; a.seed = seed; a.offset = offset;
+  a.offset_base = offset_base; a.idx = idx;
+  a.inner = inner; a.group_stride = (int64_t)B * inner; a.rows = rows; a.rows_keep = rows ? rows_keep : 0;
   hipLaunchKernelGGL(k_categorical_draw, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;

@@ -1401,7 +1401,10 @@ struct VaeFwdArgs {
   FwdArgs enc, dec;
   int64_t N;                  // sample rows
   int B, G, Zd;
-  int rows_per_b;             // encoder rows per datapoint: G (one per imputation) or 1
+  int per_comp;               // 1: an encoder row per imputation (G - n_prior of them per datapoint), 0: one per datapoint
+  int rows_per_b;             // encoder rows per datapoint
+  int n_prior;                // the last n_prior of a datapoint's G components are standard-normal proposals without
+  float prior_raw;            // an encoder row (mu = 0, raw sigma = prior_raw); only with one row per imputation
   QAddr q;
   const float* eps;           // [N][ldz] or null (Philox)
   float* eps_out;             // nullable
@@ -1430,16 +1433,21 @@ __global__ __launch_bounds__(256, 1) void k_vae_fwd_rows16(VaeFwdArgs a) {
   const int BG = a.B * a.G;
   const int bg = nl % BG;
   const int b = bg / a.G, comp = bg - b * a.G;
-  const int er = a.rows_per_b == 1 ? b : bg;                   // encoder row of this sample
+  // encoder row of this sample (a prior component has none: it rides along on a neighbour's row and ignores it), and
+  // the row of the encoder-output array its parameters live in
+  const bool prior = a.per_comp && comp >= a.rows_per_b;
+  const int er = a.per_comp ? b * a.rows_per_b + (prior ? a.rows_per_b - 1 : comp) : b;
+  const int orow = a.per_comp ? bg : b;
   // the first sample of an encoder row stores what the encoder pass saves and the row's outputs
-  const bool owner = live && nl < BG && (a.rows_per_b != 1 || comp == 0);
-  if (wv == 0 && g == 0) par_off[m] = (int)((int64_t)b * a.q.sb + (int64_t)comp * a.q.sg - (int64_t)er * ldE);
+  const bool owner = live && nl < BG && !prior && (a.per_comp || comp == 0);
+  if (wv == 0 && g == 0)
+    par_off[m] = prior ? -1 : (int)((int64_t)b * a.q.sb + (int64_t)comp * a.q.sg - (int64_t)orow * ldE);
 
   r16_forward_chain<NT, SAVE, false, W>(
       a.enc, lds, lane, wv, er, er, owner, [&](int k0) { return first_layer_input4(a.enc, er, k0); },
       [&](int ot, f32x4 o) {
         *(f32x4*)(et + m * ldE + 16 * ot + 4 * g) = o;
-        if (owner) *(f32x4*)(a.enc.y + (int64_t)er * ldE + 16 * ot + 4 * g) = o;
+        if (owner) *(f32x4*)(a.enc.y + (int64_t)orow * ldE + 16 * ot + 4 * g) = o;
       });
   __syncthreads();
 
@@ -1452,9 +1460,10 @@ __global__ __launch_bounds__(256, 1) void k_vae_fwd_rows16(VaeFwdArgs a) {
       const int64_t n2 = (int64_t)blockIdx.x * 16 + mm;
       float z = 0.f, e = 0.f;
       if (j < a.Zd) {
-        const float* pr = et + mm * ldE + par_off[mm];
-        const float mu = pr[j];
-        const float sg = dmv_softplus(pr[a.q.raw_off + j]) + a.q.eps;
+        const int po = par_off[mm];
+        const float* pr = et + mm * ldE + (po < 0 ? 0 : po);
+        const float mu = po < 0 ? 0.f : pr[j];
+        const float sg = dmv_softplus(po < 0 ? a.prior_raw : pr[a.q.raw_off + j]) + a.q.eps;
         const int64_t i = (n2 < a.N ? n2 : a.N - 1) * a.ldz + j;
         e = a.eps ? a.eps[i] : dmv_philox_normal(a.seed, off + (uint64_t)i);
         z = mu + sg * e;
@@ -1600,6 +1609,18 @@ struct VaeBwdArgs {
   const float* kl_wgt;         // nullable [BG]
   const float* gscale;         // nullable device scalar
   float* d_enc;                // [BG][ldE], every entry written
+  // when dg_dec is set the kernel forms the gradient w.r.t. the decoder outputs itself (what k_obj_bwd_dec* compute)
+  // and writes it to dec.gy for the weight-gradient GEMMs; otherwise it reads dec.gy
+  const float* dg_dec;         // decoder outputs [N][dg_ld]
+  float* dg_out;               // = dec.gy, writable
+  int64_t dg_ld;
+  const float* dg_X;           // [BG or BG / G][D]
+  const uint8_t* dg_M;
+  const float* dg_wgt;         // nullable [N]
+  const float* dg_gb;          // nullable [BG / G]
+  float dg_base_m, dg_base_f;
+  int D, gen_dist, x_per_row;  // x_per_row: X / M have a row per encoder row (else per datapoint)
+  int ldD;                     // pitch of dec.gy
 };
 
 template <int NT>
@@ -1609,19 +1630,61 @@ __global__ __launch_bounds__(256, 1) void k_vae_bwd_rows16(VaeBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [16][ZP] decoder input gradients, [16][ldE] encoder output gradients
   float* dzt = tile;
   float* det = tile + 16 * a.ZP;
+  float* ddt = det + 16 * a.ldE;                                // [16][ldD] decoder output gradients (with dg_dec)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 15, g = lane >> 4;
   const int e0 = blockIdx.x * a.Q;
+
+  // ---- gradient w.r.t. the decoder outputs of the tile's rows:
+  //      d_dec[n][c] = gs gb[b] (M_d wgt[n] base_m + wgt[n] base_f) d log p(x_d | z) / d param_c
+  if (a.dg_dec) {
+    const float gs = a.gscale ? a.gscale[0] : 1.f;
+    const bool normal = a.gen_dist <= DMV_GEN_NORMAL_EPS;
+    const int P = normal ? 2 * a.D : a.D;
+    const float geps = a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f;
+    for (int i = threadIdx.x; i < 16 * a.ldD; i += 256) {
+      const int mm = i / a.ldD, c = i - mm * a.ldD;
+      const int qd = mm / a.S, sd = mm - qd * a.S;
+      const int e = e0 + qd;
+      float v = 0.f;
+      const bool live = qd < a.Q && e < a.BG;
+      if (live && c < P) {
+        const int64_t n = (int64_t)sd * a.BG + e;
+        const int b = e / a.G;
+        const int64_t xrow = a.x_per_row ? e : b;
+        const int d = c < a.D ? c : c - a.D;
+        const float* dec = a.dg_dec + n * a.dg_ld;
+        const float gbb = gs * (a.dg_gb ? a.dg_gb[b] : 1.f);
+        const float wm = gbb * (a.dg_wgt ? a.dg_wgt[n] : 1.f);
+        const float x = a.dg_X[xrow * a.D + d];
+        const float coef = (a.dg_M[xrow * a.D + d] ? wm * a.dg_base_m : 0.f) + wm * a.dg_base_f;
+        if (normal) {
+          const float mu = dec[d], raw = dec[a.D + d];
+          const float sg = dmv_softplus(raw) + geps;
+          const float rs = __builtin_amdgcn_rcpf(sg);
+          const float u = (x - mu) * rs;
+          v = c < a.D ? coef * (u * rs) : coef * ((u * u - 1.f) * rs * (raw > 20.f ? 1.f : dmv_sigmoid(raw)));
+        } else {
+          const float t = a.gen_dist == DMV_GEN_BERN ? x : (x + 1.f) * 0.5f;
+          v = coef * (t - dmv_sigmoid(dec[d]));
+        }
+      }
+      ddt[i] = v;
+      if (live) a.dg_out[((int64_t)sd * a.BG + e) * a.ldD + c] = v;
+    }
+    __syncthreads();
+  }
 
   // ---- decoder chain on the rows (q, s) -> n = s BG + e0 + q
   {
     const int qd = m / a.S, sd = m - qd * a.S;
     const bool live = qd < a.Q && e0 + qd < a.BG;
     const int64_t n = live ? (int64_t)sd * a.BG + e0 + qd : 0;
+    const float* gyr = a.dg_dec ? ddt + m * a.ldD : a.dec.gy + n * a.dec.ldgy;
     r16_backward_chain<NT, W>(
         a.dec, lds, lane, wv, n, live, true,
-        [&](int k0) { const f32x4 b = *(const f32x4*)(a.dec.gy + n * a.dec.ldgy + k0); return live ? b : zero4(); },
+        [&](int k0) { const f32x4 b = *(const f32x4*)(gyr + k0); return live ? b : zero4(); },
         [&](int it, f32x4 o) { if (16 * it + 4 * g < a.ZP) *(f32x4*)(dzt + m * a.ZP + 16 * it + 4 * g) = o; });
   }
   for (int i = threadIdx.x; i < 16 * a.ldE; i += 256) det[i] = 0.f;
@@ -2199,6 +2262,7 @@ static int launch_vae_fwd(const VaeFwdArgs& a, size_t dyn_bytes, hipStream_t st)
 }
 
 static bool vae_forward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec) {
+  // (cfg->G counts prior components too when dmv_vae_forward is given some)
   if (!cfg || dmv_check_net(enc) != DMV_OK || dmv_check_net(dec) != DMV_OK) return false;
   if (cfg->B < 1 || cfg->G < 1 || cfg->nz < 1 || cfg->I < 1 || cfg->Zd < 1) return false;
   const int64_t N = (int64_t)cfg->nz * cfg->I * cfg->B * cfg->G;
@@ -2218,9 +2282,10 @@ extern "C" int dmv_vae_forward_fits(const DmvObjCfg* cfg, const DmvNet* enc, con
 extern "C" int dmv_vae_forward(const DmvObjCfg* cfg, const DmvNet* enc, const float* enc_packed, int32_t in_mode,
                                const float* X, const uint8_t* M, const DmvNet* dec, const float* dec_packed,
                                const float* eps, uint64_t seed, uint64_t offset, const uint64_t* offset_base,
-                               float* enc_out, float* enc_saved, float* Z, int64_t ldz, float* eps_out, float* dec_out,
-                               float* dec_saved, void* stream) {
+                               int32_t n_prior, float prior_raw, float* enc_out, float* enc_saved, float* Z, int64_t ldz,
+                               float* eps_out, float* dec_out, float* dec_saved, void* stream) {
   if (!vae_forward_fits(cfg, enc, dec)) return DMV_E_UNSUPPORTED;
+  if (n_prior < 0 || (n_prior > 0 && (!cfg->x_per_component || n_prior >= cfg->G))) return DMV_E_BADARG;
   if (!enc_packed || !dec_packed || !X || !enc_out || !Z || !dec_out || ldz < cfg->Zd) return DMV_E_BADARG;
   if (in_mode < DMV_IN_PLAIN || in_mode > DMV_IN_CONCAT_MASKED) return DMV_E_UNSUPPORTED;
   if (in_mode != DMV_IN_PLAIN && !M) return DMV_E_BADARG;
@@ -2230,11 +2295,13 @@ extern "C" int dmv_vae_forward(const DmvObjCfg* cfg, const DmvNet* enc, const fl
   if (enc_saved && ((enc->dropout_p > 0.f && enc->nb > 0) || (dec->dropout_p > 0.f && dec->nb > 0))) return DMV_E_UNSUPPORTED;
   if ((((uintptr_t)enc_out | (uintptr_t)dec_out) & 15) != 0) return DMV_E_BADARG;
   const int64_t ldE = dmv_pad32(enc->out_dim);
-  const int rows_per_b = cfg->x_per_component ? cfg->G : 1;
-  // the addressing of (mu, raw sigma) must stay inside the encoder row that serves a sample
-  const int64_t last = (rows_per_b == 1 ? (int64_t)(cfg->G - 1) * cfg->enc_sg : 0) + cfg->raw_off + cfg->Zd;
-  if (cfg->enc_sb != rows_per_b * ldE || (rows_per_b != 1 && cfg->enc_sg != ldE) || last > ldE || cfg->raw_off < cfg->Zd)
+  const int rows_per_b = cfg->x_per_component ? cfg->G - n_prior : 1;
+  const int out_rows_per_b = cfg->x_per_component ? cfg->G : 1;
+  // the addressing of (mu, raw sigma) must stay inside the encoder-output row that serves a sample
+  const int64_t last = (out_rows_per_b == 1 ? (int64_t)(cfg->G - 1) * cfg->enc_sg : 0) + cfg->raw_off + cfg->Zd;
+  if (cfg->enc_sb != out_rows_per_b * ldE || (out_rows_per_b != 1 && cfg->enc_sg != ldE) || last > ldE || cfg->raw_off < cfg->Zd)
     return DMV_E_BADARG;
+  if (enc_saved && n_prior > 0) return DMV_E_UNSUPPORTED;       // (prior proposals belong to the samplers: no backward pass)
   VaeFwdArgs a;
   auto fill = [](FwdArgs& f, const DmvNet* net, const float* packed, int64_t rows, float* y, float* saved) {
     f.drop.mode = DROP_OFF; f.drop.bits = 0; f.drop.thresh = 0; f.drop.keep = nullptr; f.drop.seed = 0; f.drop.q0 = 0;
@@ -2255,7 +2322,8 @@ extern "C" int dmv_vae_forward(const DmvObjCfg* cfg, const DmvNet* enc, const fl
   a.enc.in_mode = in_mode; a.enc.D = cfg->D; a.enc.x = X; a.enc.ldx = cfg->D; a.enc.m = M; a.enc.ldm = cfg->D;
   fill(a.dec, dec, dec_packed, a.N, dec_out, dec_saved);
   a.dec.in_mode = DMV_IN_PLAIN; a.dec.D = cfg->Zd; a.dec.x = Z; a.dec.ldx = ldz; a.dec.m = nullptr; a.dec.ldm = 0;
-  a.B = cfg->B; a.G = cfg->G; a.Zd = cfg->Zd; a.rows_per_b = rows_per_b;
+  a.B = cfg->B; a.G = cfg->G; a.Zd = cfg->Zd; a.per_comp = cfg->x_per_component ? 1 : 0; a.rows_per_b = rows_per_b;
+  a.n_prior = n_prior; a.prior_raw = prior_raw;
   a.q.sb = cfg->enc_sb; a.q.sg = cfg->enc_sg; a.q.raw_off = cfg->raw_off; a.q.logit_off = cfg->logit_off;
   a.q.eps = cfg->q_eps ? DMV_EPSILON : 0.f;
   a.eps = eps; a.eps_out = eps_out; a.Z = Z; a.ldz = ldz; a.seed = seed; a.offset = offset; a.offset_base = offset_base;
@@ -2451,8 +2519,8 @@ extern "C" int dmv_vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, co
   return vae_backward_fits(cfg, enc, dec) ? 1 : 0;
 }
 
-extern "C" int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, const DmvNet* dec, const float* dec_packed,
-                                const float* dec_saved, const uint8_t* dec_drop_keep, const float* d_dec, int64_t ld_ddec,
+extern "C" int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, const DmvDecGrad* dg, const DmvNet* dec,
+                                const float* dec_packed, const float* dec_saved, const uint8_t* dec_drop_keep, float* d_dec, int64_t ld_ddec,
                                 void* dec_ws, size_t dec_ws_bytes, const DmvNet* enc, const float* enc_packed,
                                 const float* enc_saved, const uint8_t* enc_drop_keep, float* d_enc, void* enc_ws,
                                 size_t enc_ws_bytes, const float* enc_out, const float* Z, const float* eps, int64_t ldz,
@@ -2499,6 +2567,18 @@ extern "C" int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, con
   a.own_live = p->own_live; a.use_zscale = p->use_zscale;
   a.enc_out = enc_out; a.Z = Z; a.eps = eps; a.ldz = ldz;
   a.wgt = wgt; a.gb = gb; a.zscale = zscale; a.kl_wgt = kl_wgt; a.gscale = gscale; a.d_enc = d_enc;
-  const size_t dyn = sizeof(float) * 16 * ((size_t)ldE + (size_t)a.ZP);
+  size_t dyn = sizeof(float) * 16 * ((size_t)ldE + (size_t)a.ZP);
+  a.dg_dec = nullptr; a.dg_out = d_dec; a.dg_ld = 0; a.dg_X = nullptr; a.dg_M = nullptr; a.dg_wgt = nullptr; a.dg_gb = nullptr;
+  a.dg_base_m = 0.f; a.dg_base_f = 0.f;
+  a.D = cfg->D; a.gen_dist = cfg->gen_dist; a.x_per_row = cfg->x_per_component; a.ldD = (int)ld_ddec;
+  if (dg) {
+    if (cfg->gen_dist < DMV_GEN_NORMAL || cfg->gen_dist > DMV_GEN_BERN_M1P1 || cfg->D < 1) return DMV_E_UNSUPPORTED;
+    const int P = cfg->gen_dist <= DMV_GEN_NORMAL_EPS ? 2 * cfg->D : cfg->D;
+    if (!dg->dec || !dg->X || !dg->M || dg->ld_dec < P || ld_ddec < P) return DMV_E_BADARG;
+    dyn += sizeof(float) * 16 * (size_t)ld_ddec;
+    if (dyn + (size_t)a.dec.L.NT * 2048 + 64 > 65536) return DMV_E_UNSUPPORTED;      // wide decoder rows: form d_dec beforehand
+    a.dg_dec = dg->dec; a.dg_ld = dg->ld_dec; a.dg_X = dg->X; a.dg_M = dg->M; a.dg_wgt = dg->wgt; a.dg_gb = dg->gb;
+    a.dg_base_m = dg->base_m; a.dg_base_f = dg->base_f;
+  }
   DMV_DISPATCH_NT(a.dec.L.NT, launch_vae_bwd, a, dyn, (hipStream_t)stream);
 }

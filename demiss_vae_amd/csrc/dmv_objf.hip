@@ -39,6 +39,10 @@ struct FwdArgs {
   float* __restrict__ dlogit;   // nullable [B][G]
   float cA[5], cB[5];           // PER_COMPONENT: objA = mean_z sum_t cA[t] terms[t], objB likewise (nullable)
   float* __restrict__ objA; float* __restrict__ objB;
+  // means in the same launch: the workgroup that finishes last (a ticket counter in device memory, zero between launches)
+  // sums the per-datapoint results.  mean1 / mean2: means of bound (or objA) / of objB; neg1 = -mean1.
+  unsigned* ticket;
+  float* mean1; float* mean2; float* neg1;
 };
 
 // log N(x; mu, sigma) with the division replaced by a reciprocal (1 ulp): -((x - mu) / sigma)^2 / 2 - log sigma - c
@@ -55,6 +59,67 @@ struct __attribute__((aligned(16))) QEntry { float mu, inv2s2, lnorm, pad; };
 __device__ __forceinline__ float q_logp(const QEntry& e, float z) {
   const float d = z - e.mu;
   return -(d * d) * e.inv2s2 - e.lnorm;
+}
+
+// Sum of an array over the threads of a workgroup, thread t taking elements t, t + nthr, ... (16-byte loads, four in
+// flight per thread): fixed summation order for a given workgroup size, so results are reproducible bit for bit.
+__device__ __forceinline__ float sum_strided(const float* __restrict__ v, int64_t n) {
+  float s = 0.f;
+  if (!v) return s;
+  const int64_t tid = threadIdx.x, nt = blockDim.x;
+  if ((((uintptr_t)v) & 15) == 0) {
+    const f32x4* __restrict__ v4 = (const f32x4*)v;
+    const int64_t n4 = n >> 2;
+    int64_t i = tid;
+    for (; i + 3 * nt < n4; i += 4 * nt) {
+      const f32x4 a = v4[i], b = v4[i + nt], c = v4[i + 2 * nt], d = v4[i + 3 * nt];
+      s += ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3])) + ((c[0] + c[1]) + (c[2] + c[3])) +
+           ((d[0] + d[1]) + (d[2] + d[3]));
+    }
+    for (; i < n4; i += nt) { const f32x4 a = v4[i]; s += (a[0] + a[1]) + (a[2] + a[3]); }
+    for (int64_t k = (n4 << 2) + tid; k < n; k += nt) s += v[k];
+  } else {
+    for (int64_t i = tid; i < n; i += nt) s += v[i];
+  }
+  return s;
+}
+
+// means of one or two arrays by the calling workgroup (every thread calls; sh: 32 floats of LDS)
+__device__ __forceinline__ void block_mean2(float* sh, const float* __restrict__ v1, const float* __restrict__ v2, int64_t n,
+                                            float scale, float* __restrict__ o1, float* __restrict__ o2,
+                                            float* __restrict__ o1_neg) {
+  const float s1 = gsum<64>(sum_strided(v1, n)), s2 = gsum<64>(sum_strided(v2, n));
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s1; sh[16 + (threadIdx.x >> 6)] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) { t1 += sh[w]; t2 += sh[16 + w]; }
+    if (o1) o1[0] = t1 * scale;
+    if (o1_neg) o1_neg[0] = -(t1 * scale);
+    if (o2) o2[0] = t2 * scale;
+  }
+}
+
+// End of an objective-forward workgroup when the launch also forms the batch means: make this workgroup's results
+// visible, take a ticket, and if it was the last one, sum what all workgroups wrote (then leave the counter at zero for
+// the next launch).  Every thread of the workgroup must call it.
+__device__ __forceinline__ void finish_means(const FwdArgs& a) {
+  if (!a.ticket) return;
+  __shared__ float sh[32];
+  __shared__ unsigned last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (a.kind == DMV_BOUND_PER_COMPONENT) {
+    const int64_t pairs = (int64_t)a.B * a.G;
+    block_mean2(sh, a.objA, a.objB, pairs, 1.f / (float)pairs, a.mean1, a.mean2, nullptr);
+  } else {
+    block_mean2(sh, a.bound, nullptr, (int64_t)a.B, 1.f / (float)a.B, a.mean1, nullptr, a.neg1);
+  }
+  if (threadIdx.x == 0) *a.ticket = 0u;
 }
 
 // the five terms of one sample row, summed over the R lanes of the group (every lane returns the totals).
@@ -210,6 +275,7 @@ __global__ void __launch_bounds__(256) k_obj_fwd(FwdArgs a) {
   }
   if (a.kind < 0) return;
   bound_phases(a, lw, aux, tid, nthr, b0, nb, Qn, Q, BG, row0);
+  finish_means(a);
 }
 
 // Everything after the log-weights of a workgroup's rows are in LDS: bounds by logsumexp over (i, g), weights of the
@@ -461,44 +527,14 @@ __global__ void __launch_bounds__(256) k_obj_fwd_rows4(FwdArgs a) {
   }
   if (a.kind < 0) return;
   bound_phases(a, lw, aux, tid, nthr, b0, nb, Qn, Q, BG, row0);
+  finish_means(a);
 }
 
-// means of one or two arrays in one single-workgroup launch (fixed summation order: reproducible bit for bit).
-// 1024 threads, 16-byte loads, four of them in flight per thread: a [B] array of a few hundred KB takes a few us.
-__device__ __forceinline__ float sum_strided(const float* __restrict__ v, int64_t n) {
-  float s = 0.f;
-  if (!v) return s;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  if ((((uintptr_t)v) & 15) == 0) {
-    const f32x4* v4 = (const f32x4*)v;
-    const int64_t n4 = n >> 2;
-    int64_t i = tid;
-    for (; i + 3 * (int64_t)nt < n4; i += 4 * (int64_t)nt) {
-      const f32x4 a = v4[i], b = v4[i + nt], c = v4[i + 2 * nt], d = v4[i + 3 * nt];
-      s += ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3])) + ((c[0] + c[1]) + (c[2] + c[3])) +
-           ((d[0] + d[1]) + (d[2] + d[3]));
-    }
-    for (; i < n4; i += nt) { const f32x4 a = v4[i]; s += (a[0] + a[1]) + (a[2] + a[3]); }
-    for (int64_t k = (n4 << 2) + tid; k < n; k += nt) s += v[k];
-  } else {
-    for (int64_t i = tid; i < n; i += nt) s += v[i];
-  }
-  return s;
-}
-
+// the same means as a launch of their own (callers that bring no ticket counter): one workgroup of 1024 threads
 __global__ void __launch_bounds__(1024) k_mean2(const float* __restrict__ v1, const float* __restrict__ v2, int64_t n, float scale,
                                                 float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ o1_neg) {
-  __shared__ float sh[2][16];
-  float s1 = gsum<64>(sum_strided(v1, n)), s2 = gsum<64>(sum_strided(v2, n));
-  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t1 = 0.f, t2 = 0.f;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { t1 += sh[0][w]; t2 += sh[1][w]; }
-    if (o1) o1[0] = t1 * scale;
-    if (o1_neg) o1_neg[0] = -(t1 * scale);
-    if (o2) o2[0] = t2 * scale;
-  }
+  __shared__ float sh[32];
+  block_mean2(sh, v1, v2, n, scale, o1, o2, o1_neg);
 }
 
 int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -539,8 +575,18 @@ extern "C" int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const f
   const size_t lds_max = 60 * 1024;
   const int64_t pairs = (int64_t)cfg->B * cfg->G;
   hipStream_t st = (hipStream_t)stream;
+  const bool want_means = f->mean_out || f->meanA_out || f->meanB_out || f->neg_mean_out;
+  // (decided per launch below: a ticket costs every workgroup a device-scope release - an L2 write-back on this
+  // multi-die part - which pays for itself only in the short launches of small batches)
+  a.ticket = nullptr;
+  auto use_ticket = [&](unsigned workgroups) {
+    a.ticket = (want_means && kind >= 0 && workgroups <= 256) ? (unsigned*)f->ticket : nullptr;
+  };
+  a.mean1 = kind == DMV_BOUND_PER_COMPONENT ? f->meanA_out : f->mean_out;
+  a.mean2 = kind == DMV_BOUND_PER_COMPONENT ? f->meanB_out : nullptr;
+  a.neg1 = kind == DMV_BOUND_PER_COMPONENT ? nullptr : f->neg_mean_out;
   auto means = [&]() -> int {
-    if (f->mean_out || f->meanA_out || f->meanB_out || f->neg_mean_out) {
+    if (want_means && !a.ticket) {
       if (kind == DMV_BOUND_PER_COMPONENT) {
         hipLaunchKernelGGL(k_mean2, dim3(1), dim3(1024), 0, st, (const float*)f->objA, (const float*)f->objB, pairs,
                            1.f / (float)pairs, f->meanA_out, f->meanB_out, (float*)nullptr);
@@ -576,6 +622,7 @@ extern "C" int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const f
       a.T = T;
       const dim3 grid((unsigned)((cfg->B + DPB - 1) / DPB)), block(nthr);
       const size_t lds = rows_lds(DPB);
+      use_ticket(grid.x);
 #define DMV_ROWS4(d4, z4) \
   if (D4 == d4 && Z4 == z4) hipLaunchKernelGGL((k_obj_fwd_rows4<d4, z4>), grid, block, lds, st, a)
       DMV_ROWS4(1, 1); DMV_ROWS4(1, 2); DMV_ROWS4(1, 4); DMV_ROWS4(1, 8);
@@ -629,6 +676,7 @@ extern "C" int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const f
     const int64_t want = 2048 / grid.x;
     grid.y = (unsigned)(want < 1 ? 1 : want > a.S ? a.S : want > 65535 ? 65535 : want);
   }
+  use_ticket(grid.x);
   switch (R) {
     case 1: hipLaunchKernelGGL(k_obj_fwd<1>, grid, dim3(nthr), lds, st, a); break;
     case 8: hipLaunchKernelGGL(k_obj_fwd<8>, grid, dim3(nthr), lds, st, a); break;

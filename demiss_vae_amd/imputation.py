@@ -212,98 +212,120 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
     if resample_final_imps:
         assert num_iterations > 1, "Need >1 iterations to resample final imps"
     B, K, D = X.shape
-    r, I, Zd = num_prior_replenish_proposals, num_imp_samples, dims.Zd
+    r, I, Zd, T = num_prior_replenish_proposals, num_imp_samples, dims.Zd, num_iterations
     Kp = K + r
+    N = I * B * Kp
     dev = X.device
     lib, st = L.lib(), L.stream_ptr()
     Xc = X.contiguous().float()
     Mu = _u8(M)
     cmin = clip_min.to(dev).float().contiguous() if clip_min is not None else None
     cmax = clip_max.to(dev).float().contiguous() if clip_max is not None else None
-    Z_all, lw_all = [], []
-    Me = Mu
-    if r > 0:
-        # prior components: mu = 0, sigma = 1 (vgiwae/shared/vae_imputation.py:419-441) as encoder-output rows, and the
-        # masks of the replenished proposals: the same in every iteration
-        ldE = pad32(enc.dims.out_dim)
-        rep = torch.zeros((B, r, ldE), dtype=torch.float32, device=dev)
-        rep[:, :, Zd:2 * Zd] = float(softplus_inverse(torch.tensor(1.0 - (1e-5 if dims.q_eps else 0.0), dtype=torch.float32)))
-        Me = torch.cat([Mu, Mu[:, :1].expand(B, r, D)], dim=1).contiguous()
-    for t in range(num_iterations):
-        N = I * B * Kp
+    clip = (cmin is not None or cmax is not None)
+    # The log-weights sum log p(x_d | z) over OBSERVED entries only, under the mask of a datapoint's first imputation
+    # broadcast over the others (vgiwae/shared/vae_imputation.py:407, "M is a repeated tensor"): the observed values are
+    # the same in all of a datapoint's imputations, so one [B, D] pair serves every component, prior proposals included
+    # (the reference builds a [B, K + r, D] copy for them, :439-441), in every iteration.
+    X0, M0 = Xc[:, 0].contiguous(), Mu[:, 0].contiguous()
+    ldE = pad32(enc.dims.out_dim) if isinstance(enc, PackedNet) else None
+    # prior components: mu = 0, sigma = 1 (:419-441), as rows of the encoder-output array [B, K + r, ld]; constant
+    prior_raw = float(softplus_inverse(torch.tensor(1.0 - (1e-5 if dims.q_eps else 0.0), dtype=torch.float32)))
+    enc_buf = None
+
+    def enc_buffer(ld):
+        buf_ = torch.empty((B, Kp, ld), dtype=torch.float32, device=dev)
+        if r > 0:
+            buf_[:, K:] = 0.0
+            buf_[:, K:, Zd:2 * Zd] = prior_raw
+        return buf_
+
+    # all iterations' proposals and log-weights in place, for the final resampling: [T][(i b k)]
+    Z_all = torch.empty((T, N, Zd), dtype=torch.float32, device=dev) if resample_final_imps else None
+    lw_all = torch.empty((T, N), dtype=torch.float32, device=dev) if resample_final_imps else None
+    cfg = L.DmvObjCfg()
+    cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, Kp, 1, I, D, Zd
+    cfg.gen_dist, cfg.q_eps = L.GEN[dims.gen_dist], dims.q_eps
+    in_mode = L.IN_CONCAT if dims.encoder_use_mis_mask else L.IN_PLAIN
+    from .objectives import fused_forward
+    one_launch = (isinstance(enc, PackedNet) and isinstance(dec, PackedNet) and
+                  not (training and ((enc.dims.dropout > 0 and enc.dims.nb > 0) or (dec.dims.dropout > 0 and dec.dims.nb > 0))))
+    for t in range(T):
         e = eps_z[t].reshape(N, Zd).contiguous().float() if eps_z is not None else None
-        one = _one_launch_pass(dims, enc, dec, Xc.reshape(B * K, D), Mu.reshape(B * K, D), B * K, I, e, training) if r == 0 else None
-        if one is not None:
-            enc_out, Z, _, dec_out = one
-            ldE = enc_out.shape[1]
-            Xe = Xc
+        Zt = Z_all[t] if resample_final_imps else None
+        out = None
+        if one_launch:
+            # encoder on the B K imputations, proposals z[i, b, k] ~ q(. | component (b, k)) (prior components included)
+            # and the decoder on them: one launch
+            if enc_buf is None:
+                enc_buf = enc_buffer(ldE)
+            cfg.x_per_component = 1
+            cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = Kp * ldE, ldE, Zd, 0
+            out = fused_forward(cfg, enc, dec, in_mode, Xc.reshape(B * K, D), Mu.reshape(B * K, D), e, False, False,
+                                n_prior=r, prior_raw=prior_raw, enc_out=enc_buf.view(B * Kp, ldE), Z=Zt)
+        if out is not None:
+            enc_out, Z, dec_out = out[0], out[2], out[4]
         else:
-            enc_out = _encode_rows(dims, enc, Xc.reshape(B * K, D), Mu.reshape(B * K, D), _keep(enc, B * K, training, dev))
-            ldE = enc_out.shape[1]
-            Xe = Xc
-            if r > 0:
-                enc_out = torch.cat([enc_out.reshape(B, K, ldE), rep], dim=1).reshape(B * Kp, ldE).contiguous()
-                Xe = torch.cat([Xc, Xc[:, :1].expand(B, r, D)], dim=1).contiguous()
-            # proposals z[i, b, k] ~ q(. | component (b, k))
+            rows = _encode_rows(dims, enc, Xc.reshape(B * K, D), Mu.reshape(B * K, D), _keep(enc, B * K, training, dev))
+            if enc_buf is None or enc_buf.shape[2] != rows.shape[1]:
+                enc_buf = enc_buffer(rows.shape[1])
+            ldE = rows.shape[1]
+            enc_buf[:, :K] = rows.view(B, K, ldE)
+            enc_out = enc_buf.view(B * Kp, ldE)
             scfg = _sample_cfg(dims, B * Kp, I, ldE)
-            Z = torch.empty((N, Zd), dtype=torch.float32, device=dev)
+            Z = Zt if Zt is not None else torch.empty((N, Zd), dtype=torch.float32, device=dev)
             if e is not None:
                 L.check(lib.dmv_latent_sample(C.byref(scfg), L.ptr(enc_out), L.ptr(e), 0, 0, None, Zd, None, L.ptr(Z), None, st))
             else:
                 seed, off = rng.next_offset(N * Zd)
                 L.check(lib.dmv_latent_sample(C.byref(scfg), L.ptr(enc_out), None, seed, off, rng.base_ptr(), Zd, None, L.ptr(Z), None, st))
             dec_out, _ = mlp_forward(dec, Z, Zd, N, save=False, drop_keep=_keep(dec, N, training, dev))
-        # DMIS log-weights: uniform mixture over the K+r components of the datapoint (shared/iwae.py:57-100)
-        cfg = L.DmvObjCfg()
-        cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, Kp, 1, I, D, Zd
-        cfg.gen_dist, cfg.q_eps, cfg.x_per_component = L.GEN[dims.gen_dist], dims.q_eps, 1
-        cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = Kp * ldE, ldE, Zd, 0
+        # DMIS log-weights: uniform mixture over the K+r components of the datapoint (shared/iwae.py:57-100):
         # log_w = sum_d M log p(x_d|z) + log p(z) - log q_mix(z), rows (i b k): a by-product of the fused objective forward
-        log_w = torch.empty(N, dtype=torch.float32, device=dev)
+        cfg.x_per_component = 0
+        cfg.enc_sb, cfg.enc_sg, cfg.raw_off, cfg.logit_off = Kp * ldE, ldE, Zd, 0
+        log_w = lw_all[t] if resample_final_imps else torch.empty(N, dtype=torch.float32, device=dev)
         per_b = torch.empty(B, dtype=torch.float32, device=dev)
         f = L.DmvObjFwd()
         f.q_kind, f.mix_C, f.kind = L.Q_IMPUTATION, Kp, L.BOUND_LSE
         f.log_w, f.bound = L.addr(log_w), L.addr(per_b)
-        rc = lib.dmv_obj_forward(C.byref(cfg), C.byref(f), L.ptr(dec_out), dec_out.shape[1], L.ptr(Xe), L.ptr(Me),
+        rc = lib.dmv_obj_forward(C.byref(cfg), C.byref(f), L.ptr(dec_out), dec_out.shape[1], L.ptr(X0), L.ptr(M0),
                                  L.ptr(Z), Zd, L.ptr(enc_out), st)
         if rc == L.E_UNSUPPORTED and I * Kp > 1024:
             # more proposals per datapoint than the one-launch kernel stages in LDS: terms, then the looping bound kernel
             terms = torch.empty((5, N), dtype=torch.float32, device=dev)
-            L.check(lib.dmv_obj_terms(C.byref(cfg), L.Q_IMPUTATION, Kp, L.ptr(dec_out), dec_out.shape[1], L.ptr(Xe), L.ptr(Me),
+            L.check(lib.dmv_obj_terms(C.byref(cfg), L.Q_IMPUTATION, Kp, L.ptr(dec_out), dec_out.shape[1], L.ptr(X0), L.ptr(M0),
                                       L.ptr(Z), Zd, L.ptr(enc_out), L.ptr(terms), None, st))
             L.check(lib.dmv_obj_bound(C.byref(cfg), L.BOUND_LSE, L.Q_IMPUTATION, 0, 0, L.ptr(enc_out), L.ptr(terms),
                                       L.ptr(log_w), L.ptr(per_b), None, None, None, None, st))
         else:
             L.check(rc)
-        logits = log_w.reshape(I, B, Kp).permute(1, 0, 2).reshape(B, I * Kp).contiguous()   # 'i b k -> b (i k)'
+        # resampling: K + r draws per datapoint from Categorical(logits = log_w[b, (i k)]) (:181-186), of which the first
+        # K are kept (:521-524); row_map = rows of the chosen proposals in the (i, b, k)-ordered decoder outputs
+        row_map = torch.empty(B * K, dtype=torch.int64, device=dev)
         if idx is not None:
             draw = idx[t].to(dev, torch.int64).t().contiguous()                 # [B, K+r]
+            L.check(lib.dmv_lair_row_map(B, K, Kp, L.ptr(draw), L.ptr(row_map), st))
         else:
-            draw = torch.empty((B, Kp), dtype=torch.int64, device=dev)
             seed, off = rng.next_offset(B * Kp)
-            L.check(lib.dmv_categorical_draw(B, I * Kp, Kp, L.ptr(logits), None, seed, off, rng.base_ptr(), L.ptr(draw), st))
-        # keep the first K draws (:521-524); rows of the chosen proposals in the (i, b, k)-ordered decoder outputs
-        row_map = torch.empty(B * K, dtype=torch.int64, device=dev)
-        L.check(lib.dmv_lair_row_map(B, K, Kp, L.ptr(draw), L.ptr(row_map), st))
-        clip = (cmin is not None or cmax is not None)
-        last = (t == num_iterations - 1) and not resample_final_imps
+            L.check(lib.dmv_categorical_draw_grouped(B, I, Kp, Kp, L.ptr(log_w), None, seed, off, rng.base_ptr(), None,
+                                                     L.ptr(row_map), K, st))
+        last = (t == T - 1) and not resample_final_imps
         Xc = _tail(dims, dec_out, row_map, Xc, Mu, noise_x[t] if noise_x is not None else None,
                    cmin if clip else None, cmax if clip else None, True,
                    buf if last else None, idx_imp.reshape(-1).contiguous() if (last and idx_imp is not None) else None)
-        if resample_final_imps:
-            Z_all.append(Z.reshape(I, B, Kp, Zd))
-            lw_all.append(log_w.reshape(I, B, Kp))
     if resample_final_imps:
-        T = num_iterations
-        Zs = torch.stack(Z_all).permute(2, 0, 1, 3, 4).reshape(B, T * I * Kp, Zd)          # 't i b k d -> b (t i k) d'
-        lws = torch.stack(lw_all).permute(2, 0, 1, 3).reshape(B, T * I * Kp).contiguous()
+        # K latents per datapoint from the pooled T I (K+r) proposals of all iterations (:671-694), decoded once more
+        rows_f = torch.empty(B * K, dtype=torch.int64, device=dev)
         if idx is not None:
-            draw = idx[T].to(dev, torch.int64).t().contiguous()                 # [B, K]
+            v = idx[T].to(dev, torch.int64).t().contiguous()                    # [B, K] proposal numbers (t i k)
+            bcol = torch.arange(B, device=dev, dtype=torch.int64)[:, None]
+            rows_f = (((v // Kp) * B + bcol) * Kp + v % Kp).reshape(-1).contiguous()
         else:
-            draw = torch.empty((B, K), dtype=torch.int64, device=dev)
             seed, off = rng.next_offset(B * K)
-            L.check(lib.dmv_categorical_draw(B, T * I * Kp, K, L.ptr(lws), None, seed, off, rng.base_ptr(), L.ptr(draw), st))
-        Zf = torch.gather(Zs, 1, draw[..., None].expand(B, K, Zd)).reshape(B * K, Zd).contiguous()
+            L.check(lib.dmv_categorical_draw_grouped(B, T * I, Kp, K, L.ptr(lw_all), None, seed, off, rng.base_ptr(), None,
+                                                     L.ptr(rows_f), K, st))
+        Zf = torch.empty((B * K, Zd), dtype=torch.float32, device=dev)
+        L.check(lib.dmv_rows_gather(L.ptr(Z_all), L.ptr(rows_f), B * K, Zd, L.ptr(Zf), st))
         dec_out, _ = mlp_forward(dec, Zf, Zd, B * K, save=False, drop_keep=_keep(dec, B * K, training, dev))
         Xc = _tail(dims, dec_out, None, Xc, Mu, noise_x[T] if noise_x is not None else None, None, None, False,
                    buf, idx_imp.reshape(-1).contiguous() if idx_imp is not None else None)

@@ -79,10 +79,12 @@ class _Ctx:
 FUSE_SMALL_FORWARD = True      # tests switch it off to compare with the three separate launches
 
 
-def fused_forward(cfg, enc: PackedNet, dec: PackedNet, in_mode, X2, M2, eps2, save: bool, keep_eps: bool):
+def fused_forward(cfg, enc: PackedNet, dec: PackedNet, in_mode, X2, M2, eps2, save: bool, keep_eps: bool, n_prior: int = 0,
+                  prior_raw: float = 0.0, enc_out=None, Z=None):
     """Encoder -> z = mu + sigma eps -> decoder in one launch (dmv_vae_forward) when the shapes allow it, else None.
     X2 / M2 [enc_rows, D]; eps2 [N, Zd] or None (device Philox).  Returns (enc_out, enc_saved, Z, eps_used, dec_out,
-    dec_saved) exactly as the separate launches leave them."""
+    dec_saved) exactly as the separate launches leave them.  n_prior / prior_raw: see dmv_vae_forward (the caller
+    passes enc_out [B, G, ld] with the prior rows filled in).  enc_out / Z: buffers to write into."""
     lib = L.lib()
     if not FUSE_SMALL_FORWARD or not lib.dmv_vae_forward_fits(C.byref(cfg), C.byref(enc.c), C.byref(dec.c)):
         return None
@@ -90,10 +92,15 @@ def fused_forward(cfg, enc: PackedNet, dec: PackedNet, in_mode, X2, M2, eps2, sa
         return None
     dev = X2.device
     Zd = cfg.Zd
-    enc_rows = cfg.B * (cfg.G if cfg.x_per_component else 1)
+    enc_rows = cfg.B * ((cfg.G - n_prior) if cfg.x_per_component else 1)
     N = cfg.nz * cfg.I * cfg.B * cfg.G
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-    enc_out, dec_out, Z = new(enc_rows, pad32(enc.dims.out_dim)), new(N, pad32(dec.dims.out_dim)), new(N, Zd)
+    if enc_out is None:
+        assert n_prior == 0
+        enc_out = new(enc_rows, pad32(enc.dims.out_dim))
+    dec_out = new(N, pad32(dec.dims.out_dim))
+    if Z is None:
+        Z = new(N, Zd)
     enc_saved = new(lib.dmv_mlp_saved_floats(C.byref(enc.c), enc_rows)) if save else None
     dec_saved = new(lib.dmv_mlp_saved_floats(C.byref(dec.c), N)) if save else None
     if eps2 is not None:
@@ -103,7 +110,8 @@ def fused_forward(cfg, enc: PackedNet, dec: PackedNet, in_mode, X2, M2, eps2, sa
         seed, off = rng.next_offset(N * Zd)
         base = rng.base_ptr()
     L.check(lib.dmv_vae_forward(C.byref(cfg), C.byref(enc.c), L.ptr(enc.packed()), in_mode, L.ptr(X2), L.ptr(M2), C.byref(dec.c),
-                                L.ptr(dec.packed()), L.ptr(eps2), seed, off, base, L.ptr(enc_out), L.ptr(enc_saved), L.ptr(Z),
+                                L.ptr(dec.packed()), L.ptr(eps2), seed, off, base, n_prior, prior_raw, L.ptr(enc_out),
+                                L.ptr(enc_saved), L.ptr(Z),
                                 Zd, L.ptr(eps_used) if eps2 is None else None, L.ptr(dec_out), L.ptr(dec_saved), L.stream_ptr()))
     return enc_out, enc_saved, Z, eps_used, dec_out, dec_saved
 
@@ -232,6 +240,7 @@ def _objective_forward(c, plan: _Plan, training: bool, *, kind, use_logpi=False,
         f.coefB = (C.c_float * 5)(*(coefB if coefB is not None else (0, 0, 0, 0, 0)))
         f.objA, f.objB, f.meanA_out, f.meanB_out = L.addr(objA), L.addr(objB), L.addr(mA), L.addr(mB)
         out = (objA, objB, mA, mB)
+    f.ticket = L.ticket_ptr()
     rc = lib.dmv_obj_forward(C.byref(c.cfg), C.byref(f), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
                              L.ptr(c.Z), c.Z.shape[1], L.ptr(c.enc_out), st)
     if rc == L.E_UNSUPPORTED and c.cfg.nz * c.cfg.I * c.G > 1024:
@@ -368,8 +377,13 @@ def _one_launch_backward(c, enc: PackedNet, dec: PackedNet, p: L.DmvLatentBwd, w
         return None
     dev = c.dec_out.device
     d_dec = torch.empty_like(c.dec_out)
-    L.check(lib.dmv_obj_backward_dec(C.byref(c.cfg), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
-                                     L.ptr(wgt_dec), L.ptr(gb_dec), L.ptr(gscale), base_m, base_f, L.ptr(d_dec), d_dec.shape[1], st))
+    dg = None
+    if d_dec.shape[1] <= 256:        # short decoder rows: the launch forms the decoder-side gradient itself
+        dg = L.DmvDecGrad(L.addr(c.dec_out), c.dec_out.shape[1], L.addr(c.Xc), L.addr(c.Mu), L.addr(wgt_dec), L.addr(gb_dec),
+                          base_m, base_f)
+    else:
+        L.check(lib.dmv_obj_backward_dec(C.byref(c.cfg), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
+                                         L.ptr(wgt_dec), L.ptr(gb_dec), L.ptr(gscale), base_m, base_f, L.ptr(d_dec), d_dec.shape[1], st))
     d_enc = torch.empty_like(c.enc_out)
     nb_dec = lib.dmv_mlp_backward_ws_bytes(C.byref(dec.c), c.N)
     nb_enc = lib.dmv_mlp_backward_ws_bytes(C.byref(enc.c), c.enc_rows)
@@ -377,7 +391,7 @@ def _one_launch_backward(c, enc: PackedNet, dec: PackedNet, p: L.DmvLatentBwd, w
     ws_enc = torch.empty((nb_enc + 3) // 4, dtype=torch.float32, device=dev)
     keep = lambda k: L.DROP_GENERATED if isinstance(k, GeneratedDropout) else L.ptr(k)
     L.check(lib.dmv_vae_backward(
-        C.byref(c.cfg), C.byref(p), C.byref(dec.c), L.ptr(dec.packed()), L.ptr(c.dec_saved), keep(c.dec_keep), L.ptr(d_dec),
+        C.byref(c.cfg), C.byref(p), C.byref(dg) if dg is not None else None, C.byref(dec.c), L.ptr(dec.packed()), L.ptr(c.dec_saved), keep(c.dec_keep), L.ptr(d_dec),
         d_dec.shape[1], L.ptr(ws_dec), nb_dec, C.byref(enc.c), L.ptr(enc.packed()), L.ptr(c.enc_saved), keep(c.enc_keep),
         L.ptr(d_enc), L.ptr(ws_enc), nb_enc, L.ptr(c.enc_out), L.ptr(c.Z), L.ptr(c.eps), c.Z.shape[1], L.ptr(wgt), L.ptr(gb_lat),
         L.ptr(zscale), L.ptr(kl_wgt), L.ptr(gscale), st))

@@ -178,34 +178,19 @@ int dmv_latent_sample(const DmvObjCfg* cfg, const float* enc, const float* eps, 
  * N = nz*I*B*G <= 4096 sample rows.  cfg's encoder-output addressing must be that of a row-major
  * [enc_rows][pad32(out_dim)] array.  Each 16-row tile of samples recomputes the encoder rows it draws from, so the
  * encoder outputs and the latents never leave the compute unit between the three stages.
+ * n_prior > 0 (x_per_component == 1 only; the samplers' prior-replenish proposals, vgiwae/shared/vae_imputation.py:
+ * 419-441): the last n_prior of a datapoint's G components have no encoder row (X / M are [B][G - n_prior][D]); their
+ * samples are drawn from mu = 0, sigma = softplus(prior_raw) (+1e-5 if q_eps).  enc_out keeps its [B][G] rows: the
+ * caller fills the prior rows once, the launch writes the others.  Forward only (no saved activations).
  * dmv_vae_forward_fits: 1 when the shapes qualify (relu networks of equal hidden tile count <= 8, N <= 4096,
  * Zd <= 256), else 0; dmv_vae_forward returns DMV_E_UNSUPPORTED for shapes that do not, and for a training pass
  * (saved activations requested) of networks with dropout, whose keep decisions the separate launches draw. */
 int dmv_vae_forward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec);
 int dmv_vae_forward(const DmvObjCfg* cfg, const DmvNet* enc, const float* enc_packed, int32_t in_mode, const float* X,
                     const uint8_t* M, const DmvNet* dec, const float* dec_packed, const float* eps, uint64_t seed,
-                    uint64_t offset, const uint64_t* offset_base, float* enc_out, float* enc_saved, float* Z,
-                    int64_t ldz, float* eps_out, float* dec_out, float* dec_saved, void* stream);
-
-/* The input-gradient half of a small batch's backward pass in ONE launch (the backward of vae_forward,
- * vgiwae/models/vae.py:285-318, that autograd builds for the reference): decoder chain -> gradient w.r.t. the encoder
- * outputs -> encoder chain, equivalent to dmv_mlp_backward(dec, grad_w = NULL) + dmv_obj_backward_latent +
- * dmv_mlp_backward(enc, grad_w = NULL).  d_dec [N][ld_ddec] is the gradient w.r.t. the decoder outputs
- * (dmv_obj_backward_dec); d_enc [enc_rows][pad32(enc out_dim)] receives the gradient w.r.t. the encoder outputs (every
- * entry written); dec_ws / enc_ws (dmv_mlp_backward_ws_bytes each) receive the per-layer gradients, after which
- * dmv_mlp_backward_wgrad(dec, ..., d_dec, ..., dec_ws) and dmv_mlp_backward_wgrad(enc, ..., d_enc, ..., enc_ws) form the
- * weight gradients.  p, wgt, gb, zscale, kl_wgt, gscale as in dmv_obj_backward_latent; posteriors without a mixture
- * term only (p->base_qmix == 0), one Gaussian per encoder row (cfg->G == 1 or cfg->x_per_component == 1), at most 16
- * samples per encoder row (nz*I <= 16: a row's samples share a 16-row tile) and the shapes dmv_vae_forward takes:
- * dmv_vae_backward_fits tells (the mixture-term condition aside); otherwise DMV_E_UNSUPPORTED. */
-int dmv_vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec);
-int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, const DmvNet* dec, const float* dec_packed,
-                     const float* dec_saved, const uint8_t* dec_drop_keep, const float* d_dec, int64_t ld_ddec,
-                     void* dec_ws, size_t dec_ws_bytes, const DmvNet* enc, const float* enc_packed,
-                     const float* enc_saved, const uint8_t* enc_drop_keep, float* d_enc, void* enc_ws,
-                     size_t enc_ws_bytes, const float* enc_out, const float* Z, const float* eps, int64_t ldz,
-                     const float* wgt, const float* gb, const float* zscale, const float* kl_wgt, const float* gscale,
-                     void* stream);
+                    uint64_t offset, const uint64_t* offset_base, int32_t n_prior, float prior_raw, float* enc_out,
+                    float* enc_saved, float* Z, int64_t ldz, float* eps_out, float* dec_out, float* dec_saved,
+                    void* stream);
 
 /* Per-sample terms (vgiwae/shared/iwae.py:17-45, 66-90, 102-132; models/mvbvae.py:83-137):
  *   terms[0][n] = sum_d M_d log p(x_d|z)      terms[1][n] = sum_d log p(x_d|z)
@@ -229,6 +214,12 @@ int dmv_obj_terms(const DmvObjCfg* cfg, int32_t q_kind, int32_t mix_C, const flo
  *   kind DMV_BOUND_PER_COMPONENT (I == 1): objA / objB [B][G] = mean_z sum_t coefA/B[t] * terms[t] (+ meanA/B_out scalars);
  *   kind -1: terms only.
  *   terms [5][N] and comp_lp [N][mix_C] are written when given.
+ * The means (mean_out, neg_mean_out, meanA/B_out) take a second, single-workgroup launch - unless the caller brings
+ * `ticket`: one uint32 in device memory that is zero when the call starts.  The workgroup that finishes last (it draws
+ * the last ticket) then sums the per-datapoint results inside the same launch, in a fixed order, and leaves the counter
+ * at zero again (launches of more than 256 workgroups ignore the ticket and take the second launch: the device-scope
+ * release every workgroup then pays costs more than it saves).  Calls that share a ticket must not overlap in time
+ * (one ticket per stream).
  * Limit: nz * I * G floats per datapoint must fit the workgroup's 60 KB of LDS (about 15 000); beyond it the call
  * returns DMV_E_UNSUPPORTED and the caller streams with dmv_obj_terms + dmv_lse_update. */
 typedef struct DmvObjFwd {
@@ -239,6 +230,7 @@ typedef struct DmvObjFwd {
   float *bound, *mean_out, *wgt, *zscale, *dlogit;
   float *objA, *objB, *meanA_out, *meanB_out;
   float *neg_mean_out;
+  uint32_t* ticket;   /* nullable */
 } DmvObjFwd;
 int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const float* dec, int64_t ld_dec, const float* X,
                     const uint8_t* M, const float* Z, int64_t ldz, const float* enc, void* stream);
@@ -289,6 +281,38 @@ int dmv_obj_backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const f
                             const float* eps, int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
                             const float* gb, const float* zscale, const float* comp_lp, const float* qmix,
                             const float* dlogit, const float* kl_wgt, const float* gscale, float* d_enc, void* stream);
+
+/* The input-gradient half of a small batch's backward pass in ONE launch (the backward of vae_forward,
+ * vgiwae/models/vae.py:285-318, that autograd builds for the reference): decoder chain -> gradient w.r.t. the encoder
+ * outputs -> encoder chain, equivalent to dmv_mlp_backward(dec, grad_w = NULL) + dmv_obj_backward_latent +
+ * dmv_mlp_backward(enc, grad_w = NULL).  d_dec [N][ld_ddec] is the gradient w.r.t. the decoder outputs
+ * (dmv_obj_backward_dec); d_enc [enc_rows][pad32(enc out_dim)] receives the gradient w.r.t. the encoder outputs (every
+ * entry written); dec_ws / enc_ws (dmv_mlp_backward_ws_bytes each) receive the per-layer gradients, after which
+ * dmv_mlp_backward_wgrad(dec, ..., d_dec, ..., dec_ws) and dmv_mlp_backward_wgrad(enc, ..., d_enc, ..., enc_ws) form the
+ * weight gradients.  p, wgt, gb, zscale, kl_wgt, gscale as in dmv_obj_backward_latent; posteriors without a mixture
+ * term only (p->base_qmix == 0), one Gaussian per encoder row (cfg->G == 1 or cfg->x_per_component == 1), at most 16
+ * samples per encoder row (nz*I <= 16: a row's samples share a 16-row tile) and the shapes dmv_vae_forward takes:
+ * dmv_vae_backward_fits tells (the mixture-term condition aside); otherwise DMV_E_UNSUPPORTED.
+ * dg (nullable): the arguments of dmv_obj_backward_dec; when given, the launch forms d_dec itself first (and writes it
+ * out for the weight-gradient GEMMs) instead of reading it: one launch less.  Decoder output rows of up to a few
+ * hundred floats (the tile's d_dec rows are staged in LDS); wider ones return DMV_E_UNSUPPORTED. */
+typedef struct DmvDecGrad {
+  const float* dec;        /* decoder outputs [N][ld_dec] */
+  int64_t ld_dec;
+  const float* X;          /* as in dmv_obj_backward_dec */
+  const uint8_t* M;
+  const float* wgt;        /* nullable [N] */
+  const float* gb;         /* nullable [B] */
+  float base_m, base_f;
+} DmvDecGrad;
+int dmv_vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec);
+int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, const DmvDecGrad* dg, const DmvNet* dec,
+                     const float* dec_packed, const float* dec_saved, const uint8_t* dec_drop_keep, float* d_dec, int64_t ld_ddec,
+                     void* dec_ws, size_t dec_ws_bytes, const DmvNet* enc, const float* enc_packed,
+                     const float* enc_saved, const uint8_t* enc_drop_keep, float* d_enc, void* enc_ws,
+                     size_t enc_ws_bytes, const float* enc_out, const float* Z, const float* eps, int64_t ldz,
+                     const float* wgt, const float* gb, const float* zscale, const float* kl_wgt, const float* gscale,
+                     void* stream);
 
 /* Backward from per-term cotangents, for objectives composed by the caller out of the five terms of dmv_obj_terms
  * (the importance-weighted DeMissVAE family, vgiwae/models/mvbiwae.py:97-565, combines them in a dozen ways).
@@ -364,6 +388,17 @@ int dmv_impute_tail(int64_t N, int32_t D, int32_t gen_dist, const float* dec, in
  * u (nullable) [B][K] uniforms in [0,1); NULL: Philox stream (seed, offset + b*K + k).  idx int64 [B][K]. */
 int dmv_categorical_draw(int32_t B, int32_t P, int32_t K, const float* logits, const float* u, uint64_t seed,
                          uint64_t offset, const uint64_t* offset_base, int64_t* idx, void* stream);
+
+/* The same draws when the logits are the log-weights of proposals held as a [groups][B][inner] array (LAIR: groups =
+ * importance samples i, or (iteration, i) pairs for the final resampling, vgiwae/shared/vae_imputation.py:181-198,
+ * 671-694; inner = K + r components), without first permuting them to [B][groups * inner]: category p = group * inner + k
+ * of datapoint b reads logits[(group * B + b) * inner + k].  idx (nullable) int64 [B][K] receives p; rows (nullable)
+ * int64 [B][rows_keep] receives, for the first rows_keep draws of each datapoint, (group * B + b) * inner + k itself:
+ * the row of the picked proposal in every array ordered like the logits (decoder outputs, latents), which is what the
+ * gathers that follow need (dmv_impute_tail's row_map, dmv_rows_gather). */
+int dmv_categorical_draw_grouped(int32_t B, int32_t groups, int32_t inner, int32_t K, const float* logits, const float* u,
+                                 uint64_t seed, uint64_t offset, const uint64_t* offset_base, int64_t* idx, int64_t* rows,
+                                 int32_t rows_keep, void* stream);
 
 /* Rows of the proposal table selected by the resampling draws (the gather of gr_resampling,
  * vgiwae/shared/vae_imputation.py:193-198, after keeping the first K draws, :521-524): draws int64 [B][Kp] hold proposal

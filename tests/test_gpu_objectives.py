@@ -613,3 +613,36 @@ def test_one_launch_backward_equals_separate_launches(case):
         assert torch.isfinite(a).all()
         tol = 1e-5 * float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= tol, (case, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_batch_means_formed_by_the_last_workgroup():
+    """With a ticket counter dmv_obj_forward forms the batch mean (and the loss, minus it) in the same launch: equal to
+    the mean of the per-datapoint bounds and to the two-launch path, call after call, the counter back at zero."""
+    import demiss_vae_amd as dmv
+    from demiss_vae_amd import _lib as L
+    from demiss_vae_amd import synth
+    enc = synth.packed_net(synth.NetShape(16, 32, 2, 64), 1, "cuda")
+    dec = synth.packed_net(synth.NetShape(16, 16, 2, 64), 2, "cuda")
+    dims = dmv.ModelDims(D=8, Zd=16, encoder_use_mis_mask=True)
+    gen = torch.Generator().manual_seed(3)
+    for B in (1, 37, 2000):
+        X = torch.randn(B, 8, generator=gen).cuda()
+        M = (torch.rand(B, 8, generator=gen) < 0.5).cuda()
+        eps = torch.randn(1, 5, B, 16, generator=gen).cuda()
+        assert L.ticket_ptr() is not None
+        outs = []
+        for _ in range(2):
+            mean, per_b, neg = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_importance_samples=5, STL=True, eps=eps, with_loss=True)
+            outs.append((mean.item(), neg.item()))
+            np.testing.assert_allclose(mean.item(), per_b.double().mean().item(), rtol=2e-6)
+            assert neg.item() == -mean.item()
+        assert outs[0] == outs[1]
+        saved, L.ticket_ptr = L.ticket_ptr, lambda: None
+        try:
+            mean2, _ = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_importance_samples=5, STL=True, eps=eps)
+        finally:
+            L.ticket_ptr = saved
+        np.testing.assert_allclose(outs[0][0], mean2.item(), rtol=2e-6)
+    torch.cuda.synchronize()
+    slots, _ = L._TICKETS[torch.cuda.current_device()]
+    assert int(slots.abs().sum()) == 0
