@@ -421,6 +421,7 @@ def main():
         extra["yaml_batch_512_hip_graph"] = {"ms_per_step": round(tg * 1e3, 4), "samples_per_s": round(512 * K / tg, 1)}
         from demiss_vae_amd.bench_extra import demiss_toy_step, missiwae_step
         extra["demiss_toy_mvb2"] = demiss_toy_step(device)
+        extra["demiss_uci_gas_lair"] = demiss_toy_step(device, B=512, K=5, uci=True)
         extra["hepmass_missiwae"] = missiwae_step(device, "UCI-hepmass", 4096, 21, 16, (42, 165, 2, 256), (16, 42, 2, 256))
         extra["miniboone_missiwae"] = missiwae_step(device, "UCI-miniboone", 8192, 43, 32, (86, 325, 5, 256),
                                                     (32, 86, 2, 256), dropout=0.5)

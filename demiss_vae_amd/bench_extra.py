@@ -100,15 +100,25 @@ def iwae_step(device, B, I=5, *, name="UCI-gas", D=8, Zd=16, enc_shape=(16, 32, 
             "samples_per_s": round(B * I / t, 1), "step_tflops": round(flops / t / 1e12, 2)}
 
 
-def demiss_toy_step(device, B=4096, K=5, parts=False):
+def demiss_toy_step(device, B=4096, K=5, parts=False, uci=False):
     """toy_mog2_large DeMissVAE (configs/toy_mog2_large/compare/mis50/mvb2vae_lairdmisr0_k5_stl_mlp.yaml shapes:
     D=5, Zd=2, encoder (5,4,3,200), decoder (2,10,3,200), K=5 imputations, LAIR I=1 r=0 T=1, mvb2 + STL):
-    gather from the device buffer -> LAIR update with write-back -> two objectives -> two backward calls -> Adam."""
-    enc_s, dec_s = NetSpec(5, 4, 3, 200), NetSpec(2, 10, 3, 200)
+    gather from the device buffer -> LAIR update with write-back -> two objectives -> two backward calls -> Adam.
+    uci: the UCI-gas DeMissVAE config instead (configs/uci_gas/compare/mis50/mvb2vae_lairdmisr1iter10_k5_stl_gradclip1.yaml:
+    D=8, Zd=16, encoder (8,32,2,256), decoder (16,16,2,256), normal_with_eps, LAIR with one prior-replenish proposal, ten
+    iterations and the final resampling, gradient clipping at norm 1)."""
+    if uci:
+        enc_s, dec_s, D = NetSpec(8, 32, 2, 256), NetSpec(16, 16, 2, 256), 8
+        dims = ModelDims(D=8, Zd=16, gen_dist="normal_with_eps", q_dist="normal_with_eps", encoder_use_mis_mask=False)
+        lair_kw = dict(num_iterations=10, num_imp_samples=1, num_prior_replenish_proposals=1, resample_final_imps=True)
+        N = 102400
+    else:
+        enc_s, dec_s, D = NetSpec(5, 4, 3, 200), NetSpec(2, 10, 3, 200), 5
+        dims = ModelDims(D=5, Zd=2, gen_dist="normal", q_dist="normal", encoder_use_mis_mask=False)
+        lair_kw = dict(num_iterations=1, num_imp_samples=1)
+        N = 19366
     enc, dec = _packed(device, enc_s, 1, True), _packed(device, dec_s, 2, True)
-    dims = ModelDims(D=5, Zd=2, gen_dist="normal", q_dist="normal", encoder_use_mis_mask=False)
-    N = 19366
-    X, M = make_batch(3, N, 5)
+    X, M = make_batch(3, N, D)
     buf = imp.ImputationBuffer(X, K, device)
     Mdev = M.to(device)
     params = enc.params() + dec.params()
@@ -126,14 +136,16 @@ def demiss_toy_step(device, B=4096, K=5, parts=False):
 
     def step():
         Xt, idx = buf.gather(index)
-        Mk = Mdev[index].unsqueeze(1).expand(B, K, 5).contiguous()
-        Xt = imp.lair(dims, enc, dec, Xt, Mk, num_iterations=1, num_imp_samples=1, buf=buf, idx_imp=idx)
+        Mk = Mdev[index].unsqueeze(1).expand(B, K, D).contiguous()
+        Xt = imp.lair(dims, enc, dec, Xt, Mk, buf=buf, idx_imp=idx, **lair_kw)
         # as the model class steps (vgiwae/models/mvbvae.py, mvb2_manual_optimisation_step): the two objectives as scalar
         # means, ascended through a cached root gradient of -1
         gen_obj, enc_obj = mvb2_objectives(dims, enc, dec, Xt, Mk, num_latent_samples=1, STL=True, reduce_mean=True)
         opt.zero_grad(set_to_none=True)
         gen_obj.backward(minus_one, retain_graph=True, inputs=dec.params())
         enc_obj.backward(minus_one, inputs=enc.params())
+        if uci:
+            opt.clip_on_next_step(1.0)
         opt.step()
 
     def eager():
@@ -146,7 +158,9 @@ def demiss_toy_step(device, B=4096, K=5, parts=False):
     from .graph import GraphedStep
     replay = GraphedStep(step, refresh=next_batch, nets=(enc, dec))
     t = _sync_time(replay, 100, 10)
-    return {"workload": f"toy_mog2_large DeMissVAE mvb2 step incl. LAIR update, B={B}, K={K}, HIP-graph replay",
+    name = "UCI-gas DeMissVAE mvb2 step incl. LAIR update (r=1, 10 iterations, final resampling)" if uci else \
+        "toy_mog2_large DeMissVAE mvb2 step incl. LAIR update"
+    return {"workload": f"{name}, B={B}, K={K}, HIP-graph replay",
             "ms_per_step": round(t * 1e3, 4), "samples_per_s": round(B * K / t, 1), "eager_ms_per_step": round(t_eager * 1e3, 4)}
 
 

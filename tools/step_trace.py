@@ -25,6 +25,12 @@ if what == "toy":
     from demiss_vae_amd.bench_extra import demiss_toy_step
     step, refresh, (enc, dec) = demiss_toy_step(torch.device("cuda"), parts=True)
     B = 4096
+elif what == "uci":
+    # UCI-gas DeMissVAE: LAIR update (one prior-replenish proposal, ten iterations, final resampling) + two objectives +
+    # two backward passes + clip + Adam, B = 512, K = 5
+    from demiss_vae_amd.bench_extra import demiss_toy_step
+    step, refresh, (enc, dec) = demiss_toy_step(torch.device("cuda"), B=512, K=5, parts=True, uci=True)
+    B = 512
 elif what in ("hepmass", "miniboone"):
     # MissSIWAE (stratified mixture of 5, one sample per component): configs/uci_hepmass, configs/uci_miniboone shapes
     from demiss_vae_amd import synth

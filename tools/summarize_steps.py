@@ -1,10 +1,16 @@
 #!/usr/bin/env python
 """Turn the output of tools/prof_r2.sh (gpurun_out/r2prof) into profiles/r2_training_steps.md and copy the raw
-rocprofv3 kernel statistics next to it."""
+rocprofv3 kernel statistics next to it.  `python tools/summarize_steps.py r3` does the same for tools/prof_r3.sh
+(see summarize_r3 below)."""
 import csv
 import json
 import shutil
+import sys
 
+if len(sys.argv) > 1 and sys.argv[1] == "r3":
+    from summarize_steps_r3 import main
+    main()
+    sys.exit(0)
 src = "gpurun_out/r2prof/"
 for a, b in (("step_32768_eager", "r2_step_32768"), ("step_512_graph", "r2_step_512"), ("step_hepmass_graph", "r2_step_hepmass"),
              ("step_miniboone_graph", "r2_step_miniboone"), ("runner_epoch", "r2_runner_epoch")):
