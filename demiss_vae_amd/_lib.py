@@ -96,10 +96,12 @@ SIGNATURES = {
     "dmv_vae_forward_fits": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), C.POINTER(DmvNet)]),
     "dmv_vae_forward": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), _P, _I32, _P, _P, C.POINTER(DmvNet), _P, _P, _U64, _U64,
                                   _P, _I32, _F, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "dmv_lair_resample_tail": (C.c_int, [_I32, _I32, _I32, _I32, _I32, _P, _P, _U64, _U64, _I32, _I32, _P, _I64, _P, _P, _P, _U64, _U64,
+                                         _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmv_categorical_draw_grouped": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _U64, _U64, _P, _P, _P, _I32, _P]),
-    "dmv_vae_backward_fits": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), C.POINTER(DmvNet)]),
+    "dmv_vae_backward_fits": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), C.POINTER(DmvNet), _I32]),
     "dmv_vae_backward": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvLatentBwd), C.POINTER(DmvDecGrad), C.POINTER(DmvNet), _P, _P, _P, _P, _I64, _P, _SZ,
-                                   C.POINTER(DmvNet), _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
+                                   C.POINTER(DmvNet), _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmv_obj_terms": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "dmv_obj_bound": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmv_obj_combine": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(_F), _P, _P, _P, _P]),

@@ -212,6 +212,70 @@ __global__ void k_categorical_draw(DrawArgs a) {
   }
 }
 
+// LAIR's resampling and sampling tail in one launch (vgiwae/shared/vae_imputation.py:181-198, 521-561): a wavefront per
+// datapoint draws its K + r proposal numbers exactly as k_categorical_draw does (same uniforms, same running sum), keeps
+// the rows of the first K in LDS, and then produces the datapoint's K new imputations exactly as k_impute_tail does from
+// those rows (same noise counters, same arithmetic): what the two launches compute, without the second launch and the
+// round trip of the row map.
+__global__ void k_lair_resample_tail(DrawArgs a, TailArgs t, int Kkeep) {
+  __shared__ float stage[4][kDrawStage];
+  __shared__ int64_t srow[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x * (blockDim.x >> 6) + wv;
+  if (b >= a.B) return;
+  const float* lw0 = a.logits + (int64_t)b * a.inner;
+  auto pos = [&](int p) { const int grp = p / a.inner; return (int64_t)grp * a.group_stride + (p - grp * a.inner); };
+  float mx = -INFINITY;
+  for (int p = lane; p < a.P; p += 64) mx = fmaxf(mx, lw0[pos(p)]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float se = 0.f;
+  for (int p = lane; p < a.P; p += 64) {
+    const float e = expf(lw0[pos(p)] - mx);
+    stage[wv][p] = e;
+    se += e;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  if (lane < a.K) {
+    const int k = lane;
+    const float u = a.u ? a.u[(int64_t)b * a.K + k]
+                        : dmv_philox_uniform(a.seed, a.offset + (a.offset_base ? a.offset_base[0] : 0ull) + (uint64_t)b * a.K + k);
+    const float target = u * se;
+    float c = 0.f;
+    int pick = a.P - 1;
+    for (int p = 0; p < a.P; ++p) {
+      c += stage[wv][p];
+      if (c > target) { pick = p; break; }
+    }
+    if (a.idx) a.idx[(int64_t)b * a.K + k] = pick;
+    if (k < Kkeep) {
+      const int64_t row = (int64_t)b * a.inner + pos(pick);
+      srow[wv][k] = row;
+      if (a.rows) a.rows[(int64_t)b * Kkeep + k] = row;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  // ---- the datapoint's K rows of new imputations
+  const uint64_t off = t.offset + (t.offset_base ? t.offset_base[0] : 0ull);
+  const bool normal = t.gen_dist <= DMV_GEN_NORMAL_EPS;
+  for (int e = lane; e < Kkeep * t.D; e += 64) {
+    const int k = e / t.D, d = e - k * t.D;
+    const int64_t n = (int64_t)b * Kkeep + k;
+    const int64_t i = n * t.D + d;
+    const float* dec = t.dec + srow[wv][k] * t.ld_dec;
+    const float noise = t.noise ? t.noise[i]
+                                : normal ? dmv_philox_normal(t.seed, off + (uint64_t)i)
+                                         : dmv_philox_uniform(t.seed, off + (uint64_t)i);
+    const float out = tail_element(t, dec, d, noise, t.X_old[i], t.M[i] != 0);
+    t.X_out[i] = out;
+    if (t.buf) t.buf[t.idx_imp[n] * t.D + d] = out;
+  }
+}
+
 // Bernoulli(1 - p) keep masks for the residual blocks' dropout (vgiwae/shared/neural_nets.py:65,70)
 __global__ void k_dropout_masks(uint8_t* __restrict__ keep, int64_t n, float p, uint64_t seed, uint64_t offset,
                                 const uint64_t* offset_base) {
@@ -361,6 +425,33 @@ extern "C" int dmv_categorical_draw_grouped(int32_t B, int32_t groups, int32_t i
   a.offset_base = offset_base; a.idx = idx;
   a.inner = inner; a.group_stride = (int64_t)B * inner; a.rows = rows; a.rows_keep = rows ? rows_keep : 0;
   hipLaunchKernelGGL(k_categorical_draw, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+extern "C" int dmv_lair_resample_tail(int32_t B, int32_t groups, int32_t inner, int32_t K_draws, int32_t K, const float* logits,
+                                      const float* u, uint64_t draw_seed, uint64_t draw_offset, int32_t D, int32_t gen_dist,
+                                      const float* dec, int64_t ld_dec, const float* X_old, const uint8_t* M, const float* noise,
+                                      uint64_t tail_seed, uint64_t tail_offset, const uint64_t* offset_base,
+                                      const float* clip_min, const float* clip_max, float* X_out, float* buf,
+                                      const int64_t* idx_imp, int64_t* rows, void* stream) {
+  if (B < 1 || groups < 1 || inner < 1 || K < 1 || K_draws < K || D < 1 || !logits || !dec || !X_old || !M || !X_out)
+    return DMV_E_BADARG;
+  if (gen_dist < DMV_GEN_NORMAL || gen_dist > DMV_GEN_BERN_M1P1) return DMV_E_UNSUPPORTED;
+  // the proposals' probabilities are staged in LDS and the draws sit on the lanes of one wavefront
+  if ((int64_t)groups * inner > kDrawStage || K_draws > 64) return DMV_E_UNSUPPORTED;
+  const int P = gen_dist <= DMV_GEN_NORMAL_EPS ? 2 * D : D;
+  if (ld_dec < P || (buf && !idx_imp)) return DMV_E_BADARG;
+  DrawArgs a;
+  a.B = B; a.P = groups * inner; a.K = K_draws; a.logits = logits; a.u = u; a.seed = draw_seed; a.offset = draw_offset;
+  a.offset_base = offset_base; a.idx = nullptr;
+  a.inner = inner; a.group_stride = (int64_t)B * inner; a.rows = rows; a.rows_keep = K;
+  TailArgs t;
+  t.N = (int64_t)B * K; t.D = D; t.gen_dist = gen_dist; t.dec = dec; t.ld_dec = ld_dec; t.row_map = nullptr;
+  t.X_old = X_old; t.M = M; t.noise = noise; t.seed = tail_seed; t.offset = tail_offset; t.offset_base = offset_base;
+  t.clip_min = clip_min; t.clip_max = clip_max; t.clip_after_blend = 1;
+  t.X_out = X_out; t.buf = buf; t.idx_imp = idx_imp;
+  hipLaunchKernelGGL(k_lair_resample_tail, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, t, K);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }

@@ -1621,6 +1621,16 @@ struct VaeBwdArgs {
   float dg_base_m, dg_base_f;
   int D, gen_dist, x_per_row;  // x_per_row: X / M have a row per encoder row (else per datapoint)
   int ldD;                     // pitch of dec.gy
+  // mixture term (mix != 0): the unit of a tile is a DATAPOINT with its RU = S C sample rows n = (s B + b) C + g and its ER
+  // encoder rows (1: the C components share a row, stratified mixture; C: a row per imputation); Q = 16 / RU
+  int mix;                     // 0, DMV_Q_STRATIFIED or DMV_Q_IMPUTATION
+  int B, C, RU, ER;
+  int sg, logit_off;           // stride between components and offset of the logits inside a datapoint's encoder rows
+  float base_qmix, base_w;
+  int mix_live;
+  const float* comp_lp;        // [N][C]
+  const float* qmix;           // [N]
+  const float* dlogit;         // nullable [B][C]
 };
 
 template <int NT>
@@ -1635,6 +1645,23 @@ __global__ __launch_bounds__(256, 1) void k_vae_bwd_rows16(VaeBwdArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 15, g = lane >> 4;
   const int e0 = blockIdx.x * a.Q;
+  // tile row mm -> sample row n, its datapoint b and the row of X / M it is scored against; false: no such row
+  auto sample_row = [&](int mm, int64_t& n, int& b, int64_t& xrow) {
+    if (!a.mix) {
+      const int qd = mm / a.S, sd = mm - qd * a.S;
+      const int e = e0 + qd;
+      n = (int64_t)sd * a.BG + e;
+      b = e / a.G;
+      xrow = a.x_per_row ? e : b;
+      return qd < a.Q && e < a.BG;
+    }
+    const int qd = mm / a.RU, rem = mm - qd * a.RU;
+    const int sd = rem / a.C, gc = rem - sd * a.C;
+    b = e0 + qd;
+    n = ((int64_t)sd * a.B + b) * a.C + gc;
+    xrow = a.x_per_row ? (int64_t)b * a.C + gc : b;
+    return qd < a.Q && b < a.B;
+  };
 
   // ---- gradient w.r.t. the decoder outputs of the tile's rows:
   //      d_dec[n][c] = gs gb[b] (M_d wgt[n] base_m + wgt[n] base_f) d log p(x_d | z) / d param_c
@@ -1645,14 +1672,11 @@ __global__ __launch_bounds__(256, 1) void k_vae_bwd_rows16(VaeBwdArgs a) {
     const float geps = a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f;
     for (int i = threadIdx.x; i < 16 * a.ldD; i += 256) {
       const int mm = i / a.ldD, c = i - mm * a.ldD;
-      const int qd = mm / a.S, sd = mm - qd * a.S;
-      const int e = e0 + qd;
       float v = 0.f;
-      const bool live = qd < a.Q && e < a.BG;
+      int64_t n, xrow;
+      int b;
+      const bool live = sample_row(mm, n, b, xrow);
       if (live && c < P) {
-        const int64_t n = (int64_t)sd * a.BG + e;
-        const int b = e / a.G;
-        const int64_t xrow = a.x_per_row ? e : b;
         const int d = c < a.D ? c : c - a.D;
         const float* dec = a.dg_dec + n * a.dg_ld;
         const float gbb = gs * (a.dg_gb ? a.dg_gb[b] : 1.f);
@@ -1671,16 +1695,17 @@ __global__ __launch_bounds__(256, 1) void k_vae_bwd_rows16(VaeBwdArgs a) {
         }
       }
       ddt[i] = v;
-      if (live) a.dg_out[((int64_t)sd * a.BG + e) * a.ldD + c] = v;
+      if (live) a.dg_out[n * a.ldD + c] = v;
     }
     __syncthreads();
   }
 
-  // ---- decoder chain on the rows (q, s) -> n = s BG + e0 + q
+  // ---- decoder chain on the tile's sample rows
   {
-    const int qd = m / a.S, sd = m - qd * a.S;
-    const bool live = qd < a.Q && e0 + qd < a.BG;
-    const int64_t n = live ? (int64_t)sd * a.BG + e0 + qd : 0;
+    int64_t n, xrow_;
+    int b_;
+    const bool live = sample_row(m, n, b_, xrow_);
+    if (!live) n = 0;
     const float* gyr = a.dg_dec ? ddt + m * a.ldD : a.dec.gy + n * a.dec.ldgy;
     r16_backward_chain<NT, W>(
         a.dec, lds, lane, wv, n, live, true,
@@ -1691,7 +1716,7 @@ __global__ __launch_bounds__(256, 1) void k_vae_bwd_rows16(VaeBwdArgs a) {
   __syncthreads();
 
   // ---- gradient w.r.t. (mu, raw sigma) of the tile's encoder rows
-  {
+  if (!a.mix) {
     const float gs = a.gscale ? a.gscale[0] : 1.f;
     const bool zs_on = a.use_zscale && a.zscale;
     for (int i = threadIdx.x; i < a.Q * a.Zd; i += 256) {
@@ -1727,17 +1752,154 @@ __global__ __launch_bounds__(256, 1) void k_vae_bwd_rows16(VaeBwdArgs a) {
       det[qq * a.ldE + j] = acc_mu;
       det[qq * a.ldE + a.raw_off + j] = acc_sg * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
     }
+  } else {
+    // Mixture term (the arithmetic of k_obj_bwd_latent_mix on the tile's datapoints): per datapoint the components' mu,
+    // 1 / sigma^2, 1 / sigma and log mixture weights, and per sample group s the latents, the mixture term's row weights
+    // and the responsibilities r[g][c] = pi_c N_c(z_g) / q_mix(z_g) in LDS; accumulators of (mu, raw sigma, logit) too.
+    const int C = a.C, Zd = a.Zd, GZ = C * Zd, per = 6 * GZ + 3 * C + C * C;
+    float* mx = ddt + (a.dg_dec ? 16 * a.ldD : 0);                 // behind the decoder-output gradients
+    const float gs = a.gscale ? a.gscale[0] : 1.f;
+    const bool strat = a.mix == DMV_Q_STRATIFIED;
+    const int64_t sb = (int64_t)a.ER * a.ldE;                        // a datapoint's encoder rows are consecutive
+    auto fld = [&](int q, int f) { return mx + q * per + f * GZ; };  // f = 0..5: mu, 1/sigma^2, 1/sigma, z, acc_mu, acc_sigma
+    auto sml = [&](int q, int f) { return mx + q * per + 6 * GZ + f * C; };   // f = 0..2: log pi, row weight, acc_logit
+    auto rsp = [&](int q) { return mx + q * per + 6 * GZ + 3 * C; };
+    for (int i = threadIdx.x; i < a.Q * GZ; i += 256) {
+      const int q = i / GZ, r = i - q * GZ, gp = r / Zd, j = r - gp * Zd;
+      const int b = e0 + q;
+      if (b >= a.B) continue;
+      const float* er = a.enc_out + (int64_t)b * sb + gp * a.sg;
+      const float sgm = dmv_softplus(er[a.raw_off + j]) + a.q_eps;
+      fld(q, 0)[r] = er[j];
+      fld(q, 1)[r] = 1.f / (sgm * sgm);
+      fld(q, 2)[r] = 1.f / sgm;
+      fld(q, 4)[r] = 0.f;
+      fld(q, 5)[r] = 0.f;
+    }
+    for (int i = threadIdx.x; i < a.Q * C; i += 256) {
+      const int q = i / C, c = i - q * C;
+      const int b = e0 + q;
+      if (b >= a.B) continue;
+      float lp = -logf((float)C), al = 0.f;
+      if (strat) {
+        const float* lg = a.enc_out + (int64_t)b * sb + a.logit_off;
+        float lm = -INFINITY;
+        for (int k = 0; k < C; ++k) lm = fmaxf(lm, lg[k]);
+        float ss = 0.f;
+        for (int k = 0; k < C; ++k) ss += expf(lg[k] - lm);
+        lp = lg[c] - (lm + logf(ss));
+        if (a.dlogit) al = a.base_w * gs * (a.gb ? a.gb[b] : 1.f) * a.dlogit[(int64_t)b * C + c];
+      }
+      sml(q, 0)[c] = lp;
+      sml(q, 2)[c] = al;
+    }
+    for (int s = 0; s < a.S; ++s) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < a.Q * GZ; i += 256) {
+        const int q = i / GZ, r = i - q * GZ, gp = r / Zd, j = r - gp * Zd;
+        const int b = e0 + q;
+        if (b >= a.B) continue;
+        const int64_t n = ((int64_t)s * a.B + b) * C + gp;
+        fld(q, 3)[r] = a.Z[n * a.ldz + j];
+      }
+      for (int i = threadIdx.x; i < a.Q * C; i += 256) {
+        const int q = i / C, c = i - q * C;
+        const int b = e0 + q;
+        if (b >= a.B) continue;
+        const int64_t n = ((int64_t)s * a.B + b) * C + c;
+        sml(q, 1)[c] = a.base_qmix * gs * (a.gb ? a.gb[b] : 1.f) * (a.wgt ? a.wgt[n] : 1.f);
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < a.Q * C * C; i += 256) {
+        const int q = i / (C * C), r = i - q * C * C, gg = r / C, c = r - gg * C;
+        const int b = e0 + q;
+        if (b >= a.B) continue;
+        const int64_t n = ((int64_t)s * a.B + b) * C + gg;
+        rsp(q)[r] = expf(sml(q, 0)[c] + a.comp_lp[n * C + c] - a.qmix[n]);
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < a.Q * GZ; i += 256) {
+        const int q = i / GZ, r = i - q * GZ, gp = r / Zd, j = r - gp * Zd;
+        const int b = e0 + q;
+        if (b >= a.B) continue;
+        const int64_t n = ((int64_t)s * a.B + b) * C + gp;
+        const float gbb = gs * (a.gb ? a.gb[b] : 1.f);
+        const float w = gbb * (a.wgt ? a.wgt[n] : 1.f);
+        const float mu = fld(q, 0)[r], is2 = fld(q, 1)[r], isg = fld(q, 2)[r];
+        const float z = fld(q, 3)[r];
+        // (1) reparameterised path: only samples drawn from component gp depend on (mu, sigma)_{gp}
+        float dz = dzt[(q * a.RU + s * C + gp) * a.ZP + j] + a.base_prior * w * (-z);
+        if (a.base_qown != 0.f) dz += a.base_qown * w * (-(z - mu) * is2);
+        float t = 0.f;
+        for (int c = 0; c < C; ++c) t += rsp(q)[gp * C + c] * (-(z - fld(q, 0)[c * Zd + j]) * fld(q, 1)[c * Zd + j]);
+        dz += sml(q, 1)[gp] * t;
+        if (a.use_zscale && a.zscale) dz *= a.zscale[n];
+        float am = dz, as = dz * a.eps[n * a.ldz + j];
+        // (2) direct dependence of log q_own on its parameters
+        if (a.own_live && a.base_qown != 0.f) {
+          const float df = z - mu;
+          am += a.base_qown * w * (df * is2);
+          as += a.base_qown * w * (df * df * is2 * isg - isg);
+        }
+        // (3) direct dependence of log q_mix (evaluated at every sample of the datapoint) on component gp
+        if (a.mix_live) {
+          for (int gg = 0; gg < C; ++gg) {
+            const float wr = sml(q, 1)[gg] * rsp(q)[gg * C + gp];
+            const float df = fld(q, 3)[gg * Zd + j] - mu;
+            am += wr * (df * is2);
+            as += wr * (df * df * is2 * isg - isg);
+          }
+        }
+        fld(q, 4)[r] += am;
+        fld(q, 5)[r] += as;
+      }
+      if (strat && a.mix_live) {
+        for (int i = threadIdx.x; i < a.Q * C; i += 256) {
+          const int q = i / C, c = i - q * C;
+          if (e0 + q >= a.B) continue;
+          const float pi = expf(sml(q, 0)[c]);
+          float al = 0.f;
+          for (int gg = 0; gg < C; ++gg) al += sml(q, 1)[gg] * (rsp(q)[gg * C + c] - pi);
+          sml(q, 2)[c] += al;
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.Q * GZ; i += 256) {
+      const int q = i / GZ, r = i - q * GZ, gp = r / Zd, j = r - gp * Zd;
+      const int b = e0 + q;
+      if (b >= a.B) continue;
+      const float raw = a.enc_out[(int64_t)b * sb + gp * a.sg + a.raw_off + j];
+      float am = fld(q, 4)[r], as = fld(q, 5)[r];
+      if (a.kl_coef != 0.f) {
+        const float kc = a.kl_coef * gs * (a.kl_wgt ? a.kl_wgt[(int64_t)b * C + gp] : 1.f);
+        const float isg = fld(q, 2)[r];
+        am += kc * fld(q, 0)[r];
+        as += kc * (1.f / isg - isg);
+      }
+      det[q * (int)sb + gp * a.sg + j] = am;
+      det[q * (int)sb + gp * a.sg + a.raw_off + j] = as * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
+    }
+    if (strat)
+      for (int i = threadIdx.x; i < a.Q * C; i += 256) {
+        const int q = i / C, c = i - q * C;
+        if (e0 + q < a.B) det[q * (int)sb + a.logit_off + c] = sml(q, 2)[c];
+      }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < a.Q * a.ldE; i += 256) {
+  // the tile's encoder rows: Q (one per unit), or Q ER (the encoder rows of Q datapoints)
+  const int erows = a.mix ? a.Q * a.ER : a.Q;
+  const int64_t erow0 = a.mix ? (int64_t)e0 * a.ER : e0;
+  const int64_t erow_end = a.mix ? (int64_t)a.B * a.ER : a.BG;
+  for (int i = threadIdx.x; i < erows * a.ldE; i += 256) {
     const int qq = i / a.ldE;
-    if (e0 + qq < a.BG) a.d_enc[(int64_t)e0 * a.ldE + i] = det[i];
+    if (erow0 + qq < erow_end) a.d_enc[erow0 * a.ldE + i] = det[i];
   }
 
-  // ---- encoder chain on the tile's encoder rows (lanes m >= Q idle)
+  // ---- encoder chain on the tile's encoder rows (the other lanes idle)
   {
-    const bool live = m < a.Q && e0 + m < a.BG;
-    const int64_t row = live ? e0 + m : 0;
+    const bool live = m < erows && erow0 + m < erow_end;
+    const int64_t row = live ? erow0 + m : 0;
     r16_backward_chain<NT, W>(
         a.enc, lds, lane, wv, row, live, false,
         [&](int k0) { const f32x4 b = *(const f32x4*)(det + m * a.ldE + k0); return live ? b : zero4(); },
@@ -2501,22 +2663,24 @@ extern "C" int dmv_mlp_backward_wgrad(const DmvNet* net, const float* saved, con
 // ---- decoder chain -> latent-side gradient -> encoder chain in one launch
 template <int NT>
 static int launch_vae_bwd(const VaeBwdArgs& a, size_t dyn_bytes, hipStream_t st) {
-  const unsigned tiles = (unsigned)((a.BG + a.Q - 1) / a.Q);
+  const int units = a.mix ? a.B : a.BG;
+  const unsigned tiles = (unsigned)((units + a.Q - 1) / a.Q);
   hipLaunchKernelGGL((k_vae_bwd_rows16<NT>), dim3(tiles), dim3(256), dyn_bytes, st, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
 
-static bool vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec) {
+static bool vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec, bool mixture) {
   if (!vae_forward_fits(cfg, enc, dec)) return false;
   const int S = cfg->nz * cfg->I;
-  if (S > 16) return false;                                       // a row's samples share a tile
+  if (mixture) return S * cfg->G <= 16;                           // a datapoint's samples of all components share a tile
+  if (S > 16) return false;                                       // an encoder row's samples share a tile
   if (!cfg->x_per_component && cfg->G != 1) return false;         // one Gaussian per encoder row
   return true;
 }
 
-extern "C" int dmv_vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec) {
-  return vae_backward_fits(cfg, enc, dec) ? 1 : 0;
+extern "C" int dmv_vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec, int32_t mixture) {
+  return vae_backward_fits(cfg, enc, dec, mixture != 0) ? 1 : 0;
 }
 
 extern "C" int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, const DmvDecGrad* dg, const DmvNet* dec,
@@ -2525,9 +2689,14 @@ extern "C" int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, con
                                 const float* enc_saved, const uint8_t* enc_drop_keep, float* d_enc, void* enc_ws,
                                 size_t enc_ws_bytes, const float* enc_out, const float* Z, const float* eps, int64_t ldz,
                                 const float* wgt, const float* gb, const float* zscale, const float* kl_wgt,
-                                const float* gscale, void* stream) {
-  if (!vae_backward_fits(cfg, enc, dec)) return DMV_E_UNSUPPORTED;
-  if (!p || p->base_qmix != 0.f) return DMV_E_UNSUPPORTED;        // mixture terms: the separate launches
+                                const float* comp_lp, const float* qmix, const float* dlogit, const float* gscale,
+                                void* stream) {
+  if (!p) return DMV_E_BADARG;
+  const bool mixture = p->base_qmix != 0.f;
+  if (!vae_backward_fits(cfg, enc, dec, mixture)) return DMV_E_UNSUPPORTED;
+  if (mixture && (p->mix_kind != DMV_Q_STRATIFIED && p->mix_kind != DMV_Q_IMPUTATION)) return DMV_E_BADARG;
+  if (mixture && (!comp_lp || !qmix)) return DMV_E_BADARG;
+  if (mixture && ((p->mix_kind == DMV_Q_IMPUTATION) != (cfg->x_per_component != 0))) return DMV_E_BADARG;
   if (!dec_packed || !dec_saved || !d_dec || !dec_ws || !enc_packed || !enc_saved || !d_enc || !enc_ws || !enc_out || !Z || !eps)
     return DMV_E_BADARG;
   const int64_t ldE = dmv_pad32(enc->out_dim);
@@ -2537,6 +2706,9 @@ extern "C" int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, con
     return DMV_E_BADARG;
   if (cfg->enc_sb != rows_per_b * ldE || (rows_per_b != 1 && cfg->enc_sg != ldE) || cfg->raw_off < cfg->Zd ||
       cfg->raw_off + cfg->Zd > ldE)
+    return DMV_E_BADARG;
+  if (mixture && rows_per_b == 1 &&
+      ((int64_t)(cfg->G - 1) * cfg->enc_sg + cfg->raw_off + cfg->Zd > ldE || cfg->logit_off + cfg->G > ldE || cfg->enc_sg < cfg->Zd))
     return DMV_E_BADARG;
   if ((dec->dropout_p > 0.f && dec->nb > 0 && !dec_drop_keep) || (enc->dropout_p > 0.f && enc->nb > 0 && !enc_drop_keep))
     return DMV_E_BADARG;
@@ -2568,6 +2740,16 @@ extern "C" int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, con
   a.enc_out = enc_out; a.Z = Z; a.eps = eps; a.ldz = ldz;
   a.wgt = wgt; a.gb = gb; a.zscale = zscale; a.kl_wgt = kl_wgt; a.gscale = gscale; a.d_enc = d_enc;
   size_t dyn = sizeof(float) * 16 * ((size_t)ldE + (size_t)a.ZP);
+  a.mix = mixture ? p->mix_kind : 0;
+  a.B = cfg->B; a.C = cfg->G; a.RU = a.S * cfg->G; a.ER = rows_per_b;
+  a.sg = (int)cfg->enc_sg; a.logit_off = (int)cfg->logit_off;
+  a.base_qmix = p->base_qmix; a.base_w = p->base_w; a.mix_live = p->mix_live;
+  a.comp_lp = comp_lp; a.qmix = qmix; a.dlogit = dlogit;
+  if (mixture) {
+    a.Q = 16 / a.RU;
+    const size_t GZ = (size_t)cfg->G * cfg->Zd;
+    dyn += sizeof(float) * (size_t)a.Q * (6 * GZ + 3 * (size_t)cfg->G + (size_t)cfg->G * cfg->G);
+  }
   a.dg_dec = nullptr; a.dg_out = d_dec; a.dg_ld = 0; a.dg_X = nullptr; a.dg_M = nullptr; a.dg_wgt = nullptr; a.dg_gb = nullptr;
   a.dg_base_m = 0.f; a.dg_base_f = 0.f;
   a.D = cfg->D; a.gen_dist = cfg->gen_dist; a.x_per_row = cfg->x_per_component; a.ldD = (int)ld_ddec;
@@ -2580,5 +2762,6 @@ extern "C" int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, con
     a.dg_dec = dg->dec; a.dg_ld = dg->ld_dec; a.dg_X = dg->X; a.dg_M = dg->M; a.dg_wgt = dg->wgt; a.dg_gb = dg->gb;
     a.dg_base_m = dg->base_m; a.dg_base_f = dg->base_f;
   }
+  if (dyn + (size_t)a.dec.L.NT * 2048 + 64 > 65536) return DMV_E_UNSUPPORTED;
   DMV_DISPATCH_NT(a.dec.L.NT, launch_vae_bwd, a, dyn, (hipStream_t)stream);
 }

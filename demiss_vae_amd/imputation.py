@@ -200,6 +200,10 @@ def pseudo_gibbs(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_i
 
 
 # ------------------------------------------------------------------------------------------ LAIR
+# LAIR's resampling draws and sampling tail as one launch (dmv_lair_resample_tail) where its limits allow
+MERGE_RESAMPLE_TAIL = True
+
+
 @torch.no_grad()
 def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iterations=1, num_imp_samples=1,
          num_prior_replenish_proposals=0, resample_final_imps=False, clip_min=None, clip_max=None,
@@ -301,6 +305,27 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
             L.check(rc)
         # resampling: K + r draws per datapoint from Categorical(logits = log_w[b, (i k)]) (:181-186), of which the first
         # K are kept (:521-524); row_map = rows of the chosen proposals in the (i, b, k)-ordered decoder outputs
+        last = (t == T - 1) and not resample_final_imps
+        nz_t = noise_x[t] if noise_x is not None else None
+        buf_t = buf if last else None
+        idx_t = idx_imp.reshape(-1).contiguous() if (last and idx_imp is not None) else None
+        if idx is None and MERGE_RESAMPLE_TAIL and I * Kp <= 1024 and Kp <= 64:
+            # draws and sampling tail in one launch; the Philox ranges are taken in the order of the two launches below,
+            # so both ways produce the same imputations
+            seed, off = rng.next_offset(B * Kp)
+            X_new = torch.empty_like(Xc)
+            seed_t = off_t = 0
+            if nz_t is None:
+                seed_t, off_t = rng.next_offset(B * K * D)
+            else:
+                nz_t = nz_t.reshape(B * K, D).contiguous().float()
+            L.check(lib.dmv_lair_resample_tail(B, I, Kp, Kp, K, L.ptr(log_w), None, seed, off, D, L.GEN[dims.gen_dist],
+                                               L.ptr(dec_out), dec_out.shape[1], L.ptr(Xc), L.ptr(Mu), L.ptr(nz_t), seed_t, off_t,
+                                               rng.base_ptr(), L.ptr(cmin) if clip else None, L.ptr(cmax) if clip else None,
+                                               L.ptr(X_new), L.ptr(buf_t.data_imp) if buf_t is not None else None, L.ptr(idx_t),
+                                               None, st))
+            Xc = X_new
+            continue
         row_map = torch.empty(B * K, dtype=torch.int64, device=dev)
         if idx is not None:
             draw = idx[t].to(dev, torch.int64).t().contiguous()                 # [B, K+r]
@@ -309,10 +334,7 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
             seed, off = rng.next_offset(B * Kp)
             L.check(lib.dmv_categorical_draw_grouped(B, I, Kp, Kp, L.ptr(log_w), None, seed, off, rng.base_ptr(), None,
                                                      L.ptr(row_map), K, st))
-        last = (t == T - 1) and not resample_final_imps
-        Xc = _tail(dims, dec_out, row_map, Xc, Mu, noise_x[t] if noise_x is not None else None,
-                   cmin if clip else None, cmax if clip else None, True,
-                   buf if last else None, idx_imp.reshape(-1).contiguous() if (last and idx_imp is not None) else None)
+        Xc = _tail(dims, dec_out, row_map, Xc, Mu, nz_t, cmin if clip else None, cmax if clip else None, True, buf_t, idx_t)
     if resample_final_imps:
         # K latents per datapoint from the pooled T I (K+r) proposals of all iterations (:671-694), decoded once more
         rows_f = torch.empty(B * K, dtype=torch.int64, device=dev)

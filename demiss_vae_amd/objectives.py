@@ -365,15 +365,16 @@ FUSE_SMALL_BACKWARD = True     # tests switch it off to compare with the separat
 
 
 def _one_launch_backward(c, enc: PackedNet, dec: PackedNet, p: L.DmvLatentBwd, wgt_dec, base_m, base_f, wgt, zscale, kl_wgt,
-                         gb_dec, gb_lat, gscale, dec_param_grads: bool, complete: bool = False):
+                         gb_dec, gb_lat, gscale, dec_param_grads: bool, complete: bool = False, dlogit=None):
     """Decoder-side gradient, then the decoder's chain, the latent-side gradient and the encoder's chain in one launch
-    (dmv_vae_backward), then the weight gradients of both networks side by side on two streams.  For posteriors
-    without a mixture term on batches small enough for the 16-row kernels; returns (decoder parameter gradients or
-    None, encoder parameter gradients), or None when the library does not take the case."""
+    (dmv_vae_backward), then the weight gradients of both networks side by side on two streams.  On batches small enough
+    for the 16-row kernels whose tiles can hold a unit's samples; returns (decoder parameter gradients or None, encoder
+    parameter gradients), or None when the library does not take the case."""
     lib, st = L.lib(), L.stream_ptr()
-    if not FUSE_SMALL_BACKWARD or p.base_qmix != 0.0 or c.reparam:
+    if not FUSE_SMALL_BACKWARD or c.reparam:
         return None
-    if not lib.dmv_vae_backward_fits(C.byref(c.cfg), C.byref(enc.c), C.byref(dec.c)):
+    mixture = p.base_qmix != 0.0
+    if not lib.dmv_vae_backward_fits(C.byref(c.cfg), C.byref(enc.c), C.byref(dec.c), int(mixture)):
         return None
     dev = c.dec_out.device
     d_dec = torch.empty_like(c.dec_out)
@@ -394,7 +395,8 @@ def _one_launch_backward(c, enc: PackedNet, dec: PackedNet, p: L.DmvLatentBwd, w
         C.byref(c.cfg), C.byref(p), C.byref(dg) if dg is not None else None, C.byref(dec.c), L.ptr(dec.packed()), L.ptr(c.dec_saved), keep(c.dec_keep), L.ptr(d_dec),
         d_dec.shape[1], L.ptr(ws_dec), nb_dec, C.byref(enc.c), L.ptr(enc.packed()), L.ptr(c.enc_saved), keep(c.enc_keep),
         L.ptr(d_enc), L.ptr(ws_enc), nb_enc, L.ptr(c.enc_out), L.ptr(c.Z), L.ptr(c.eps), c.Z.shape[1], L.ptr(wgt), L.ptr(gb_lat),
-        L.ptr(zscale), L.ptr(kl_wgt), L.ptr(gscale), st))
+        L.ptr(zscale), L.ptr(kl_wgt), L.ptr(c.comp_lp) if mixture else None, L.ptr(c.terms[4]) if mixture else None,
+        L.ptr(dlogit), L.ptr(gscale), st))
     g_dec = None
     side = None
     if dec_param_grads:
@@ -512,9 +514,13 @@ class _FusedObjective(torch.autograd.Function):
 
         if k in ("iwae", "miwae") and any(g is not None for g in gouts):
             gb, gs, f = upstream(*gouts)
-            if c.q_kind == L.Q_OWN and not c.reparam:
-                p = _latent_params(prior=f, qown=-f, w=f, own_live=not (plan.STL or plan.DREG), use_zscale=plan.DREG)
-                one = _one_launch_backward(c, enc, dec, p, c.wgt, f, 0.0, c.wgt, c.zscale, None, gb, gb, gs, True, complete=True)
+            if not c.reparam:
+                if c.q_kind == L.Q_STRATIFIED:
+                    p = _latent_params(prior=f, qmix=-f, w=f, mix_live=not plan.STL, mix_kind=L.Q_STRATIFIED)
+                else:
+                    p = _latent_params(prior=f, qown=-f, w=f, own_live=not (plan.STL or plan.DREG), use_zscale=plan.DREG)
+                one = _one_launch_backward(c, enc, dec, p, c.wgt, f, 0.0, c.wgt, c.zscale, None, gb, gb, gs, True, complete=True,
+                                           dlogit=c.dlogit)
                 if one is not None:
                     return (None,) * 10 + tuple(one[1]) + tuple(one[0])
             pending = []
@@ -546,6 +552,10 @@ class _FusedObjective(torch.autograd.Function):
             _join(pending)
         elif k == "cvi" and gouts[0] is not None:
             wt = per_sample(gouts[0])
+            p = _latent_params(prior=1.0, qmix=-1.0, mix_live=not plan.STL, mix_kind=L.Q_IMPUTATION)
+            one = _one_launch_backward(c, enc, dec, p, wt, 1.0, 0.0, wt, None, None, None, None, None, True)
+            if one is not None:
+                return (None,) * 10 + tuple(one[1]) + tuple(one[0])
             pending = []
             dZ, g_dec_params = _dec_side(c, dec, wt, 1.0, 0.0, True, True, overlap=pending)
             p = _latent_params(prior=1.0, qmix=-1.0, mix_live=not plan.STL, mix_kind=L.Q_IMPUTATION)

@@ -289,10 +289,11 @@ int dmv_obj_backward_latent(const DmvObjCfg* cfg, const DmvLatentBwd* p, const f
  * (dmv_obj_backward_dec); d_enc [enc_rows][pad32(enc out_dim)] receives the gradient w.r.t. the encoder outputs (every
  * entry written); dec_ws / enc_ws (dmv_mlp_backward_ws_bytes each) receive the per-layer gradients, after which
  * dmv_mlp_backward_wgrad(dec, ..., d_dec, ..., dec_ws) and dmv_mlp_backward_wgrad(enc, ..., d_enc, ..., enc_ws) form the
- * weight gradients.  p, wgt, gb, zscale, kl_wgt, gscale as in dmv_obj_backward_latent; posteriors without a mixture
- * term only (p->base_qmix == 0), one Gaussian per encoder row (cfg->G == 1 or cfg->x_per_component == 1), at most 16
- * samples per encoder row (nz*I <= 16: a row's samples share a 16-row tile) and the shapes dmv_vae_forward takes:
- * dmv_vae_backward_fits tells (the mixture-term condition aside); otherwise DMV_E_UNSUPPORTED.
+ * weight gradients.  p, wgt, gb, zscale, kl_wgt, comp_lp, qmix, dlogit, gscale as in dmv_obj_backward_latent.  Without a
+ * mixture term (p->base_qmix == 0): one Gaussian per encoder row (cfg->G == 1 or cfg->x_per_component == 1) and at most
+ * 16 samples per encoder row (nz*I <= 16: a row's samples share a 16-row tile).  With one (stratified or imputation
+ * mixture, p->mix_kind): all nz*I*G sample rows of a datapoint share a tile (nz*I*G <= 16).  In both cases the shapes
+ * dmv_vae_forward takes: dmv_vae_backward_fits(cfg, enc, dec, mixture) tells; otherwise DMV_E_UNSUPPORTED.
  * dg (nullable): the arguments of dmv_obj_backward_dec; when given, the launch forms d_dec itself first (and writes it
  * out for the weight-gradient GEMMs) instead of reading it: one launch less.  Decoder output rows of up to a few
  * hundred floats (the tile's d_dec rows are staged in LDS); wider ones return DMV_E_UNSUPPORTED. */
@@ -305,14 +306,14 @@ typedef struct DmvDecGrad {
   const float* gb;         /* nullable [B] */
   float base_m, base_f;
 } DmvDecGrad;
-int dmv_vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec);
+int dmv_vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec, int32_t mixture);
 int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, const DmvDecGrad* dg, const DmvNet* dec,
                      const float* dec_packed, const float* dec_saved, const uint8_t* dec_drop_keep, float* d_dec, int64_t ld_ddec,
                      void* dec_ws, size_t dec_ws_bytes, const DmvNet* enc, const float* enc_packed,
                      const float* enc_saved, const uint8_t* enc_drop_keep, float* d_enc, void* enc_ws,
                      size_t enc_ws_bytes, const float* enc_out, const float* Z, const float* eps, int64_t ldz,
-                     const float* wgt, const float* gb, const float* zscale, const float* kl_wgt, const float* gscale,
-                     void* stream);
+                     const float* wgt, const float* gb, const float* zscale, const float* kl_wgt, const float* comp_lp,
+                     const float* qmix, const float* dlogit, const float* gscale, void* stream);
 
 /* Backward from per-term cotangents, for objectives composed by the caller out of the five terms of dmv_obj_terms
  * (the importance-weighted DeMissVAE family, vgiwae/models/mvbiwae.py:97-565, combines them in a dozen ways).
@@ -399,6 +400,19 @@ int dmv_categorical_draw(int32_t B, int32_t P, int32_t K, const float* logits, c
 int dmv_categorical_draw_grouped(int32_t B, int32_t groups, int32_t inner, int32_t K, const float* logits, const float* u,
                                  uint64_t seed, uint64_t offset, const uint64_t* offset_base, int64_t* idx, int64_t* rows,
                                  int32_t rows_keep, void* stream);
+
+/* LAIR's resampling and sampling tail in one launch (vgiwae/shared/vae_imputation.py:181-198, 521-561): per datapoint
+ * K_draws draws as dmv_categorical_draw_grouped (uniforms u or the Philox stream (draw_seed, draw_offset + b*K_draws + k)),
+ * the first K kept, then the K new imputation rows as dmv_impute_tail with clip_after_blend = 1 computes them from the
+ * picked proposals' decoder outputs (noise or (tail_seed, tail_offset + n*D + d); X_old, M, X_out [B*K][D]; optional
+ * write-back into buf).  rows (nullable) int64 [B][K] receives the picked rows.  Same values as the two launches.
+ * At most 1024 proposals per datapoint and 64 draws (DMV_E_UNSUPPORTED beyond: use the two launches). */
+int dmv_lair_resample_tail(int32_t B, int32_t groups, int32_t inner, int32_t K_draws, int32_t K, const float* logits,
+                           const float* u, uint64_t draw_seed, uint64_t draw_offset, int32_t D, int32_t gen_dist,
+                           const float* dec, int64_t ld_dec, const float* X_old, const uint8_t* M, const float* noise,
+                           uint64_t tail_seed, uint64_t tail_offset, const uint64_t* offset_base, const float* clip_min,
+                           const float* clip_max, float* X_out, float* buf, const int64_t* idx_imp, int64_t* rows,
+                           void* stream);
 
 /* Rows of the proposal table selected by the resampling draws (the gather of gr_resampling,
  * vgiwae/shared/vae_imputation.py:193-198, after keeping the first K draws, :521-524): draws int64 [B][Kp] hold proposal

@@ -62,6 +62,34 @@ def test_lair(name):
     torch.testing.assert_close(out.cpu(), torch.from_numpy(g["X_new"]), rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("final,clip", [(False, False), (True, True)])
+def test_lair_one_launch_resampling_equals_two_launches(final, clip):
+    """The merged resampling + sampling-tail launch takes the same Philox ranges and does the same arithmetic as the
+    draw launch followed by the tail launch: identical imputations, bit for bit, from the same generator state."""
+    from demiss_vae_amd import imputation as imp, rng
+    name = [n for n in gu.names("lair_")][0]
+    g = gu.load(name)
+    q = str(g["q_dist"])
+    spec, enc_p, dec_p = gu.model_case(dict(g, gen_dist=q, q_dist=q, mask_concat=False))
+    dims, enc, dec = _nets(spec, enc_p, dec_p)
+    X, M = torch.from_numpy(g["Xt"]).cuda(), torch.from_numpy(g["M"]).cuda()
+    D = X.shape[-1]
+    kw = dict(num_iterations=3, num_imp_samples=2, num_prior_replenish_proposals=1, resample_final_imps=final,
+              clip_min=torch.full((D,), -1.5) if clip else None, clip_max=torch.full((D,), 1.5) if clip else None)
+    outs = []
+    for merged in (True, False):
+        imp.MERGE_RESAMPLE_TAIL = merged
+        try:
+            rng.set_seed(4321)
+            outs.append(imp.lair(dims, enc, dec, X, M, **kw))
+        finally:
+            imp.MERGE_RESAMPLE_TAIL = True
+    assert torch.equal(outs[0], outs[1])
+    # observed entries come back unchanged (clamped with everything else where the reference clamps the blended tensor)
+    obs = X[M].clamp(-1.5, 1.5) if clip else X[M]
+    assert torch.equal(outs[0][M], obs) and not torch.equal(outs[0], X)
+
+
 def test_lair_device_draws_match_inverse_cdf():
     """Device categorical draws = inverse CDF of softmax(logits) at the given uniforms (oracle restatement)."""
     from demiss_vae_amd import _lib as L

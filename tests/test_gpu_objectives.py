@@ -539,7 +539,7 @@ def _saved_live(net, saved, rows):
 
 @pytest.mark.parametrize("case", [
     "iwae_stl", "iwae_dreg", "iwae_plain", "iwae_ragged_nz2", "elbo_analytic", "elbo_mc", "mvb2", "mvb2_mean", "mvb2_kl", "mvb",
-    "mvb_kl", "iwae_dropout"])
+    "mvb_kl", "iwae_dropout", "miwae_stl", "miwae_plain_i2", "miwae_looser", "mvae_plain", "cvi", "cvi_stl_nz2"])
 def test_one_launch_backward_equals_separate_launches(case):
     """dmv_vae_backward (decoder chain, latent-side gradient, encoder chain in one launch) against the three separate
     launches on the same forward buffers: every parameter gradient to 1e-5 of its tensor's largest entry (same terms in
@@ -550,6 +550,7 @@ def test_one_launch_backward_equals_separate_launches(case):
     from demiss_vae_amd import synth
     gas = ((16, 32, 2, 256), (16, 16, 2, 256))
     toy = ((5, 4, 3, 200), (2, 10, 3, 200))
+    hep = ((42, 165, 2, 256), (16, 42, 2, 256))          # stratified mixture of 5 in 16 latent dimensions
     shapes = {
         "iwae_stl": (512, 8, 16, 1, 5, 1, gas, dict(STL=True)),
         "iwae_dreg": (64, 8, 16, 1, 5, 1, gas, dict(DREG=True)),
@@ -563,12 +564,20 @@ def test_one_launch_backward_equals_separate_launches(case):
         "mvb2_kl": (20, 5, 2, 2, 1, 3, toy, dict()),
         "mvb": (33, 5, 2, 1, 1, 5, toy, dict()),
         "mvb_kl": (33, 5, 2, 1, 1, 5, toy, dict()),
+        "miwae_stl": (512, 21, 16, 1, 1, 5, hep, dict(STL=True)),
+        "miwae_plain_i2": (41, 21, 16, 1, 2, 5, hep, dict()),
+        "miwae_looser": (41, 21, 16, 1, 1, 5, hep, dict(looser=True)),
+        "mvae_plain": (41, 21, 16, 2, 1, 5, hep, dict()),
+        "cvi": (33, 5, 2, 1, 1, 5, toy, dict()),
+        "cvi_stl_nz2": (20, 5, 2, 2, 1, 3, toy, dict(STL=True)),
     }
     B, D, Zd, nz, I, K, (es, ds), kw = shapes[case]
     drop = 0.5 if case == "iwae_dropout" else 0.0
-    demiss = case.startswith("mvb")
+    demiss = case.startswith(("mvb", "cvi"))
+    strat = case.startswith(("miwae", "mvae"))
     mc = not demiss
-    dims = dmv.ModelDims(D=D, Zd=Zd, gen_dist="normal_with_eps", q_dist="normal_with_eps", encoder_use_mis_mask=mc)
+    dims = dmv.ModelDims(D=D, Zd=Zd, gen_dist="normal_with_eps", q_dist="stratified_with_eps" if strat else "normal_with_eps",
+                         C=K if strat else 1, encoder_use_mis_mask=mc)
     gen = torch.Generator().manual_seed(11)
     if demiss:
         X = torch.randn(B, K, D, generator=gen).cuda()
@@ -594,6 +603,16 @@ def test_one_launch_backward_equals_separate_launches(case):
             elif case.startswith("elbo"):
                 bound, _ = dmv.estimate_elbo(dims, enc, dec, X, M, num_latent_samples=nz, kl_analytic=case == "elbo_analytic")
                 (-bound).backward()
+            elif case.startswith("miwae"):
+                bound, _ = dmv.estimate_multiple_iwelbo(dims, enc, dec, X, M, num_latent_samples=nz,
+                                                        num_importance_samples_for_each_component=I, **kw)
+                (-bound).backward()
+            elif case.startswith("mvae"):
+                bound, _ = dmv.estimate_multiple_elbo(dims, enc, dec, X, M, num_latent_samples=nz)
+                (-bound).backward()
+            elif case.startswith("cvi"):
+                obj = O.cvi_objective(dims, enc, dec, X, M, num_latent_samples=nz, **kw)
+                (-obj.mean()).backward()
             elif case.startswith("mvb2"):
                 gobj, eobj = O.mvb2_objectives(dims, enc, dec, X, M, num_latent_samples=nz, kl_analytic=case == "mvb2_kl",
                                                reduce_mean=case == "mvb2_mean", **kw)
