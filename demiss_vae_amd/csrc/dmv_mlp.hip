@@ -800,7 +800,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_coop(FwdArgs a) {
   float* act_row = SAVE ? a.acts + row * Hp + 4 * h : nullptr;              // layer 0; + l * act_stride
   uint32_t* mask_row = SAVE ? a.masks + (row * 2 + h) * MW : nullptr;       // layer 0; + l * mask_stride
 
-  f32x16 A[NT], T[NT], acc[TW];
+  // F: the layer input every wave holds in full; res: this wave's slice of the residual stream, which is all of the
+  // stream a wave needs while F holds the block's inner activation (at hidden 512 two full states would not fit 512 registers)
+  f32x16 F[NT], res[TW], acc[TW];
   const uint64_t drop_q0 = (DROP && a.drop.mode == DROP_GEN) ? drop_first_call(a.drop) : 0ull;
 
   // ---- initial layer: this wave's output tiles from the (tiny) network input
@@ -828,21 +830,26 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_coop(FwdArgs a) {
     }
   }
   coop_relu_save<NT, SAVE>(acc, t0, act_row, mask_row);
-  coop_exchange<NT>(lds, lane, t0, acc, A);
+#pragma unroll
+  for (int i = 0; i < TW; ++i) res[i] = acc[i];
+  coop_exchange<NT>(lds, lane, t0, acc, F);
 
   // ---- residual blocks
   for (int blk = 0; blk < a.nb; ++blk) {
     const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
     uint32_t kb[MW];
     if (DROP) drop_words<NT>(a.drop, drop_q0, a.rows, a.hidden, blk, rl, h, t0, t0 + TW, kb);   // (independent of the GEMM)
-    coop_gemm<NT, true, true>((const f32x4*)(a.packed + a.L.w[l1]), a.packed + a.L.b[l1], lane, t0, A, acc);
+    coop_gemm<NT, true, true>((const f32x4*)(a.packed + a.L.w[l1]), a.packed + a.L.b[l1], lane, t0, F, acc);
     coop_relu_save<NT, SAVE, DROP>(acc, t0, act_row + l1 * act_stride, mask_row + l1 * mask_stride, kb, a.drop_scale);
-    coop_exchange<NT>(lds, lane, t0, acc, T);
-    // this wave's slice of the residual stream becomes the accumulator of the second GEMM
-    coop_own_slice<NT>(A, wv, acc);
-    coop_gemm<NT, false, true>((const f32x4*)(a.packed + a.L.w[l2]), a.packed + a.L.b[l2], lane, t0, T, acc);
+    coop_exchange<NT>(lds, lane, t0, acc, F);
+    // this wave's slice of the residual stream is the accumulator of the second GEMM
+#pragma unroll
+    for (int i = 0; i < TW; ++i) acc[i] = res[i];
+    coop_gemm<NT, false, true>((const f32x4*)(a.packed + a.L.w[l2]), a.packed + a.L.b[l2], lane, t0, F, acc);
     coop_relu_save<NT, SAVE>(acc, t0, act_row + l2 * act_stride, mask_row + l2 * mask_stride);
-    coop_exchange<NT>(lds, lane, t0, acc, A);
+#pragma unroll
+    for (int i = 0; i < TW; ++i) res[i] = acc[i];
+    coop_exchange<NT>(lds, lane, t0, acc, F);
   }
 
   // ---- final layer: output tiles round-robin over the waves
@@ -854,7 +861,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd_coop(FwdArgs a) {
     uint32_t nomask[MW];
     for (int ot = wv; ot < a.L.OT; ot += 4) {
       f32x16 o16 = MFMA(Bf[ot * 64 + lane], 1.f, zero16());
-      gemm_h1<NT, false, false, IN_ASIS>(W + (int64_t)ot * S * 64, lane, A, o16, nullptr, 0u, nullptr, nomask, 1.f);
+      gemm_h1<NT, false, false, IN_ASIS>(W + (int64_t)ot * S * 64, lane, F, o16, nullptr, 0u, nullptr, nomask, 1.f);
       if (live) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1069,7 +1076,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_coop(BwdArgs a) {
   const uint32_t* mask_row = a.masks + (row * 2 + h) * MW;
   const float dscale = a.drop_keep ? a.drop_scale : 1.f;
 
-  f32x16 dA[NT], dT[NT], acc[TW];
+  f32x16 F[NT], res[TW], acc[TW];   // as in the forward kernel: full layer input, own slice of the skip-path gradient
   // ---- this wave's tiles of Wf^T gy
   {
     const f32x4* W = (const f32x4*)(a.packed + a.L.wt[lf]);
@@ -1091,17 +1098,22 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_coop(BwdArgs a) {
     }
   }
   coop_mask_store<NT>(acc, t0, mask_row + (lf - 1) * mask_stride, 1.f, dact_row + (lf - 1) * act_stride);
-  coop_exchange<NT>(lds, lane, t0, acc, dA);
+#pragma unroll
+  for (int i = 0; i < TW; ++i) res[i] = acc[i];
+  coop_exchange<NT>(lds, lane, t0, acc, F);
 
   for (int blk = a.nb - 1; blk >= 0; --blk) {
     const int l1 = 1 + 2 * blk, l2 = 2 + 2 * blk;
-    coop_gemm<NT, true, false>((const f32x4*)(a.packed + a.L.wt[l2]), nullptr, lane, t0, dA, acc);
+    coop_gemm<NT, true, false>((const f32x4*)(a.packed + a.L.wt[l2]), nullptr, lane, t0, F, acc);
     coop_mask_store<NT>(acc, t0, mask_row + l1 * mask_stride, dscale, dact_row + l1 * act_stride);
-    coop_exchange<NT>(lds, lane, t0, acc, dT);
-    coop_own_slice<NT>(dA, wv, acc);                                        // skip path
-    coop_gemm<NT, false, false>((const f32x4*)(a.packed + a.L.wt[l1]), nullptr, lane, t0, dT, acc);
+    coop_exchange<NT>(lds, lane, t0, acc, F);
+#pragma unroll
+    for (int i = 0; i < TW; ++i) acc[i] = res[i];                           // skip path
+    coop_gemm<NT, false, false>((const f32x4*)(a.packed + a.L.wt[l1]), nullptr, lane, t0, F, acc);
     coop_mask_store<NT>(acc, t0, mask_row + (l1 - 1) * mask_stride, 1.f, dact_row + (l1 - 1) * act_stride);
-    coop_exchange<NT>(lds, lane, t0, acc, dA);
+#pragma unroll
+    for (int i = 0; i < TW; ++i) res[i] = acc[i];
+    coop_exchange<NT>(lds, lane, t0, acc, F);
   }
 
   if (a.dx) {
@@ -1110,7 +1122,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd_coop(BwdArgs a) {
     uint32_t nomask[MW];
     for (int it = wv; it < a.L.T_in; it += 4) {
       f32x16 o16 = zero16();
-      gemm_h1<NT, false, false, IN_ASIS>(W + (int64_t)it * S * 64, lane, dA, o16, nullptr, 0u, nullptr, nomask, 1.f);
+      gemm_h1<NT, false, false, IN_ASIS>(W + (int64_t)it * S * 64, lane, F, o16, nullptr, 0u, nullptr, nomask, 1.f);
       if (live) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -2165,17 +2177,19 @@ extern "C" size_t dmv_mlp_saved_floats(const DmvNet* net, int64_t rows) {
 enum { FAM_ONE = 0, FAM_COOP = 1, FAM_ROWS16 = 2 };
 struct RowSeg { int family; int64_t begin, end; };
 
-static int plan_row_segments(int64_t rows, RowSeg (&seg)[3]) {
+// wide (hidden above 256): no one-wave family, and every round costs proportionally more, so the same comparison of
+// four-wave rounds against a last round of sixteen-row tiles decides.
+static int plan_row_segments(int64_t rows, RowSeg (&seg)[3], bool wide = false) {
   int n = 0;
   if (dmv_use_rows16(rows)) { seg[n++] = RowSeg{FAM_ROWS16, 0, rows}; return n; }
   const int64_t tiles = (rows + 31) / 32;
-  const int64_t full = (tiles / 1024) * 1024;
+  const int64_t full = wide ? 0 : (tiles / 1024) * 1024;
   if (full) seg[n++] = RowSeg{FAM_ONE, 0, std::min<int64_t>(rows, full * 32)};
   const int64_t rest = tiles - full;
   if (rest == 0) return n;
   const int64_t b = full * 32;
   const int64_t coop_rounds = (rest + 255) / 256, tail = rest % 256;
-  const int64_t cost_one = 140, cost_coop = coop_rounds * 47;
+  const int64_t cost_one = wide ? INT64_MAX : 140, cost_coop = coop_rounds * 47;
   const int64_t cost_mixed = (tail > 0 && tail <= 128) ? (rest / 256) * 47 + 28 : INT64_MAX;
   if (cost_one <= cost_coop && cost_one <= cost_mixed) {
     if (n && seg[n - 1].family == FAM_ONE) seg[n - 1].end = rows;
@@ -2256,23 +2270,44 @@ static int launch_bwd(const BwdArgs& a0, hipStream_t st) {
 template <int NT>
 static int launch_fwd_wide(const FwdArgs& a0, hipStream_t st) {
   FwdArgs a = a0;
-  a.row_begin = 0; a.row_end = a.rows;
-  const unsigned tiles = (unsigned)((a.rows + 15) / 16);
   const bool drop = a.drop.mode != DROP_OFF;
-  if (a.acts && drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, true, 4>), dim3(tiles), dim3(256), 0, st, a);
-  else if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, false, 4>), dim3(tiles), dim3(256), 0, st, a);
-  else if (drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, true, 4>), dim3(tiles), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, false, 4>), dim3(tiles), dim3(256), 0, st, a);
-  DMV_HIP_CHECK_LAUNCH();
+  RowSeg seg[3];
+  int n = 1;
+  seg[0] = RowSeg{FAM_ROWS16, 0, a.rows};
+  if (!drop) n = plan_row_segments(a.rows, seg, true);     // (generated dropout: sixteen-row kernels at every batch size)
+  for (int i = 0; i < n; ++i) {
+    a.row_begin = seg[i].begin; a.row_end = seg[i].end;
+    const int64_t m = a.row_end - a.row_begin;
+    if (seg[i].family == FAM_COOP) {
+      const unsigned tiles = (unsigned)((m + 31) / 32);
+      if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_coop<NT, true, false>), dim3(tiles), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((k_mlp_fwd_coop<NT, false, false>), dim3(tiles), dim3(256), 0, st, a);
+    } else {
+      const unsigned tiles = (unsigned)((m + 15) / 16);
+      if (a.acts && drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, true, 4>), dim3(tiles), dim3(256), 0, st, a);
+      else if (a.acts) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, true, false, 4>), dim3(tiles), dim3(256), 0, st, a);
+      else if (drop) hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, true, 4>), dim3(tiles), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((k_mlp_fwd_rows16<NT, false, false, 4>), dim3(tiles), dim3(256), 0, st, a);
+    }
+    DMV_HIP_CHECK_LAUNCH();
+  }
   return DMV_OK;
 }
 
 template <int NT>
 static int launch_bwd_wide(const BwdArgs& a0, hipStream_t st) {
   BwdArgs a = a0;
-  a.row_begin = 0; a.row_end = a.rows;
-  hipLaunchKernelGGL((k_mlp_bwd_rows16<NT, 4>), dim3((unsigned)((a.rows + 15) / 16)), dim3(256), 0, st, a);
-  DMV_HIP_CHECK_LAUNCH();
+  RowSeg seg[3];
+  const int n = plan_row_segments(a.rows, seg, true);
+  for (int i = 0; i < n; ++i) {
+    a.row_begin = seg[i].begin; a.row_end = seg[i].end;
+    const int64_t m = a.row_end - a.row_begin;
+    if (seg[i].family == FAM_COOP)
+      hipLaunchKernelGGL((k_mlp_bwd_coop<NT>), dim3((unsigned)((m + 31) / 32)), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_mlp_bwd_rows16<NT, 4>), dim3((unsigned)((m + 15) / 16)), dim3(256), 0, st, a);
+    DMV_HIP_CHECK_LAUNCH();
+  }
   return DMV_OK;
 }
 
