@@ -613,6 +613,11 @@ extern "C" int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const f
     int nthr = pairs * a.S >= 256 * 512 ? 256 : 64;       // small batches: more, smaller workgroups
     int DPB = nthr / SG;
     if (DPB < 1) { nthr = 256; DPB = 256 / SG; }
+    // a mixture posterior on a batch that does not fill the chip anyway: a workgroup's time is its chain of component
+    // table, rows (every component per row) and logsumexp, which shortens with the datapoints it holds, so they are
+    // spread over up to 256 workgroups (idle lanes cost nothing here; LAIR's weights at B = 512, 6 components: 18 -> 11 us.
+    // Without a mixture the rows are short and the spread gains nothing: 14.0 against 14.7 us)
+    if (nthr == 64 && f->q_kind != DMV_Q_OWN) { const int want = (cfg->B + 255) / 256; if (DPB > want) DPB = want; }
     while (DPB > 1 && rows_lds(DPB) > lds_max) --DPB;
     if (rows_lds(DPB) <= lds_max) {
       a.DPB = DPB; a.nC = nC_full;

@@ -31,6 +31,22 @@ elif what == "uci":
     from demiss_vae_amd.bench_extra import demiss_toy_step
     step, refresh, (enc, dec) = demiss_toy_step(torch.device("cuda"), B=512, K=5, parts=True, uci=True)
     B = 512
+elif what == "wide":
+    # synthetic hidden-512 pair with 784-dimensional Bernoulli data (not a reference configuration), MissIWAE I = 5, B = 4096
+    from demiss_vae_amd import synth
+    B, D, Zd = 4096, 784, 50
+    enc = synth.packed_net(synth.NetShape(784, 100, 2, 512), 1, "cuda")
+    dec = synth.packed_net(synth.NetShape(50, 784, 2, 512), 2, "cuda")
+    dims = dmv.ModelDims(D=D, Zd=Zd, gen_dist="bern", encoder_use_mis_mask=False)
+    X, M = (t.cuda() for t in synth.batch(3, B, D))
+    X = (X > 1.1).float()
+    opt = Adam(enc.params() + dec.params(), lr=1e-3, amsgrad=True).attach_images((enc, dec))
+
+    def step():
+        _, _, loss = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_importance_samples=K, STL=True, with_loss=True)
+        opt.zero_grad(set_to_none=True)
+        loss.backward(unit_gradient(loss))
+        opt.step()
 elif what in ("hepmass", "miniboone"):
     # MissSIWAE (stratified mixture of 5, one sample per component): configs/uci_hepmass, configs/uci_miniboone shapes
     from demiss_vae_amd import synth
