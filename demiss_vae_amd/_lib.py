@@ -96,6 +96,9 @@ SIGNATURES = {
     "dmv_vae_forward_fits": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), C.POINTER(DmvNet)]),
     "dmv_vae_forward": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), _P, _I32, _P, _P, C.POINTER(DmvNet), _P, _P, _U64, _U64,
                                   _P, _I32, _F, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "dmv_lair_update_fits": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "dmv_lair_update": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_float, _I32, _P, _P, _P,
+                                  _P, _P, _P, _U64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmv_lair_resample_tail": (C.c_int, [_I32, _I32, _I32, _I32, _I32, _P, _P, _U64, _U64, _I32, _I32, _P, _I64, _P, _P, _P, _U64, _U64,
                                          _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmv_categorical_draw_grouped": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _U64, _U64, _P, _P, _P, _I32, _P]),

@@ -17,6 +17,7 @@
 #include "dmv_common.h"
 #include "dmv_rng.h"
 #include "dmv_objmath.h"
+#include "dmv_tail.h"
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -1494,6 +1495,233 @@ __global__ __launch_bounds__(256, 1) void k_vae_fwd_rows16(VaeFwdArgs a) {
       [&](int ot, f32x4 o) { if (live) *(f32x4*)(a.dec.y + n * a.dec.ldy + 16 * ot + 4 * g) = o; });
 }
 
+// ------------------------------------------------------------------------------------------
+// LAIR's whole imputation update in one launch (vgiwae/shared/vae_imputation.py:390-563: encoder on the current
+// imputations, proposals z ~ q(. | x_k) plus standard-normal replenish proposals, decoder, DMIS log-weights against the
+// uniform mixture of the datapoint's components (shared/iwae.py:57-100), global multinomial resampling (:181-198), new
+// imputations from the chosen proposals (:521-561); and :671-694, the final resampling from the pooled proposals of all
+// iterations with one more decoder pass).  Nothing in the update couples two datapoints, so a workgroup owns DP = 16 / Kp
+// datapoints - their Kp = K + r proposals are the rows of one 16-row tile - and walks them through all T iterations:
+// encoder outputs, latents, decoder outputs, log-weights and the proposals kept for the final resampling never leave
+// LDS; only the imputations themselves are updated in global memory (in place, read back by the same workgroup after a
+// barrier).  One importance sample per component (I = 1, what every shipped configuration uses).
+// Noise: explicit arrays (parity with recorded draws) or the Philox ranges the separate launches would take, handed
+// over per iteration, so both ways consume the same stream.
+// ------------------------------------------------------------------------------------------
+#define DMV_LAIR_MAX_T 32
+struct LairArgs {
+  FwdArgs enc, dec;           // enc.x = the imputations X [B K][D] (updated in place), enc.m = their masks; y unused
+  int B, K, Kp, Zd, D, T, DP;
+  int gen_dist, final_resample;
+  float prior_raw, q_eps;
+  int raw_off;                // where the raw sigma starts in an encoder output row
+  int ZP, ldE, ldD;
+  uint64_t seed;
+  uint64_t off_eps[DMV_LAIR_MAX_T], off_draw[DMV_LAIR_MAX_T + 1], off_tail[DMV_LAIR_MAX_T + 1];
+  const uint64_t* offset_base;
+  const float* eps;           // nullable [T][B Kp][Zd]
+  const int64_t* draws;       // nullable [T][B][Kp]: proposal numbers chosen by the resampling
+  const int64_t* final_draws; // nullable [B][K]: pooled proposal numbers t Kp + c
+  const float* noise;         // nullable [T (+1)][B K][D]
+  const uint8_t* M;           // [B K][D]
+  float* X;                   // [B K][D]
+  const float* clip_min; const float* clip_max;
+  float* buf; const int64_t* idx_imp;
+  float* lw_out;              // nullable [T][B][Kp]: the log-weights of every iteration (checks)
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k_lair_rows16(LairArgs a) {
+  constexpr int W = 4;
+  __shared__ __attribute__((aligned(16))) float lds[Rows16<NT, W>::LDS_BYTES / 4];
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int ldE = a.ldE, ldD = a.ldD, ZP = a.ZP, Zd = a.Zd, Kp = a.Kp, K = a.K, D = a.D;
+  const int PW = Kp + 2;                         // per row: Kp component log densities, log p(x_o | z), log p(z)
+  float* et = tile;                              // [16][ldE] encoder outputs
+  float* zt = et + 16 * ldE;                     // [16][ZP] proposals (the decoder's input)
+  float* dt = zt + 16 * ZP;                      // [16][ldD] decoder outputs
+  QEntry* qt = (QEntry*)(dt + 16 * ldD);         // [16][Zd] the components' Gaussians
+  float* part = (float*)(qt + 16 * Zd);          // [16][PW]
+  float* lw = part + ((16 * PW + 3) & ~3);       // [16] log-weights of this iteration
+  int* pick = (int*)(lw + 16);                   // [16] tile row (or pooled row) chosen for output row (dp, k)
+  float* lwall = (float*)(pick + 16);            // [T][16]       final resampling only
+  float* zall = lwall + 16 * a.T;                // [T][16][Zd]   final resampling only
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int b0 = blockIdx.x * a.DP;
+  const int nb = min(a.DP, a.B - b0);
+  const int live_rows = a.DP * Kp;               // tile rows that map to a proposal (those of datapoints past the batch
+                                                 // repeat the tile's first datapoint; their results are never used)
+  // this lane's tile row as a proposal, and the encoder row it draws from (a replenish proposal has none: it rides
+  // along on a neighbour's and ignores the result)
+  const int dpm = m / Kp, km = m - dpm * Kp;
+  const int64_t er = (int64_t)(b0 + (dpm < nb ? dpm : 0)) * K + (km < K ? km : K - 1);
+  const uint64_t base = a.offset_base ? a.offset_base[0] : 0ull;
+  const int64_t NZ = (int64_t)a.B * Kp, NX = (int64_t)a.B * K;
+  const bool normal = a.gen_dist <= DMV_GEN_NORMAL_EPS;
+  const float geps = a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f;
+  TailArgs ta;
+  ta.D = D; ta.gen_dist = a.gen_dist; ta.clip_min = a.clip_min; ta.clip_max = a.clip_max; ta.clip_after_blend = 1;
+
+  auto decode = [&]() {
+    r16_forward_chain<NT, false, false, W>(
+        a.dec, lds, lane, wv, 0, 0, false, [&](int k0) { return *(const f32x4*)(zt + m * ZP + k0); },
+        [&](int ot, f32x4 o) { *(f32x4*)(dt + m * ldD + 16 * ot + 4 * g) = o; });
+    __syncthreads();
+  };
+  // new imputations of the tile's datapoints from the decoder rows pick[] names, noise set `tn`
+  auto tail = [&](const TailArgs& tt, int tn, bool write_buf) {
+    const int per_dp = K * D;
+    for (int e = tid; e < nb * per_dp; e += 256) {
+      const int dp2 = e / per_dp, rem = e - dp2 * per_dp;
+      const int k2 = rem / D, d = rem - k2 * D;
+      const int64_t n = (int64_t)(b0 + dp2) * K + k2;
+      const int64_t i = n * D + d;
+      const float* dec = dt + pick[dp2 * K + k2] * ldD;
+      const float nz = a.noise ? a.noise[(int64_t)tn * NX * D + i]
+                               : normal ? dmv_philox_normal(a.seed, a.off_tail[tn] + base + (uint64_t)i)
+                                        : dmv_philox_uniform(a.seed, a.off_tail[tn] + base + (uint64_t)i);
+      const float out = tail_element(tt, dec, d, nz, a.X[i], a.M[i] != 0);
+      a.X[i] = out;
+      if (write_buf && a.buf) a.buf[a.idx_imp[n] * D + d] = out;
+    }
+  };
+  // inverse-CDF draw from softmax of P log-weights l(p), p = 0 .. P-1 (the order of dmv_categorical_draw)
+  auto draw = [&](int P, float u, auto l) {
+    float mx = -INFINITY;
+    for (int p = 0; p < P; ++p) mx = fmaxf(mx, l(p));
+    float se = 0.f;
+    for (int p = 0; p < P; ++p) se += expf(l(p) - mx);
+    const float target = u * se;
+    float c = 0.f;
+    for (int p = 0; p < P; ++p) {
+      c += expf(l(p) - mx);
+      if (c > target) return p;
+    }
+    return P - 1;
+  };
+
+  for (int t = 0; t < a.T; ++t) {
+    // ---- encoder on the current imputations
+    r16_forward_chain<NT, false, false, W>(
+        a.enc, lds, lane, wv, er, er, false, [&](int k0) { return first_layer_input4(a.enc, er, k0); },
+        [&](int ot, f32x4 o) { *(f32x4*)(et + m * ldE + 16 * ot + 4 * g) = o; });
+    __syncthreads();
+    // ---- proposals z = mu + sigma eps and the table of the components' Gaussians
+    for (int idx = tid; idx < 16 * ZP; idx += 256) {
+      const int mm = idx / ZP, j = idx - mm * ZP;
+      float z = 0.f;
+      if (j < Zd) {
+        const int dp2 = mm / Kp, k2 = mm - dp2 * Kp;
+        const bool pri = k2 >= K;
+        const float mu = pri ? 0.f : et[mm * ldE + j];
+        const float sg = dmv_softplus(pri ? a.prior_raw : et[mm * ldE + a.raw_off + j]) + a.q_eps;
+        const int64_t i = ((int64_t)(b0 + (dp2 < nb ? dp2 : 0)) * Kp + k2) * Zd + j;
+        const float e = a.eps ? a.eps[(int64_t)t * NZ * Zd + i] : dmv_philox_normal(a.seed, a.off_eps[t] + base + (uint64_t)i);
+        z = mu + sg * e;
+        const float rs = __builtin_amdgcn_rcpf(sg);
+        qt[mm * Zd + j] = QEntry{mu, 0.5f * rs * rs, dmv_log(sg) + LOG_SQRT_2PI, 0.f};
+        if (a.final_resample) zall[((size_t)t * 16 + mm) * Zd + j] = z;
+      }
+      zt[mm * ZP + j] = z;
+    }
+    __syncthreads();
+    decode();
+    // ---- DMIS log-weights: log p(x_o | z) + log p(z) - log (1 / Kp) sum_c q_c(z), the observed entries under the mask of
+    // the datapoint's first imputation (:407) and that imputation's values
+    if (tid < 16 * PW) {
+      const int p = tid / PW, c = tid - p * PW;
+      float v = 0.f;
+      if (p < live_rows) {
+        const int dp2 = p / Kp;
+        const float* z = zt + p * ZP;
+        if (c < Kp) {
+          const QEntry* q = qt + (dp2 * Kp + c) * Zd;
+          for (int j = 0; j < Zd; ++j) v += q_logp(q[j], z[j]);
+        } else if (c == Kp) {
+          const int64_t r0 = (int64_t)(b0 + (dp2 < nb ? dp2 : 0)) * K * D;
+          const float* x0 = a.X + r0;
+          const uint8_t* m0 = a.M + r0;
+          const float* dec = dt + p * ldD;
+          for (int d = 0; d < D; ++d) {
+            const float x = x0[d];
+            float lp;
+            if (normal) lp = log_normal_r(x, dec[d], dmv_softplus(dec[D + d]) + geps);
+            else if (a.gen_dist == DMV_GEN_BERN) lp = log_bern(x, dec[d]);
+            else lp = log_bern((x + 1.f) * 0.5f, dec[d]);
+            v += lp * (m0[d] ? 1.f : 0.f);       // (the product the reference forms: non-finite under a missing entry -> NaN)
+          }
+        } else {
+          for (int j = 0; j < Zd; ++j) { const float zj = z[j]; v += -(zj * zj) * 0.5f - LOG_SQRT_2PI; }
+        }
+      }
+      part[p * PW + c] = v;
+    }
+    __syncthreads();
+    if (tid < live_rows) {
+      const float* pp = part + tid * PW;
+      float mx = -INFINITY, se = 0.f;
+      for (int c = 0; c < Kp; ++c) {
+        const float tt = pp[c], nm = fmaxf(mx, tt);
+        se = se * dmv_exp(mx - nm) + dmv_exp(tt - nm);
+        mx = nm;
+      }
+      const float w = pp[Kp] + pp[Kp + 1] - (mx + dmv_log(se) - dmv_log((float)Kp));
+      lw[tid] = w;
+      if (a.final_resample) lwall[t * 16 + tid] = w;
+      const int dp2 = tid / Kp;
+      if (a.lw_out && dp2 < nb) a.lw_out[((int64_t)t * a.B + b0 + dp2) * Kp + (tid - dp2 * Kp)] = w;
+    }
+    __syncthreads();
+    // ---- resampling: of the Kp draws per datapoint the first K are kept (:521-524)
+    if (tid < nb * K) {
+      const int dp2 = tid / K, kd = tid - dp2 * K;
+      const int64_t b2 = b0 + dp2;
+      int pk;
+      if (a.draws) {
+        pk = (int)a.draws[((int64_t)t * a.B + b2) * Kp + kd];
+      } else {
+        const float u = dmv_philox_uniform(a.seed, a.off_draw[t] + base + (uint64_t)(b2 * Kp + kd));
+        const float* l = lw + dp2 * Kp;
+        pk = draw(Kp, u, [&](int p) { return l[p]; });
+      }
+      pick[tid] = dp2 * Kp + pk;
+    }
+    __syncthreads();
+    tail(ta, t, t == a.T - 1 && !a.final_resample);
+    __syncthreads();                              // the next encoder pass reads the new imputations
+  }
+
+  if (a.final_resample) {
+    // ---- K latents per datapoint from the pooled T Kp proposals, decoded once more; no clamping (:657-666)
+    if (tid < nb * K) {
+      const int dp2 = tid / K, k2 = tid - dp2 * K;
+      const int64_t b2 = b0 + dp2;
+      int v;
+      if (a.final_draws) {
+        v = (int)a.final_draws[b2 * K + k2];
+      } else {
+        const float u = dmv_philox_uniform(a.seed, a.off_draw[a.T] + base + (uint64_t)(b2 * K + k2));
+        v = draw(a.T * Kp, u, [&](int p) { const int tt = p / Kp; return lwall[tt * 16 + dp2 * Kp + (p - tt * Kp)]; });
+      }
+      const int tt = v / Kp;
+      pick[tid] = tt * 16 + dp2 * Kp + (v - tt * Kp);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 16 * ZP; idx += 256) {
+      const int mm = idx / ZP, j = idx - mm * ZP;
+      zt[mm * ZP + j] = (mm < nb * K && j < Zd) ? zall[(size_t)pick[mm] * Zd + j] : 0.f;
+    }
+    __syncthreads();
+    if (tid < 16) pick[tid] = tid;                // output row (dp, k) decodes in tile row dp K + k
+    decode();                                     // (its leading barriers order the pick update after the gather)
+    TailArgs tf = ta;
+    tf.clip_min = nullptr; tf.clip_max = nullptr; tf.clip_after_blend = 0;
+    tail(tf, a.T, true);
+  }
+}
+
 // relu backward on a slice (sign bits of that layer's saved activation), then its columns of the layer-gradient buffer
 template <int NT, int W>
 __device__ __forceinline__ void r16_mask_store(R16Slice<NT, W>& slice, int lane, int t0, const uint32_t* mask_line,
@@ -2527,6 +2755,90 @@ extern "C" int dmv_vae_forward(const DmvObjCfg* cfg, const DmvNet* enc, const fl
   a.ZP = 16 * dmv_ceil_div(cfg->Zd, 16);
   const size_t dyn = sizeof(float) * 16 * ((size_t)ldE + (size_t)a.ZP);
   DMV_DISPATCH_NT(a.enc.L.NT, launch_vae_fwd, a, dyn, (hipStream_t)stream);
+}
+
+// ---- LAIR's imputation update in one launch
+template <int NT>
+static int launch_lair(const LairArgs& a, size_t dyn_bytes, hipStream_t st) {
+  static_assert(sizeof(LairArgs) <= 4096, "kernel arguments");
+  const unsigned tiles = (unsigned)((a.B + a.DP - 1) / a.DP);
+  hipLaunchKernelGGL((k_lair_rows16<NT>), dim3(tiles), dim3(256), dyn_bytes, st, a);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
+}
+
+static size_t lair_dyn_bytes(const DmvNet* enc, const DmvNet* dec, int Kp, int Zd, int T, int final_resample) {
+  const size_t ldE = (size_t)dmv_pad32(enc->out_dim), ldD = (size_t)dmv_pad32(dec->out_dim), ZP = 16 * (size_t)dmv_ceil_div(Zd, 16);
+  size_t fl = 16 * (ldE + ZP + ldD) + 16 * (size_t)Zd * 4 + ((16 * (size_t)(Kp + 2) + 3) & ~(size_t)3) + 16 + 16;
+  fl += 16 * (size_t)T;                                       // (the pooled log-weights' slot exists either way)
+  if (final_resample) fl += 16 * (size_t)T * Zd;
+  return fl * sizeof(float);
+}
+
+static bool lair_fits(const DmvNet* enc, const DmvNet* dec, int B, int K, int n_prior, int T, int D, int Zd, int final_resample) {
+  if (dmv_check_net(enc) != DMV_OK || dmv_check_net(dec) != DMV_OK) return false;
+  if (B < 1 || K < 1 || n_prior < 0 || T < 1 || D < 1 || Zd < 1) return false;
+  if (K + n_prior > 16 || T > DMV_LAIR_MAX_T) return false;   // a datapoint's proposals are rows of one 16-row tile
+  if (enc->act != DMV_ACT_RELU || dec->act != DMV_ACT_RELU) return false;
+  const int NTe = dmv_ceil_div(enc->hidden, 32), NTd = dmv_ceil_div(dec->hidden, 32);
+  if (NTe != NTd || NTe > 8) return false;
+  if (dec->in_dim != Zd || enc->out_dim < 2 * Zd || Zd > 256) return false;
+  return lair_dyn_bytes(enc, dec, K + n_prior, Zd, T, final_resample) + (size_t)NTe * 2048 + 64 <= 65536;
+}
+
+extern "C" int dmv_lair_update_fits(const DmvNet* enc, const DmvNet* dec, int32_t B, int32_t K, int32_t n_prior, int32_t T,
+                                    int32_t D, int32_t Zd, int32_t final_resample) {
+  return lair_fits(enc, dec, B, K, n_prior, T, D, Zd, final_resample) ? 1 : 0;
+}
+
+extern "C" int dmv_lair_update(const DmvNet* enc, const float* enc_packed, int32_t in_mode, const DmvNet* dec,
+                               const float* dec_packed, int32_t B, int32_t K, int32_t n_prior, int32_t T, int32_t D, int32_t Zd,
+                               int32_t gen_dist, int32_t q_eps, float prior_raw, int32_t final_resample, float* X,
+                               const uint8_t* M, const float* eps, const int64_t* draws, const int64_t* final_draws,
+                               const float* noise, uint64_t seed, const uint64_t* off_eps, const uint64_t* off_draw,
+                               const uint64_t* off_tail, const uint64_t* offset_base, const float* clip_min,
+                               const float* clip_max, float* buf, const int64_t* idx_imp, float* lw_out, void* stream) {
+  if (!lair_fits(enc, dec, B, K, n_prior, T, D, Zd, final_resample)) return DMV_E_UNSUPPORTED;
+  if (!enc_packed || !dec_packed || !X || !M || (buf && !idx_imp)) return DMV_E_BADARG;
+  if (gen_dist < DMV_GEN_NORMAL || gen_dist > DMV_GEN_BERN_M1P1) return DMV_E_UNSUPPORTED;
+  if (in_mode < DMV_IN_PLAIN || in_mode > DMV_IN_CONCAT_MASKED) return DMV_E_UNSUPPORTED;
+  if (((in_mode >= DMV_IN_CONCAT) ? 2 * D : D) != enc->in_dim) return DMV_E_BADARG;
+  if (dec->out_dim != (gen_dist <= DMV_GEN_NORMAL_EPS ? 2 * D : D)) return DMV_E_BADARG;
+  const bool philox = !eps || !draws || !noise || (final_resample && !final_draws);
+  if (philox && (!off_eps || !off_draw || !off_tail)) return DMV_E_BADARG;
+  LairArgs a;
+  auto fill = [](FwdArgs& f, const DmvNet* net, const float* packed, int64_t rows) {
+    f.drop.mode = DROP_OFF; f.drop.bits = 0; f.drop.thresh = 0; f.drop.keep = nullptr; f.drop.seed = 0; f.drop.q0 = 0;
+    f.drop.offset_base = nullptr;
+    f.L = dmv_layout(net);
+    f.packed = packed;
+    f.nb = net->nb; f.in_dim = net->in_dim; f.hidden = net->hidden; f.act = net->act;
+    f.drop_scale = 1.f;
+    f.rows = rows; f.row_begin = 0; f.row_end = rows;
+    f.y = nullptr; f.ldy = dmv_pad32(net->out_dim);
+    f.xs = nullptr; f.acts = nullptr; f.masks = nullptr;
+  };
+  const int Kp = K + n_prior;
+  fill(a.enc, enc, enc_packed, (int64_t)B * K);
+  a.enc.in_mode = in_mode; a.enc.D = D; a.enc.x = X; a.enc.ldx = D; a.enc.m = M; a.enc.ldm = D;
+  fill(a.dec, dec, dec_packed, (int64_t)B * Kp);
+  a.dec.in_mode = DMV_IN_PLAIN; a.dec.D = Zd; a.dec.x = nullptr; a.dec.ldx = 0; a.dec.m = nullptr; a.dec.ldm = 0;
+  a.B = B; a.K = K; a.Kp = Kp; a.Zd = Zd; a.D = D; a.T = T; a.DP = 16 / Kp;
+  a.gen_dist = gen_dist; a.final_resample = final_resample ? 1 : 0;
+  a.prior_raw = prior_raw; a.q_eps = q_eps ? DMV_EPSILON : 0.f; a.raw_off = Zd;
+  a.ZP = 16 * dmv_ceil_div(Zd, 16); a.ldE = dmv_pad32(enc->out_dim); a.ldD = dmv_pad32(dec->out_dim);
+  a.seed = seed;
+  for (int t = 0; t <= DMV_LAIR_MAX_T; ++t) {
+    if (t < DMV_LAIR_MAX_T) a.off_eps[t] = (off_eps && t < T) ? off_eps[t] : 0;
+    a.off_draw[t] = (off_draw && t <= T) ? off_draw[t] : 0;
+    a.off_tail[t] = (off_tail && t <= T) ? off_tail[t] : 0;
+  }
+  a.offset_base = offset_base;
+  a.eps = eps; a.draws = draws; a.final_draws = final_draws; a.noise = noise;
+  a.M = M; a.X = X; a.clip_min = clip_min; a.clip_max = clip_max; a.buf = buf; a.idx_imp = idx_imp;
+  a.lw_out = lw_out;
+  const size_t dyn = lair_dyn_bytes(enc, dec, Kp, Zd, T, final_resample);
+  DMV_DISPATCH_NT(a.enc.L.NT, launch_lair, a, dyn, (hipStream_t)stream);
 }
 
 // ---- backward host side

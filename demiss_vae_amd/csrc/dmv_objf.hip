@@ -45,22 +45,6 @@ struct FwdArgs {
   float* mean1; float* mean2; float* neg1;
 };
 
-// log N(x; mu, sigma) with the division replaced by a reciprocal (1 ulp): -((x - mu) / sigma)^2 / 2 - log sigma - c
-__device__ __forceinline__ float log_normal_r(float x, float mu, float sigma) {
-  const float d = (x - mu) * __builtin_amdgcn_rcpf(sigma);
-  return -0.5f * d * d - dmv_log(sigma) - LOG_SQRT_2PI;
-}
-
-// One entry of the LDS table of q's parameters: log N(z; mu, sigma) = -(z - mu)^2 * inv2s2 - lnorm.  The softplus, the
-// logarithm and the reciprocal are paid once per (datapoint, component, dimension) of the workgroup instead of once
-// per sample row that evaluates the component.
-struct __attribute__((aligned(16))) QEntry { float mu, inv2s2, lnorm, pad; };
-
-__device__ __forceinline__ float q_logp(const QEntry& e, float z) {
-  const float d = z - e.mu;
-  return -(d * d) * e.inv2s2 - e.lnorm;
-}
-
 // Sum of an array over the threads of a workgroup, thread t taking elements t, t + nthr, ... (16-byte loads, four in
 // flight per thread): fixed summation order for a given workgroup size, so results are reproducible bit for bit.
 __device__ __forceinline__ float sum_strided(const float* __restrict__ v, int64_t n) {

@@ -200,6 +200,10 @@ def pseudo_gibbs(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_i
 
 
 # ------------------------------------------------------------------------------------------ LAIR
+# LAIR's whole update as one launch (dmv_lair_update) where its limits allow
+ONE_LAUNCH_LAIR = True
+# a dict here makes lair() leave every iteration's log-weights in it ("log_w": [T, I B (K + r)]); tests only
+LAIR_DEBUG = None
 # LAIR's resampling draws and sampling tail as one launch (dmv_lair_resample_tail) where its limits allow
 MERGE_RESAMPLE_TAIL = True
 
@@ -229,8 +233,10 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
     # The log-weights sum log p(x_d | z) over OBSERVED entries only, under the mask of a datapoint's first imputation
     # broadcast over the others (vgiwae/shared/vae_imputation.py:407, "M is a repeated tensor"): the observed values are
     # the same in all of a datapoint's imputations, so one [B, D] pair serves every component, prior proposals included
-    # (the reference builds a [B, K + r, D] copy for them, :439-441), in every iteration.
+    # (the reference builds a [B, K + r, D] copy for them, :439-441).  Clamping after the blend (:545-561) also clamps
+    # observed values that lie outside the range, so with clamping the pair is taken afresh from the current imputations.
     X0, M0 = Xc[:, 0].contiguous(), Mu[:, 0].contiguous()
+    lw_dbg = [] if LAIR_DEBUG is not None else None
     ldE = pad32(enc.dims.out_dim) if isinstance(enc, PackedNet) else None
     # prior components: mu = 0, sigma = 1 (:419-441), as rows of the encoder-output array [B, K + r, ld]; constant
     prior_raw = float(softplus_inverse(torch.tensor(1.0 - (1e-5 if dims.q_eps else 0.0), dtype=torch.float32)))
@@ -243,17 +249,66 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
             buf_[:, K:, Zd:2 * Zd] = prior_raw
         return buf_
 
+    in_mode = L.IN_CONCAT if dims.encoder_use_mis_mask else L.IN_PLAIN
+    # ---- the whole update in one launch where the shapes allow (one importance sample per component, relu networks of
+    # equal width, K + r <= 16, no dropout to draw): a workgroup walks its datapoints through all iterations with
+    # everything but the imputations in LDS
+    if (ONE_LAUNCH_LAIR and I == 1 and isinstance(enc, PackedNet) and isinstance(dec, PackedNet) and
+            not (training and ((enc.dims.dropout > 0 and enc.dims.nb > 0) or (dec.dims.dropout > 0 and dec.dims.nb > 0))) and
+            lib.dmv_lair_update_fits(C.byref(enc.c), C.byref(dec.c), B, K, r, T, D, Zd, 1 if resample_final_imps else 0)):
+        Xw = Xc.clone().view(B * K, D)
+        Mw = Mu.reshape(B * K, D).contiguous()
+        lw_dbg = torch.empty((T, B * Kp), dtype=torch.float32, device=dev) if LAIR_DEBUG is not None else None
+        e_all = (torch.stack([e.reshape(B * Kp, Zd) for e in eps_z[:T]]).contiguous().float().to(dev)
+                 if eps_z is not None else None)
+        d_all = f_draw = None
+        if idx is not None:
+            d_all = torch.stack([idx[t].to(dev, torch.int64).t() for t in range(T)]).contiguous()          # [T, B, K+r]
+            if resample_final_imps:
+                f_draw = idx[T].to(dev, torch.int64).t().contiguous()                                     # [B, K]
+        nT = T + (1 if resample_final_imps else 0)
+        n_all = (torch.stack([x.reshape(B * K, D) for x in noise_x[:nT]]).contiguous().float().to(dev)
+                 if noise_x is not None else None)
+        # the Philox ranges of the separate launches, in their order: per iteration proposals, draws, tail; then the final
+        # draws and tail
+        off_e, off_d, off_t = (C.c_uint64 * T)(), (C.c_uint64 * (T + 1))(), (C.c_uint64 * (T + 1))()
+        seed = 0
+        for t in range(T):
+            if e_all is None:
+                seed, off_e[t] = rng.next_offset(B * Kp * Zd)
+            if d_all is None:
+                seed, off_d[t] = rng.next_offset(B * Kp)
+            if n_all is None:
+                seed, off_t[t] = rng.next_offset(B * K * D)
+        if resample_final_imps:
+            if f_draw is None:
+                seed, off_d[T] = rng.next_offset(B * K)
+            if n_all is None:
+                seed, off_t[T] = rng.next_offset(B * K * D)
+        L.check(lib.dmv_lair_update(C.byref(enc.c), L.ptr(enc.packed()), in_mode, C.byref(dec.c), L.ptr(dec.packed()),
+                                    B, K, r, T, D, Zd, L.GEN[dims.gen_dist], 1 if dims.q_eps else 0, prior_raw,
+                                    1 if resample_final_imps else 0, L.ptr(Xw), L.ptr(Mw), L.ptr(e_all), L.ptr(d_all),
+                                    L.ptr(f_draw), L.ptr(n_all), seed, off_e, off_d, off_t, rng.base_ptr(),
+                                    L.ptr(cmin) if clip else None, L.ptr(cmax) if clip else None,
+                                    L.ptr(buf.data_imp) if buf is not None else None,
+                                    L.ptr(idx_imp.reshape(-1).contiguous()) if (buf is not None and idx_imp is not None) else None,
+                                    L.ptr(lw_dbg), st))
+        if LAIR_DEBUG is not None:
+            LAIR_DEBUG["log_w"] = lw_dbg
+        return Xw.view(B, K, D)
+
     # all iterations' proposals and log-weights in place, for the final resampling: [T][(i b k)]
     Z_all = torch.empty((T, N, Zd), dtype=torch.float32, device=dev) if resample_final_imps else None
     lw_all = torch.empty((T, N), dtype=torch.float32, device=dev) if resample_final_imps else None
     cfg = L.DmvObjCfg()
     cfg.B, cfg.G, cfg.nz, cfg.I, cfg.D, cfg.Zd = B, Kp, 1, I, D, Zd
     cfg.gen_dist, cfg.q_eps = L.GEN[dims.gen_dist], dims.q_eps
-    in_mode = L.IN_CONCAT if dims.encoder_use_mis_mask else L.IN_PLAIN
     from .objectives import fused_forward
     one_launch = (isinstance(enc, PackedNet) and isinstance(dec, PackedNet) and
                   not (training and ((enc.dims.dropout > 0 and enc.dims.nb > 0) or (dec.dims.dropout > 0 and dec.dims.nb > 0))))
     for t in range(T):
+        if clip and t > 0:
+            X0 = Xc[:, 0].contiguous()
         e = eps_z[t].reshape(N, Zd).contiguous().float() if eps_z is not None else None
         Zt = Z_all[t] if resample_final_imps else None
         out = None
@@ -305,6 +360,8 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
             L.check(rc)
         # resampling: K + r draws per datapoint from Categorical(logits = log_w[b, (i k)]) (:181-186), of which the first
         # K are kept (:521-524); row_map = rows of the chosen proposals in the (i, b, k)-ordered decoder outputs
+        if lw_dbg is not None:
+            lw_dbg.append(log_w.clone())
         last = (t == T - 1) and not resample_final_imps
         nz_t = noise_x[t] if noise_x is not None else None
         buf_t = buf if last else None
@@ -335,6 +392,8 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
             L.check(lib.dmv_categorical_draw_grouped(B, I, Kp, Kp, L.ptr(log_w), None, seed, off, rng.base_ptr(), None,
                                                      L.ptr(row_map), K, st))
         Xc = _tail(dims, dec_out, row_map, Xc, Mu, nz_t, cmin if clip else None, cmax if clip else None, True, buf_t, idx_t)
+    if lw_dbg is not None:
+        LAIR_DEBUG["log_w"] = torch.stack(lw_dbg)
     if resample_final_imps:
         # K latents per datapoint from the pooled T I (K+r) proposals of all iterations (:671-694), decoded once more
         rows_f = torch.empty(B * K, dtype=torch.int64, device=dev)

@@ -401,6 +401,33 @@ int dmv_categorical_draw_grouped(int32_t B, int32_t groups, int32_t inner, int32
                                  uint64_t seed, uint64_t offset, const uint64_t* offset_base, int64_t* idx, int64_t* rows,
                                  int32_t rows_keep, void* stream);
 
+/* LAIR's whole imputation update in one launch (vgiwae/shared/vae_imputation.py:390-563 per iteration, :671-694 the final
+ * resampling; DMIS log-weights shared/iwae.py:57-100; global multinomial resampling :181-198), one importance sample per
+ * component.  X [B*K][D] holds the K imputations of every datapoint and is updated in place, M [B*K][D] their masks.
+ * Per iteration t < T: encoder on the imputations (in_mode as dmv_mlp_forward), proposals from the K components and
+ * n_prior standard-normal ones (raw sigma prior_raw), decoder, log-weights against the uniform mixture of the K + n_prior
+ * components, K + n_prior categorical draws per datapoint of which the first K are kept, new imputations from the chosen
+ * proposals' decoder outputs (clamped after blending when clip_min / clip_max are given).  final_resample: afterwards K
+ * proposals per datapoint are drawn from the pooled T (K + n_prior) of all iterations, decoded once more and sampled
+ * without clamping.  buf / idx_imp (nullable): the imputation buffer rows that receive the final imputations.
+ * Noise: eps [T][B*(K+n_prior)][Zd], draws [T][B][K+n_prior] (proposal numbers), final_draws [B][K] (pooled numbers
+ * t*(K+n_prior) + c), noise [T (+1)][B*K][D] - each nullable; what is null comes from the Philox stream `seed` at the
+ * counters off_eps[t] + (b*(K+n_prior)+k)*Zd + j, off_draw[t] + b*(K+n_prior) + k (off_draw[T] + b*K + k for the final
+ * draws), off_tail[t] + (b*K+k)*D + d (host arrays of T, T+1, T+1 entries; offset_base as elsewhere): the ranges the
+ * separate launches (dmv_vae_forward, dmv_obj_forward, dmv_lair_resample_tail) would consume, so both ways use the same
+ * stream.  Everything between the imputations stays in LDS: relu networks of equal hidden width <= 256, K + n_prior <= 16,
+ * T <= 32 (dmv_lair_update_fits; DMV_E_UNSUPPORTED otherwise: use the separate launches).  No dropout is applied.
+ * lw_out (nullable) [T][B][K+n_prior] receives every iteration's log-weights. */
+int dmv_lair_update_fits(const DmvNet* enc, const DmvNet* dec, int32_t B, int32_t K, int32_t n_prior, int32_t T, int32_t D,
+                         int32_t Zd, int32_t final_resample);
+int dmv_lair_update(const DmvNet* enc, const float* enc_packed, int32_t in_mode, const DmvNet* dec, const float* dec_packed,
+                    int32_t B, int32_t K, int32_t n_prior, int32_t T, int32_t D, int32_t Zd, int32_t gen_dist, int32_t q_eps,
+                    float prior_raw, int32_t final_resample, float* X, const uint8_t* M, const float* eps,
+                    const int64_t* draws, const int64_t* final_draws, const float* noise, uint64_t seed,
+                    const uint64_t* off_eps, const uint64_t* off_draw, const uint64_t* off_tail, const uint64_t* offset_base,
+                    const float* clip_min, const float* clip_max, float* buf, const int64_t* idx_imp, float* lw_out,
+                    void* stream);
+
 /* LAIR's resampling and sampling tail in one launch (vgiwae/shared/vae_imputation.py:181-198, 521-561): per datapoint
  * K_draws draws as dmv_categorical_draw_grouped (uniforms u or the Philox stream (draw_seed, draw_offset + b*K_draws + k)),
  * the first K kept, then the K new imputation rows as dmv_impute_tail with clip_after_blend = 1 computes them from the

@@ -46,8 +46,11 @@ def test_pseudo_gibbs_bernoulli():
     assert (out.cpu() != ref).float().mean().item() < 2e-3
 
 
+@pytest.mark.parametrize("one_launch", [True, False])
 @pytest.mark.parametrize("name", gu.names("lair_"))
-def test_lair(name):
+def test_lair(name, one_launch):
+    """The reference's LAIR update with its recorded noise and draws, through the one-launch update (one importance
+    sample per component) and through the separate launches."""
     from demiss_vae_amd import imputation as imp
     g = gu.load(name)
     q = str(g["q_dist"])
@@ -55,11 +58,78 @@ def test_lair(name):
     dims, enc, dec = _nets(spec, enc_p, dec_p)
     T, r, final = int(g["T"]), int(g["r"]), bool(g["final"])
     idx = [torch.from_numpy(g[f"idx{t}"]) for t in range(T + (1 if final else 0))]
-    out = imp.lair(dims, enc, dec, torch.from_numpy(g["Xt"]).cuda(), torch.from_numpy(g["M"]).cuda(),
-                   num_iterations=T, num_imp_samples=int(g["I"]), num_prior_replenish_proposals=r,
-                   resample_final_imps=final, eps_z=[torch.from_numpy(e).cuda() for e in g["eps_z"]],
-                   idx=idx, noise_x=[torch.from_numpy(e).cuda() for e in g["eps_x"]])
+    imp.ONE_LAUNCH_LAIR = one_launch
+    imp.LAIR_DEBUG = {}
+    try:
+        out = imp.lair(dims, enc, dec, torch.from_numpy(g["Xt"]).cuda(), torch.from_numpy(g["M"]).cuda(),
+                       num_iterations=T, num_imp_samples=int(g["I"]), num_prior_replenish_proposals=r,
+                       resample_final_imps=final, eps_z=[torch.from_numpy(e).cuda() for e in g["eps_z"]],
+                       idx=idx, noise_x=[torch.from_numpy(e).cuda() for e in g["eps_x"]])
+        seen = "log_w" in imp.LAIR_DEBUG
+    finally:
+        imp.ONE_LAUNCH_LAIR, imp.LAIR_DEBUG = True, None
+    assert seen
     torch.testing.assert_close(out.cpu(), torch.from_numpy(g["X_new"]), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", ["small_r1_final_clip", "small_r0", "gas_r1_final", "gas_bern_r2"])
+def test_lair_one_launch_update_equals_separate_launches(case):
+    """dmv_lair_update against the launches it replaces, both fed from the same Philox stream: every iteration's
+    log-weights agree to rounding on the datapoints whose draws agreed so far (a draw flips only when its uniform sits
+    within rounding of a bin edge, after which that datapoint's trajectories part), the imputations are identical on
+    all but a handful of datapoints, and observed entries come back untouched."""
+    from demiss_vae_amd import imputation as imp, rng, synth
+    import demiss_vae_amd as dmv
+    if case.startswith("small"):
+        name = [n for n in gu.names("lair_")][0]
+        g = gu.load(name)
+        q = str(g["q_dist"])
+        spec, enc_p, dec_p = gu.model_case(dict(g, gen_dist=q, q_dist=q, mask_concat=False))
+        dims, enc, dec = _nets(spec, enc_p, dec_p)
+        X, M = torch.from_numpy(g["Xt"]).cuda(), torch.from_numpy(g["M"]).cuda()
+        D = X.shape[-1]
+        final, r, clip = case == "small_r1_final_clip", (1 if case == "small_r1_final_clip" else 0), case == "small_r1_final_clip"
+        T = 3
+    else:
+        # UCI-gas shapes (hidden 256), a batch that ends inside a tile
+        B, K, D, Zd = 301, 5, 8, 16
+        bern = case == "gas_bern_r2"
+        gen = "bern" if bern else "normal_with_eps"
+        enc = synth.packed_net(synth.NetShape(2 * D if bern else D, 2 * Zd, 2, 256), 11, "cuda", requires_grad=False)
+        dec = synth.packed_net(synth.NetShape(Zd, D if bern else 2 * D, 2, 256), 12, "cuda", requires_grad=False)
+        dims = dmv.ModelDims(D=D, Zd=Zd, gen_dist=gen, q_dist="normal_with_eps", encoder_use_mis_mask=bern)
+        X1, M1 = (t.cuda() for t in synth.batch(13, B, D))
+        if bern:
+            X1 = (X1 > 0.3).float()
+        X = X1[:, None, :].repeat(1, K, 1).contiguous()
+        X = torch.where(M1[:, None, :], X, (torch.randn_like(X) > 0.5).float() if bern else torch.randn_like(X))
+        M = M1[:, None, :].repeat(1, K, 1).contiguous()
+        final, r, clip, T = not bern, (2 if bern else 1), False, 4
+    kw = dict(num_iterations=T, num_imp_samples=1, num_prior_replenish_proposals=r, resample_final_imps=final,
+              clip_min=torch.full((D,), -1.5) if clip else None, clip_max=torch.full((D,), 1.5) if clip else None)
+    outs, lws = [], []
+    for one in (True, False):
+        imp.ONE_LAUNCH_LAIR, imp.LAIR_DEBUG = one, {}
+        try:
+            rng.set_seed(977)
+            outs.append(imp.lair(dims, enc, dec, X, M, **kw))
+            lws.append(imp.LAIR_DEBUG["log_w"])
+        finally:
+            imp.ONE_LAUNCH_LAIR, imp.LAIR_DEBUG = True, None
+    B, K = X.shape[0], X.shape[1]
+    Kp = K + r
+    a, b = (w.view(T, B, Kp) for w in lws)
+    same = torch.ones(B, dtype=torch.bool, device=a.device)          # datapoints whose trajectories have not parted
+    for t in range(T):
+        err = ((a[t] - b[t]).abs() / (1.0 + b[t].abs())).amax(1)
+        assert float(err[same].max()) < 2e-5, (t, float(err[same].max()))
+        same &= err < 2e-5
+        # (a parted trajectory shows in the next iteration's log-weights)
+    assert float(same.float().mean()) > 0.97
+    diff_dp = (outs[0] != outs[1]).flatten(1).any(1)
+    assert float(diff_dp.float().mean()) < 0.03, float(diff_dp.float().mean())
+    obs = X[M].clamp(-1.5, 1.5) if clip else X[M]
+    assert torch.equal(outs[0][M], obs) and not torch.equal(outs[0], X)
 
 
 @pytest.mark.parametrize("final,clip", [(False, False), (True, True)])
