@@ -7,7 +7,7 @@ set -u
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 P=gpurun_out/r3prof
 mkdir -p $P
-for spec in "32768 eager 30" "512 graph 200" "hepmass graph 100" "miniboone graph 100" "toy graph 100" "uci graph 100"; do
+for spec in "32768 eager 30" "512 graph 200" "hepmass graph 100" "miniboone graph 100" "toy graph 100" "uci graph 100" "wide graph 50"; do
   set -- $spec
   bash tools/step_trace.sh $1 $2 $3 > $P/step_$1_$2.md 2>&1 || { echo "step trace $spec failed"; tail -5 $P/step_$1_$2.md; exit 1; }
   cp gpurun_out/steptrace_$1_$2/trace/*/*_kernel_stats.csv $P/step_$1_$2_kernel_stats.csv

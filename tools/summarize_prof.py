@@ -19,12 +19,21 @@ dirty = "+uncommitted" if subprocess.run(["git", "status", "--porcelain", "demis
                                          text=True).stdout.strip() else ""
 lines = [f"# rocprofv3 summary ({tag}): `python bench.py --kernels-only` (decoder MLP kernels, 163840 rows)", "",
          f"Collected: {datetime.date.today().isoformat()}, tree at {head}{dirty}, one MI355X (tools/prof.sh)", "",
-         "## --kernel-trace --stats", "", "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
+         "## --kernel-trace --stats", "",
+         "avg us: over all launches, as rocprofv3 --stats prints it.  steady avg us: the last 20 launches of each kernel (the",
+         "timed ones of `bench.py --kernels-only`, which come after 30 untimed launches), from the per-launch kernel trace.", "",
+         "| kernel | calls | avg us | steady avg us | min us | max us |", "|---|---|---|---|---|---|"]
+trace = newest(f"{src}/trace/vm/*_kernel_trace.csv")
+per_launch = collections.defaultdict(list)
+for r in sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"])):
+    per_launch[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 dur = {}
 for r in csv.DictReader(open(stats)):
     if r["Name"].startswith(("void k_", "k_")):
-        dur[r["Name"]] = float(r["AverageNs"])
-        lines.append(f"| {r['Name']} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} |")
+        rest = per_launch.get(r["Name"], [])[-20:]
+        steady = sum(rest) / len(rest) if rest else float(r["AverageNs"])
+        dur[r["Name"]] = steady
+        lines.append(f"| {r['Name']} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {steady/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} |")
 lines += ["", "## --pmc (separate passes; averages per launch)", ""]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("pmc1", "pmc2", "pmc3"):

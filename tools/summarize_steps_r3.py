@@ -26,9 +26,16 @@ What changed in the steps since `profiles/r2_training_steps.md`, kernel by kerne
   at most 256 workgroups);
 - stratified / imputation mixtures: `k_obj_bwd_latent` -> `k_obj_bwd_latent_mix` (parameters, samples and
   responsibilities of a datapoint in LDS; `profiles/r3_latent_mixture_kernel.md`);
-- LAIR update: per iteration encoder + two `cat` + sample + decoder + objective + draw + row map + tail (9 launches) ->
-  one-launch forward (prior-replenish proposals included) + objective + draw (emits the proposal rows) + tail (4); the
-  final resampling reads all iterations' proposals where the iterations left them (no `stack` / `permute` / `gather`).
+- LAIR update: per iteration encoder + two `cat` + sample + decoder + objective + draw + row map + tail (9 launches), then
+  `stack` / `permute` / `gather` and four more launches for the final resampling -> ONE launch for the whole update,
+  `k_lair_rows16` (a workgroup walks its datapoints through all iterations; encoder outputs, proposals, decoder outputs,
+  log-weights and the proposals kept for the final resampling stay in LDS).  Shapes outside its limits (several importance
+  samples per component, more than 16 proposals per datapoint, dropout to draw) take three launches per iteration: the
+  one-launch forward with the prior-replenish proposals, the objective forward, and the draws + sampling tail
+  (`k_lair_resample_tail`);
+- hidden widths 257 - 512 (synthetic pair, not a reference configuration): four-wave 32-row tiles beyond 4096 rows
+  (`k_mlp_fwd_coop<16>`, `k_mlp_bwd_coop<16>`: one full layer input + the wave's own slice of the residual stream in
+  registers), a last partial round on 16-row tiles.
 
 """
 TITLES = {
@@ -42,6 +49,8 @@ TITLES = {
                       "K = 5, replayed from a HIP graph",
     "step_uci_graph": "UCI-gas DeMissVAE mvb2 step with its LAIR update (one prior-replenish proposal, ten iterations, final "
                       "resampling), B = 512, K = 5, clip 1, replayed from a HIP graph",
+    "step_wide_graph": "synthetic hidden-512 pair with 784-dimensional Bernoulli data (NOT a reference configuration), MissIWAE "
+                       "I = 5, B = 4096 (decoder 20 480 rows, hidden 512), replayed from a HIP graph",
 }
 
 
