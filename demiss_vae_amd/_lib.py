@@ -99,6 +99,9 @@ SIGNATURES = {
     "dmv_lair_update_fits": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
     "dmv_lair_update": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_float, _I32, _P, _P, _P,
                                   _P, _P, _P, _U64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dmv_pgibbs_update_fits": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32]),
+    "dmv_pgibbs_update": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _U64, _P, _P, _P,
+                                    _P, _P, _P, _P, _P]),
     "dmv_lair_resample_tail": (C.c_int, [_I32, _I32, _I32, _I32, _I32, _P, _P, _U64, _U64, _I32, _I32, _P, _I64, _P, _P, _P, _U64, _U64,
                                          _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmv_categorical_draw_grouped": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _U64, _U64, _P, _P, _P, _I32, _P]),

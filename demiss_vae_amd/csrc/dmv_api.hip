@@ -7,7 +7,7 @@ extern "C" const char* dmv_strerror(int rc) {
   switch (rc) {
     case DMV_OK: return "ok";
     case DMV_E_BADARG: return "dmv: bad argument (null pointer, negative size, or inconsistent dimensions / pitches)";
-    case DMV_E_UNSUPPORTED: return "dmv: unsupported value (enum out of range, hidden > 256, nb > 8, or more than 64 mixture components)";
+    case DMV_E_UNSUPPORTED: return "dmv: unsupported value (enum out of range, hidden > 512 or > 256 with a non-relu activation, nb > 8, more than 64 mixture components, or a shape beyond an entry point's stated limits)";
     case DMV_E_WORKSPACE: return "dmv: workspace too small";
     default: break;
   }

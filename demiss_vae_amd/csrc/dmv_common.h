@@ -39,7 +39,7 @@ static inline int dmv_check_net(const DmvNet* n) {
   if (!n) return DMV_E_BADARG;
   if (n->in_dim < 1 || n->out_dim < 1 || n->hidden < 1 || n->nb < 0) return DMV_E_BADARG;
   if (n->hidden > 512 || n->nb > 8 || n->in_dim > 4096 || n->out_dim > 4096) return DMV_E_UNSUPPORTED;
-  // hidden widths 257..512 run on the 16-row kernels only: relu
+  // hidden widths 257..512 run on the four-wave and 16-row kernels only: relu
   if (n->hidden > 256 && n->act != DMV_ACT_RELU) return DMV_E_UNSUPPORTED;
   if (n->act < DMV_ACT_RELU || n->act > DMV_ACT_SIGMOID) return DMV_E_UNSUPPORTED;
   if (!(n->dropout_p >= 0.f && n->dropout_p < 1.f)) return DMV_E_BADARG;

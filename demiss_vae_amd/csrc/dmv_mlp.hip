@@ -1513,6 +1513,8 @@ struct LairArgs {
   FwdArgs enc, dec;           // enc.x = the imputations X [B K][D] (updated in place), enc.m = their masks; y unused
   int B, K, Kp, Zd, D, T, DP;
   int gen_dist, final_resample;
+  int resample;               // 1: LAIR.  0: pseudo-Gibbs (:38-52) - every row its own datapoint (K = Kp = 1), the one
+                              // proposal is taken as it is, and the sample is clamped before the blend
   float prior_raw, q_eps;
   int raw_off;                // where the raw sigma starts in an encoder output row
   int ZP, ldE, ldD;
@@ -1562,7 +1564,8 @@ __global__ __launch_bounds__(256, 1) void k_lair_rows16(LairArgs a) {
   const bool normal = a.gen_dist <= DMV_GEN_NORMAL_EPS;
   const float geps = a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f;
   TailArgs ta;
-  ta.D = D; ta.gen_dist = a.gen_dist; ta.clip_min = a.clip_min; ta.clip_max = a.clip_max; ta.clip_after_blend = 1;
+  ta.D = D; ta.gen_dist = a.gen_dist; ta.clip_min = a.clip_min; ta.clip_max = a.clip_max; ta.clip_after_blend = a.resample;
+  if (!a.resample && tid < 16) pick[tid] = tid;   // (ordered before its first reader by the barriers of the passes below)
 
   auto decode = [&]() {
     r16_forward_chain<NT, false, false, W>(
@@ -1620,14 +1623,21 @@ __global__ __launch_bounds__(256, 1) void k_lair_rows16(LairArgs a) {
         const int64_t i = ((int64_t)(b0 + (dp2 < nb ? dp2 : 0)) * Kp + k2) * Zd + j;
         const float e = a.eps ? a.eps[(int64_t)t * NZ * Zd + i] : dmv_philox_normal(a.seed, a.off_eps[t] + base + (uint64_t)i);
         z = mu + sg * e;
-        const float rs = __builtin_amdgcn_rcpf(sg);
-        qt[mm * Zd + j] = QEntry{mu, 0.5f * rs * rs, dmv_log(sg) + LOG_SQRT_2PI, 0.f};
+        if (a.resample) {
+          const float rs = __builtin_amdgcn_rcpf(sg);
+          qt[mm * Zd + j] = QEntry{mu, 0.5f * rs * rs, dmv_log(sg) + LOG_SQRT_2PI, 0.f};
+        }
         if (a.final_resample) zall[((size_t)t * 16 + mm) * Zd + j] = z;
       }
       zt[mm * ZP + j] = z;
     }
     __syncthreads();
     decode();
+    if (!a.resample) {
+      tail(ta, t, t == a.T - 1);
+      __syncthreads();
+      continue;
+    }
     // ---- DMIS log-weights: log p(x_o | z) + log p(z) - log (1 / Kp) sum_c q_c(z), the observed entries under the mask of
     // the datapoint's first imputation (:407) and that imputation's values
     if (tid < 16 * PW) {
@@ -2801,21 +2811,21 @@ extern "C" int dmv_lair_update_fits(const DmvNet* enc, const DmvNet* dec, int32_
   return lair_fits(enc, dec, B, K, n_prior, T, D, Zd, final_resample) ? 1 : 0;
 }
 
-extern "C" int dmv_lair_update(const DmvNet* enc, const float* enc_packed, int32_t in_mode, const DmvNet* dec,
-                               const float* dec_packed, int32_t B, int32_t K, int32_t n_prior, int32_t T, int32_t D, int32_t Zd,
-                               int32_t gen_dist, int32_t q_eps, float prior_raw, int32_t final_resample, float* X,
-                               const uint8_t* M, const float* eps, const int64_t* draws, const int64_t* final_draws,
-                               const float* noise, uint64_t seed, const uint64_t* off_eps, const uint64_t* off_draw,
-                               const uint64_t* off_tail, const uint64_t* offset_base, const float* clip_min,
-                               const float* clip_max, float* buf, const int64_t* idx_imp, float* lw_out, void* stream) {
+static int sampler_update(int resample, const DmvNet* enc, const float* enc_packed, int32_t in_mode, const DmvNet* dec,
+                          const float* dec_packed, int32_t B, int32_t K, int32_t n_prior, int32_t T, int32_t D, int32_t Zd,
+                          int32_t gen_dist, int32_t q_eps, float prior_raw, int32_t final_resample, float* X,
+                          const uint8_t* M, const float* eps, const int64_t* draws, const int64_t* final_draws,
+                          const float* noise, uint64_t seed, const uint64_t* off_eps, const uint64_t* off_draw,
+                          const uint64_t* off_tail, const uint64_t* offset_base, const float* clip_min,
+                          const float* clip_max, float* buf, const int64_t* idx_imp, float* lw_out, void* stream) {
   if (!lair_fits(enc, dec, B, K, n_prior, T, D, Zd, final_resample)) return DMV_E_UNSUPPORTED;
   if (!enc_packed || !dec_packed || !X || !M || (buf && !idx_imp)) return DMV_E_BADARG;
   if (gen_dist < DMV_GEN_NORMAL || gen_dist > DMV_GEN_BERN_M1P1) return DMV_E_UNSUPPORTED;
   if (in_mode < DMV_IN_PLAIN || in_mode > DMV_IN_CONCAT_MASKED) return DMV_E_UNSUPPORTED;
   if (((in_mode >= DMV_IN_CONCAT) ? 2 * D : D) != enc->in_dim) return DMV_E_BADARG;
   if (dec->out_dim != (gen_dist <= DMV_GEN_NORMAL_EPS ? 2 * D : D)) return DMV_E_BADARG;
-  const bool philox = !eps || !draws || !noise || (final_resample && !final_draws);
-  if (philox && (!off_eps || !off_draw || !off_tail)) return DMV_E_BADARG;
+  if ((!eps && !off_eps) || (!noise && !off_tail)) return DMV_E_BADARG;
+  if (resample && (!draws || (final_resample && !final_draws)) && !off_draw) return DMV_E_BADARG;
   LairArgs a;
   auto fill = [](FwdArgs& f, const DmvNet* net, const float* packed, int64_t rows) {
     f.drop.mode = DROP_OFF; f.drop.bits = 0; f.drop.thresh = 0; f.drop.keep = nullptr; f.drop.seed = 0; f.drop.q0 = 0;
@@ -2834,7 +2844,7 @@ extern "C" int dmv_lair_update(const DmvNet* enc, const float* enc_packed, int32
   fill(a.dec, dec, dec_packed, (int64_t)B * Kp);
   a.dec.in_mode = DMV_IN_PLAIN; a.dec.D = Zd; a.dec.x = nullptr; a.dec.ldx = 0; a.dec.m = nullptr; a.dec.ldm = 0;
   a.B = B; a.K = K; a.Kp = Kp; a.Zd = Zd; a.D = D; a.T = T; a.DP = 16 / Kp;
-  a.gen_dist = gen_dist; a.final_resample = final_resample ? 1 : 0;
+  a.gen_dist = gen_dist; a.final_resample = final_resample ? 1 : 0; a.resample = resample;
   a.prior_raw = prior_raw; a.q_eps = q_eps ? DMV_EPSILON : 0.f; a.raw_off = Zd;
   a.ZP = 16 * dmv_ceil_div(Zd, 16); a.ldE = dmv_pad32(enc->out_dim); a.ldD = dmv_pad32(dec->out_dim);
   a.seed = seed;
@@ -2849,6 +2859,33 @@ extern "C" int dmv_lair_update(const DmvNet* enc, const float* enc_packed, int32
   a.lw_out = lw_out;
   const size_t dyn = lair_dyn_bytes(enc, dec, Kp, Zd, T, final_resample);
   DMV_DISPATCH_NT(a.enc.L.NT, launch_lair, a, dyn, (hipStream_t)stream);
+}
+
+extern "C" int dmv_lair_update(const DmvNet* enc, const float* enc_packed, int32_t in_mode, const DmvNet* dec,
+                               const float* dec_packed, int32_t B, int32_t K, int32_t n_prior, int32_t T, int32_t D, int32_t Zd,
+                               int32_t gen_dist, int32_t q_eps, float prior_raw, int32_t final_resample, float* X,
+                               const uint8_t* M, const float* eps, const int64_t* draws, const int64_t* final_draws,
+                               const float* noise, uint64_t seed, const uint64_t* off_eps, const uint64_t* off_draw,
+                               const uint64_t* off_tail, const uint64_t* offset_base, const float* clip_min,
+                               const float* clip_max, float* buf, const int64_t* idx_imp, float* lw_out, void* stream) {
+  return sampler_update(1, enc, enc_packed, in_mode, dec, dec_packed, B, K, n_prior, T, D, Zd, gen_dist, q_eps, prior_raw,
+                        final_resample, X, M, eps, draws, final_draws, noise, seed, off_eps, off_draw, off_tail, offset_base,
+                        clip_min, clip_max, buf, idx_imp, lw_out, stream);
+}
+
+extern "C" int dmv_pgibbs_update_fits(const DmvNet* enc, const DmvNet* dec, int32_t rows, int32_t T, int32_t D, int32_t Zd) {
+  return lair_fits(enc, dec, rows, 1, 0, T, D, Zd, 0) ? 1 : 0;
+}
+
+extern "C" int dmv_pgibbs_update(const DmvNet* enc, const float* enc_packed, int32_t in_mode, const DmvNet* dec,
+                                 const float* dec_packed, int32_t rows, int32_t T, int32_t D, int32_t Zd, int32_t gen_dist,
+                                 int32_t q_eps, float* X, const uint8_t* M, const float* eps, const float* noise, uint64_t seed,
+                                 const uint64_t* off_eps, const uint64_t* off_tail, const uint64_t* offset_base,
+                                 const float* clip_min, const float* clip_max, float* buf, const int64_t* idx_imp,
+                                 void* stream) {
+  return sampler_update(0, enc, enc_packed, in_mode, dec, dec_packed, rows, 1, 0, T, D, Zd, gen_dist, q_eps, 0.f, 0, X, M, eps,
+                        nullptr, nullptr, noise, seed, off_eps, nullptr, off_tail, offset_base, clip_min, clip_max, buf, idx_imp,
+                        nullptr, stream);
 }
 
 // ---- backward host side

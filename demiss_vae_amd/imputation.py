@@ -160,6 +160,10 @@ def _keep(net, rows, training, device):
 
 
 # ------------------------------------------------------------------------------------------ pseudo-Gibbs
+# all iterations of the sampler as one launch (dmv_pgibbs_update) where its limits allow
+ONE_LAUNCH_PGIBBS = True
+
+
 @torch.no_grad()
 def pseudo_gibbs(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iterations=1, clip_min=None,
                  clip_max=None, eps_z=None, noise_x=None, training=True, buf: Optional[ImputationBuffer] = None,
@@ -175,6 +179,32 @@ def pseudo_gibbs(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_i
     cmin = clip_min.to(dev).float().contiguous() if clip_min is not None else None
     cmax = clip_max.to(dev).float().contiguous() if clip_max is not None else None
     N = B * K
+    T = num_iterations
+    if (ONE_LAUNCH_PGIBBS and isinstance(enc, PackedNet) and isinstance(dec, PackedNet) and T >= 1 and
+            not (training and ((enc.dims.dropout > 0 and enc.dims.nb > 0) or (dec.dims.dropout > 0 and dec.dims.nb > 0))) and
+            lib.dmv_pgibbs_update_fits(C.byref(enc.c), C.byref(dec.c), N, T, D, dims.Zd)):
+        # every iteration in one launch: a workgroup keeps 16 imputation rows and walks them through all T passes
+        Xw = Xc.clone().view(N, D)
+        Mw = Mu.reshape(N, D).contiguous()
+        e_all = (torch.stack([e.reshape(N, dims.Zd) for e in eps_z[:T]]).contiguous().float().to(dev)
+                 if eps_z is not None else None)
+        n_all = (torch.stack([x.reshape(N, D) for x in noise_x[:T]]).contiguous().float().to(dev)
+                 if noise_x is not None else None)
+        off_e, off_t = (C.c_uint64 * T)(), (C.c_uint64 * (T + 1))()
+        seed = 0
+        for t in range(T):                                  # the ranges of the separate launches, in their order
+            if e_all is None:
+                seed, off_e[t] = rng.next_offset(N * dims.Zd)
+            if n_all is None:
+                seed, off_t[t] = rng.next_offset(N * D)
+        in_mode = L.IN_CONCAT if dims.encoder_use_mis_mask else L.IN_PLAIN
+        L.check(lib.dmv_pgibbs_update(C.byref(enc.c), L.ptr(enc.packed()), in_mode, C.byref(dec.c), L.ptr(dec.packed()), N, T, D,
+                                      dims.Zd, L.GEN[dims.gen_dist], 1 if dims.q_eps else 0, L.ptr(Xw), L.ptr(Mw), L.ptr(e_all),
+                                      L.ptr(n_all), seed, off_e, off_t, rng.base_ptr(), L.ptr(cmin), L.ptr(cmax),
+                                      L.ptr(buf.data_imp) if buf is not None else None,
+                                      L.ptr(idx_imp.reshape(-1).contiguous()) if (buf is not None and idx_imp is not None) else None,
+                                      st))
+        return Xw.view(B, K, D)
     for t in range(num_iterations):
         e = eps_z[t].reshape(N, dims.Zd).contiguous().float() if eps_z is not None else None
         one = _one_launch_pass(dims, enc, dec, Xc.reshape(N, D), Mu.reshape(N, D), N, 1, e, training)

@@ -428,6 +428,18 @@ int dmv_lair_update(const DmvNet* enc, const float* enc_packed, int32_t in_mode,
                     const float* clip_min, const float* clip_max, float* buf, const int64_t* idx_imp, float* lw_out,
                     void* stream);
 
+/* All iterations of the pseudo-Gibbs sampler in one launch (vgiwae/shared/vae_imputation.py:26-82: encoder on the
+ * imputation, z ~ q(. | x), decoder, x_m ~ p(. | z) clamped, blended with the observed values - T times): the same kernel
+ * with every imputation row a datapoint of its own.  X [rows][D] is updated in place; eps [T][rows][Zd], noise
+ * [T][rows][D] nullable (then Philox at off_eps[t] + r*Zd + j and off_tail[t] + r*D + d, the ranges dmv_vae_forward and
+ * dmv_impute_tail would take); buf / idx_imp as above.  Same values as those launches; same limits as dmv_lair_update. */
+int dmv_pgibbs_update_fits(const DmvNet* enc, const DmvNet* dec, int32_t rows, int32_t T, int32_t D, int32_t Zd);
+int dmv_pgibbs_update(const DmvNet* enc, const float* enc_packed, int32_t in_mode, const DmvNet* dec, const float* dec_packed,
+                      int32_t rows, int32_t T, int32_t D, int32_t Zd, int32_t gen_dist, int32_t q_eps, float* X,
+                      const uint8_t* M, const float* eps, const float* noise, uint64_t seed, const uint64_t* off_eps,
+                      const uint64_t* off_tail, const uint64_t* offset_base, const float* clip_min, const float* clip_max,
+                      float* buf, const int64_t* idx_imp, void* stream);
+
 /* LAIR's resampling and sampling tail in one launch (vgiwae/shared/vae_imputation.py:181-198, 521-561): per datapoint
  * K_draws draws as dmv_categorical_draw_grouped (uniforms u or the Philox stream (draw_seed, draw_offset + b*K_draws + k)),
  * the first K kept, then the K new imputation rows as dmv_impute_tail with clip_after_blend = 1 computes them from the

@@ -17,8 +17,17 @@ def _nets(spec, enc_p, dec_p):
             G.packed_net(spec.dec, dec_p, requires_grad=False))
 
 
+@pytest.fixture(params=[True, False], ids=["one_launch", "separate_launches"])
+def pgibbs_path(request):
+    """the sampler's iterations as one launch (dmv_pgibbs_update) or as a forward launch and a tail launch each"""
+    from demiss_vae_amd import imputation as imp
+    imp.ONE_LAUNCH_PGIBBS = request.param
+    yield request.param
+    imp.ONE_LAUNCH_PGIBBS = True
+
+
 @pytest.mark.parametrize("name", gu.names("pgibbs_normal"))
-def test_pseudo_gibbs_normal(name):
+def test_pseudo_gibbs_normal(name, pgibbs_path):
     from demiss_vae_amd import imputation as imp
     g = gu.load(name)
     spec, enc_p, dec_p = gu.model_case(dict(g, gen_dist="normal", q_dist="normal", mask_concat=False))
@@ -33,7 +42,54 @@ def test_pseudo_gibbs_normal(name):
     assert torch.equal(out[M], Xt[M])      # observed entries bit-exact
 
 
-def test_pseudo_gibbs_bernoulli():
+@pytest.mark.parametrize("case", ["toy_clip", "gas", "gas_bern"])
+def test_pseudo_gibbs_one_launch_equals_separate_launches(case):
+    """dmv_pgibbs_update walks the same tiles through the same chains and takes the same Philox ranges as a
+    dmv_vae_forward + dmv_impute_tail pair per iteration: identical imputations, bit for bit, and identical rows in the
+    imputation buffer."""
+    from demiss_vae_amd import imputation as imp, rng, synth
+    from demiss_vae_amd.imputation import ImputationBuffer
+    import demiss_vae_amd as dmv
+    if case == "toy_clip":
+        g = gu.load(gu.names("pgibbs_normal")[0])
+        spec, enc_p, dec_p = gu.model_case(dict(g, gen_dist="normal", q_dist="normal", mask_concat=False))
+        dims, enc, dec = _nets(spec, enc_p, dec_p)
+        X, M = torch.from_numpy(g["Xt"]).cuda(), torch.from_numpy(g["M"]).cuda()
+        D = X.shape[-1]
+        kw = dict(num_iterations=4, clip_min=torch.full((D,), -0.8), clip_max=torch.full((D,), 0.9))
+    else:
+        B, K, D, Zd = 203, 5, 8, 16
+        bern = case == "gas_bern"
+        enc = synth.packed_net(synth.NetShape(2 * D, 2 * Zd, 2, 256), 21, "cuda", requires_grad=False)
+        dec = synth.packed_net(synth.NetShape(Zd, D if bern else 2 * D, 2, 256), 22, "cuda", requires_grad=False)
+        dims = dmv.ModelDims(D=D, Zd=Zd, gen_dist="bern" if bern else "normal_with_eps", q_dist="normal_with_eps",
+                             encoder_use_mis_mask=True)
+        X1, M1 = (t.cuda() for t in synth.batch(23, B, D))
+        X = X1[:, None, :].repeat(1, K, 1).contiguous()
+        X = torch.where(M1[:, None, :], X, torch.randn_like(X))
+        if bern:
+            X = (X > 0.3).float()
+        M = M1[:, None, :].repeat(1, K, 1).contiguous()
+        kw = dict(num_iterations=3)
+    B, K = X.shape[0], X.shape[1]
+    outs, bufs = [], []
+    for one in (True, False):
+        imp.ONE_LAUNCH_PGIBBS = one
+        try:
+            rng.set_seed(555)
+            buf = ImputationBuffer(X[:, 0].cpu(), K, "cuda")
+            idx_imp = buf.idx_imp[:B].clone()
+            outs.append(imp.pseudo_gibbs(dims, enc, dec, X, M, buf=buf, idx_imp=idx_imp, **kw))
+            bufs.append(buf.data_imp.clone())
+        finally:
+            imp.ONE_LAUNCH_PGIBBS = True
+    assert torch.equal(outs[0], outs[1]) and torch.equal(bufs[0], bufs[1])
+    assert not torch.equal(outs[0], X)
+    if case != "toy_clip":
+        assert torch.equal(outs[0][M], X[M])
+
+
+def test_pseudo_gibbs_bernoulli(pgibbs_path):
     from demiss_vae_amd import imputation as imp
     g = gu.load("pgibbs_bern_m1_p1")
     spec, enc_p, dec_p = gu.model_case(dict(g, gen_dist="bern_m1_p1", q_dist="normal_with_eps", mask_concat=True))
