@@ -21,6 +21,16 @@
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// The build compiles this file three times (-DDMV_MLP_PART=1, 2, 3: three objects, in parallel), each time with the
+// entry points of one group of kernels; a kernel template is only instantiated in the object whose entry points reach
+// it.  1: the C entry points, the kernels of hidden widths up to 256 and the weight-gradient kernels; 2: hidden widths
+// 257 - 512; 3: the one-launch encoder-decoder passes and sampler updates.  Without the macro (the tuning build) everything
+// lands in one object.
+#ifndef DMV_MLP_PART
+#define DMV_MLP_PART 0
+#endif
+#define DMV_PART(p) (DMV_MLP_PART == 0 || DMV_MLP_PART == (p))
+
 // Phase timestamps for kernel tuning (debug builds only: make TRACE=1): wave w writes the shader clock at
 // phase i to dmv_trace_buf[16 w + i]; dmv_debug_trace copies the buffer out.
 #ifdef DMV_TRACE
@@ -56,6 +66,7 @@ struct PackArgs {
 };
 
 // one thread = one lane slot of one fragment (16 bytes of an image) or one bias-fragment lane
+#if DMV_PART(1)
 __global__ void k_pack(PackArgs a) {
   const int l = blockIdx.y;
   const int N = a.L.N[l], K = a.L.K[l];
@@ -96,6 +107,7 @@ __global__ void k_pack(PackArgs a) {
     }
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // device building blocks
@@ -2286,6 +2298,7 @@ __device__ __forceinline__ void wgrad_dispatch_k(int tk, const WgradLayer& Ly, i
   }
 }
 
+#if DMV_PART(1)
 __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(WgradArgs a) {
   const int lane = threadIdx.x & 63;
   // wave-uniform by construction; readfirstlane lets the compiler keep the whole work decomposition scalar
@@ -2317,6 +2330,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(WgradArgs a) {
   TRACE_REAL(14);
 }
 
+#endif
+
 struct ReduceArgs {
   int nl;
   int N[DMV_MAX_LAYERS], K[DMV_MAX_LAYERS], Kp[DMV_MAX_LAYERS];
@@ -2330,6 +2345,7 @@ struct ReduceArgs {
   float beta;
 };
 
+#if DMV_PART(1)
 __global__ void k_wgrad_reduce(ReduceArgs a) {
   const int64_t total = a.first[a.nl];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -2363,9 +2379,21 @@ __global__ void k_wgrad_reduce(ReduceArgs a) {
   }
 }
 
+#endif
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// launchers of the other objects' kernels (see DMV_MLP_PART above)
+struct VaeFwdArgs; struct VaeBwdArgs; struct LairArgs;
+int dmv_part_fwd_wide(const FwdArgs& a, hipStream_t st);
+int dmv_part_bwd_wide(const BwdArgs& a, hipStream_t st);
+int dmv_part_dropout_keep_wide(int NT, const DropSrc& d, int nb, int64_t rows, int hidden, uint8_t* keep, hipStream_t st);
+int dmv_part_vae_fwd(const VaeFwdArgs& a, size_t dyn_bytes, hipStream_t st);
+int dmv_part_vae_bwd(const VaeBwdArgs& a, size_t dyn_bytes, hipStream_t st);
+int dmv_part_lair(const LairArgs& a, size_t dyn_bytes, hipStream_t st);
+
+#if DMV_PART(1)
 extern "C" int32_t dmv_pad32(int32_t n) { return 32 * ((n + 31) / 32); }
 
 extern "C" size_t dmv_mlp_packed_floats(const DmvNet* net) {
@@ -2417,6 +2445,8 @@ extern "C" size_t dmv_mlp_saved_floats(const DmvNet* net, int64_t rows) {
   const int64_t mw = 2 * (((Hp / 32) + 1) / 2);    // sign-bit words per row and layer (two half-rows)
   return (size_t)(rp * Ip + (2 * net->nb + 1) * rp * (Hp + mw));
 }
+
+#endif
 
 // How a relu pass over `rows` rows is cut into launches.  The chip holds 1024 one-wave tiles (32 rows), 256
 // four-wave tiles or 256 sixteen-row tiles per round, and a round of those takes about 140 / 47 / 28 us at
@@ -2593,12 +2623,15 @@ static void drop_plan(float p, int32_t* bits, uint32_t* thresh) {
   else { *bits = 16; *thresh = (uint32_t)((double)p * 65536.0 + 0.5); }
 }
 
+#if DMV_PART(1)
 extern "C" size_t dmv_mlp_dropout_rng_elements(const DmvNet* net, int64_t rows) {
   if (dmv_check_net(net) || rows <= 0 || net->dropout_p <= 0.f) return 0;
   int32_t bits; uint32_t thresh;
   drop_plan(net->dropout_p, &bits, &thresh);
   return (size_t)net->nb * (size_t)rows * 2u * (size_t)drop_calls(bits, dmv_layout(net).NT) * 4u;
 }
+
+#endif
 
 template <int NT>
 __global__ void k_dropout_keep(DropSrc d, int nb, int64_t rows, int hidden, uint8_t* keep) {
@@ -2640,6 +2673,15 @@ static int drop_source(const DmvNet* net, const uint8_t* drop_keep, const DmvDro
   return DMV_OK;
 }
 
+#if DMV_PART(2)
+int dmv_part_fwd_wide(const FwdArgs& a, hipStream_t st) { DMV_DISPATCH_WIDE(a.L.NT, launch_fwd_wide, a, st); }
+int dmv_part_bwd_wide(const BwdArgs& a, hipStream_t st) { DMV_DISPATCH_WIDE(a.L.NT, launch_bwd_wide, a, st); }
+int dmv_part_dropout_keep_wide(int NT, const DropSrc& d, int nb, int64_t rows, int hidden, uint8_t* keep, hipStream_t st) {
+  DMV_DISPATCH_WIDE(NT, launch_dropout_keep, d, nb, rows, hidden, keep, st);
+}
+#endif
+
+#if DMV_PART(1)
 extern "C" int dmv_mlp_dropout_keep(const DmvNet* net, int64_t rows, const DmvDropRng* gen, uint8_t* keep, void* stream) {
   int rc = dmv_check_net(net);
   if (rc) return rc;
@@ -2658,7 +2700,7 @@ extern "C" int dmv_mlp_dropout_keep(const DmvNet* net, int64_t rows, const DmvDr
     case 6: return launch_dropout_keep<6>(d, net->nb, rows, net->hidden, keep, (hipStream_t)stream);
     case 7: return launch_dropout_keep<7>(d, net->nb, rows, net->hidden, keep, (hipStream_t)stream);
     case 8: return launch_dropout_keep<8>(d, net->nb, rows, net->hidden, keep, (hipStream_t)stream);
-    default: return [&]() -> int { DMV_DISPATCH_WIDE(NT, launch_dropout_keep, d, net->nb, rows, net->hidden, keep, (hipStream_t)stream); }();
+    default: return dmv_part_dropout_keep_wide(NT, d, net->nb, rows, net->hidden, keep, (hipStream_t)stream);
   }
 }
 
@@ -2691,10 +2733,11 @@ extern "C" int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t i
   a.masks = saved ? (uint32_t*)(a.acts + (2 * net->nb + 1) * rp * dmv_pad32(net->hidden)) : nullptr;
   if (a.L.NT > 8) {
     if (a.drop.mode != DROP_OFF && net->act != DMV_ACT_RELU) return DMV_E_UNSUPPORTED;
-    DMV_DISPATCH_WIDE(a.L.NT, launch_fwd_wide, a, (hipStream_t)stream);
+    return dmv_part_fwd_wide(a, (hipStream_t)stream);
   }
   DMV_DISPATCH_NT(a.L.NT, launch_fwd, a, (hipStream_t)stream);
 }
+#endif
 
 // ---- encoder -> sample -> decoder in one launch
 template <int NT>
@@ -2720,6 +2763,11 @@ static bool vae_forward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvN
   return dyn + (size_t)NTe * 2048 + 64 <= 65536;
 }
 
+#if DMV_PART(3)
+int dmv_part_vae_fwd(const VaeFwdArgs& a, size_t dyn_bytes, hipStream_t st) { DMV_DISPATCH_NT(a.enc.L.NT, launch_vae_fwd, a, dyn_bytes, st); }
+#endif
+
+#if DMV_PART(1)
 extern "C" int dmv_vae_forward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec) {
   return vae_forward_fits(cfg, enc, dec) ? 1 : 0;
 }
@@ -2774,8 +2822,9 @@ extern "C" int dmv_vae_forward(const DmvObjCfg* cfg, const DmvNet* enc, const fl
   a.eps = eps; a.eps_out = eps_out; a.Z = Z; a.ldz = ldz; a.seed = seed; a.offset = offset; a.offset_base = offset_base;
   a.ZP = 16 * dmv_ceil_div(cfg->Zd, 16);
   const size_t dyn = sizeof(float) * 16 * ((size_t)ldE + (size_t)a.ZP);
-  DMV_DISPATCH_NT(a.enc.L.NT, launch_vae_fwd, a, dyn, (hipStream_t)stream);
+  return dmv_part_vae_fwd(a, dyn, (hipStream_t)stream);
 }
+#endif
 
 // ---- LAIR's imputation update in one launch
 template <int NT>
@@ -2806,6 +2855,11 @@ static bool lair_fits(const DmvNet* enc, const DmvNet* dec, int B, int K, int n_
   return lair_dyn_bytes(enc, dec, K + n_prior, Zd, T, final_resample) + (size_t)NTe * 2048 + 64 <= 65536;
 }
 
+#if DMV_PART(3)
+int dmv_part_lair(const LairArgs& a, size_t dyn_bytes, hipStream_t st) { DMV_DISPATCH_NT(a.enc.L.NT, launch_lair, a, dyn_bytes, st); }
+#endif
+
+#if DMV_PART(1)
 extern "C" int dmv_lair_update_fits(const DmvNet* enc, const DmvNet* dec, int32_t B, int32_t K, int32_t n_prior, int32_t T,
                                     int32_t D, int32_t Zd, int32_t final_resample) {
   return lair_fits(enc, dec, B, K, n_prior, T, D, Zd, final_resample) ? 1 : 0;
@@ -2858,7 +2912,7 @@ static int sampler_update(int resample, const DmvNet* enc, const float* enc_pack
   a.M = M; a.X = X; a.clip_min = clip_min; a.clip_max = clip_max; a.buf = buf; a.idx_imp = idx_imp;
   a.lw_out = lw_out;
   const size_t dyn = lair_dyn_bytes(enc, dec, Kp, Zd, T, final_resample);
-  DMV_DISPATCH_NT(a.enc.L.NT, launch_lair, a, dyn, (hipStream_t)stream);
+  return dmv_part_lair(a, dyn, (hipStream_t)stream);
 }
 
 extern "C" int dmv_lair_update(const DmvNet* enc, const float* enc_packed, int32_t in_mode, const DmvNet* dec,
@@ -2887,6 +2941,8 @@ extern "C" int dmv_pgibbs_update(const DmvNet* enc, const float* enc_packed, int
                         nullptr, nullptr, noise, seed, off_eps, nullptr, off_tail, offset_base, clip_min, clip_max, buf, idx_imp,
                         nullptr, stream);
 }
+
+#endif
 
 // ---- backward host side
 // Work decomposition of the weight-gradient GEMMs.  A wave owns one block (up to bt x bt tiles) of one layer over
@@ -2952,6 +3008,7 @@ static int64_t wgrad_plan(const DmvNet* net, int64_t rows, WgradArgs* wa, Reduce
   return slab;
 }
 
+#if DMV_PART(1)
 extern "C" size_t dmv_mlp_backward_ws_bytes(const DmvNet* net, int64_t rows) {
   if (dmv_check_net(net) != DMV_OK || rows < 0) return 0;
   if (rows == 0) return 16;
@@ -3007,7 +3064,7 @@ static int mlp_backward_impl(const DmvNet* net, const float* packed, const float
       case 6: r2 = launch_bwd<6>(b, st); break;
       case 7: r2 = launch_bwd<7>(b, st); break;
       case 8: r2 = launch_bwd<8>(b, st); break;
-      default: r2 = [&]() -> int { DMV_DISPATCH_WIDE(b.L.NT, launch_bwd_wide, b, st); }();
+      default: r2 = dmv_part_bwd_wide(b, st);
     }
     if (r2) return r2;
   }
@@ -3055,6 +3112,8 @@ extern "C" int dmv_mlp_backward_wgrad(const DmvNet* net, const float* saved, con
 }
 
 // ---- decoder chain -> latent-side gradient -> encoder chain in one launch
+#endif
+
 template <int NT>
 static int launch_vae_bwd(const VaeBwdArgs& a, size_t dyn_bytes, hipStream_t st) {
   const int units = a.mix ? a.B : a.BG;
@@ -3073,6 +3132,11 @@ static bool vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const Dmv
   return true;
 }
 
+#if DMV_PART(3)
+int dmv_part_vae_bwd(const VaeBwdArgs& a, size_t dyn_bytes, hipStream_t st) { DMV_DISPATCH_NT(a.dec.L.NT, launch_vae_bwd, a, dyn_bytes, st); }
+#endif
+
+#if DMV_PART(1)
 extern "C" int dmv_vae_backward_fits(const DmvObjCfg* cfg, const DmvNet* enc, const DmvNet* dec, int32_t mixture) {
   return vae_backward_fits(cfg, enc, dec, mixture != 0) ? 1 : 0;
 }
@@ -3157,5 +3221,6 @@ extern "C" int dmv_vae_backward(const DmvObjCfg* cfg, const DmvLatentBwd* p, con
     a.dg_base_m = dg->base_m; a.dg_base_f = dg->base_f;
   }
   if (dyn + (size_t)a.dec.L.NT * 2048 + 64 > 65536) return DMV_E_UNSUPPORTED;
-  DMV_DISPATCH_NT(a.dec.L.NT, launch_vae_bwd, a, dyn, (hipStream_t)stream);
+  return dmv_part_vae_bwd(a, dyn, (hipStream_t)stream);
 }
+#endif

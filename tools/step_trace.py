@@ -25,6 +25,11 @@ if what == "toy":
     from demiss_vae_amd.bench_extra import demiss_toy_step
     step, refresh, (enc, dec) = demiss_toy_step(torch.device("cuda"), parts=True)
     B = 4096
+elif what == "toy64":
+    # the same model at the batch size its config trains with
+    from demiss_vae_amd.bench_extra import demiss_toy_step
+    step, refresh, (enc, dec) = demiss_toy_step(torch.device("cuda"), B=64, K=5, parts=True)
+    B = 64
 elif what == "uci":
     # UCI-gas DeMissVAE: LAIR update (one prior-replenish proposal, ten iterations, final resampling) + two objectives +
     # two backward passes + clip + Adam, B = 512, K = 5
