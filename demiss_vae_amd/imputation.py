@@ -324,7 +324,7 @@ def lair(dims: ModelDims, enc: PackedNet, dec: PackedNet, X, M, *, num_iteration
                                     L.ptr(idx_imp.reshape(-1).contiguous()) if (buf is not None and idx_imp is not None) else None,
                                     L.ptr(lw_dbg), st))
         if LAIR_DEBUG is not None:
-            LAIR_DEBUG["log_w"] = lw_dbg
+            LAIR_DEBUG["log_w"], LAIR_DEBUG["one_launch"] = lw_dbg, True
         return Xw.view(B, K, D)
 
     # all iterations' proposals and log-weights in place, for the final resampling: [T][(i b k)]
