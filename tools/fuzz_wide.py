@@ -43,7 +43,8 @@ def main():
         bad_dx = int((((a[1] - c[1]).abs() > 1e-3 * float(c[1].abs().max())).any(1)).sum())
         wg = max(float((p - q).abs().max()) / (float(q.abs().max()) + 1e-30) for p, q in zip(a[2], c[2]))
         fin = bool(torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all())
-        ok = fin and bad_y <= 4 and bad_dx <= 8 and wg < 2e-2
+        # without a flipped row the weight gradients agree to rounding; a flipped row changes some entries by its contribution
+        ok = fin and bad_y <= 4 and bad_dx <= 8 and wg < (5e-2 if bad_dx else 1e-4)
         print(f"{i:3d} {'ok ' if ok else 'BAD'} hidden={hidden} nb={nb} in={din} out={dout} rows={rows}: rows off y={bad_y} dx={bad_dx}, "
               f"worst weight-gradient diff {wg:.1e} of max", flush=True)
         bad += 0 if ok else 1
