@@ -520,9 +520,8 @@ struct FwdArgs {
 
 // Four consecutive first-layer inputs (columns k0 .. k0+3) of row r, branch-free: loads are unconditional with
 // the column clamped into the row, the input mode only selects between the loaded values.
-__device__ __forceinline__ f32x4 first_layer_input4(const FwdArgs& a, int64_t r, int k0) {
+__device__ __forceinline__ f32x4 first_layer_input4_of(const FwdArgs& a, const float* xr, const uint8_t* mr, int k0) {
   const bool use_mask = a.in_mode == DMV_IN_MASKED || a.in_mode == DMV_IN_CONCAT_MASKED;
-  const float* xr = a.x + r * a.ldx;
   f32x4 out;
   if (a.in_mode == DMV_IN_PLAIN) {   // uniform
 #pragma unroll
@@ -533,7 +532,6 @@ __device__ __forceinline__ f32x4 first_layer_input4(const FwdArgs& a, int64_t r,
     }
     return out;
   }
-  const uint8_t* mr = a.m + r * a.ldm;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int k = k0 + e;
@@ -544,6 +542,10 @@ __device__ __forceinline__ f32x4 first_layer_input4(const FwdArgs& a, int64_t r,
     out[e] = k < a.in_dim ? (k < a.D ? head : mv) : 0.f;
   }
   return out;
+}
+
+__device__ __forceinline__ f32x4 first_layer_input4(const FwdArgs& a, int64_t r, int k0) {
+  return first_layer_input4_of(a, a.x + r * a.ldx, a.in_mode == DMV_IN_PLAIN ? nullptr : a.m + r * a.ldm, k0);
 }
 
 // SAVE: training forward (stores the first-layer input and every hidden activation for the backward;
@@ -1173,6 +1175,7 @@ struct Rows16 {
   static constexpr int NK = 2 * NT;                       // 16-wide tiles of the hidden width
   static constexpr int TW = 2 * ((NT + W - 1) / W);       // output tiles per wave (whole 32-wide tiles: sign-bit halfwords)
   static constexpr int PF = W == 8 ? 4 : 2;               // input tiles a weight fragment is requested ahead of its use
+                                                          // (3 and 4 were measured in the one-launch sampler: slower)
   static constexpr int LDS_BYTES = NK * 1024;
 };
 template <int NT, int W> using R16Slice = f32x4[Rows16<NT, W>::TW];   // a wave's output tiles of a layer
@@ -1550,16 +1553,19 @@ __global__ __launch_bounds__(256, 1) void k_lair_rows16(LairArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[Rows16<NT, W>::LDS_BYTES / 4];
   extern __shared__ __attribute__((aligned(16))) float tile[];
   const int ldE = a.ldE, ldD = a.ldD, ZP = a.ZP, Zd = a.Zd, Kp = a.Kp, K = a.K, D = a.D;
-  const int PW = Kp + 2;                         // per row: Kp component log densities, log p(x_o | z), log p(z)
   float* et = tile;                              // [16][ldE] encoder outputs
   float* zt = et + 16 * ldE;                     // [16][ZP] proposals (the decoder's input)
   float* dt = zt + 16 * ZP;                      // [16][ldD] decoder outputs
   QEntry* qt = (QEntry*)(dt + 16 * ldD);         // [16][Zd] the components' Gaussians
-  float* part = (float*)(qt + 16 * Zd);          // [16][PW]
-  float* lw = part + ((16 * PW + 3) & ~3);       // [16] log-weights of this iteration
+  float* lw = (float*)(qt + 16 * Zd);            // [16] log-weights of this iteration
   int* pick = (int*)(lw + 16);                   // [16] tile row (or pooled row) chosen for output row (dp, k)
   float* lwall = (float*)(pick + 16);            // [T][16]       final resampling only
   float* zall = lwall + 16 * a.T;                // [T][16][Zd]   final resampling only
+  const int RX = a.DP * K;                       // imputation rows of a tile
+  float* xs = zall + (a.final_resample ? 16 * a.T * Zd : 0);   // [RX][D] the tile's imputations, updated in place
+  float* nzs = xs + RX * D;                      // [RX][D] this iteration's sampling noise
+  float* us = nzs + RX * D;                      // [16] this iteration's resampling uniforms
+  uint8_t* ms = (uint8_t*)(us + 16);             // [RX][D] the imputations' masks
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, g = lane >> 4;
@@ -1570,7 +1576,7 @@ __global__ __launch_bounds__(256, 1) void k_lair_rows16(LairArgs a) {
   // this lane's tile row as a proposal, and the encoder row it draws from (a replenish proposal has none: it rides
   // along on a neighbour's and ignores the result)
   const int dpm = m / Kp, km = m - dpm * Kp;
-  const int64_t er = (int64_t)(b0 + (dpm < nb ? dpm : 0)) * K + (km < K ? km : K - 1);
+  const int er = (dpm < nb ? dpm : 0) * K + (km < K ? km : K - 1);          // row of xs / ms
   const uint64_t base = a.offset_base ? a.offset_base[0] : 0ull;
   const int64_t NZ = (int64_t)a.B * Kp, NX = (int64_t)a.B * K;
   const bool normal = a.gen_dist <= DMV_GEN_NORMAL_EPS;
@@ -1578,28 +1584,40 @@ __global__ __launch_bounds__(256, 1) void k_lair_rows16(LairArgs a) {
   TailArgs ta;
   ta.D = D; ta.gen_dist = a.gen_dist; ta.clip_min = a.clip_min; ta.clip_max = a.clip_max; ta.clip_after_blend = a.resample;
   if (!a.resample && tid < 16) pick[tid] = tid;   // (ordered before its first reader by the barriers of the passes below)
+  // the tile's imputations and masks: global memory sees them again when the update is over
+  const int nx = nb * K * D;                     // (a tile's rows are consecutive in X and M)
+  for (int e = tid; e < nx; e += 256) {
+    xs[e] = a.X[(int64_t)b0 * K * D + e];
+    ms[e] = a.M[(int64_t)b0 * K * D + e];
+  }
+  __syncthreads();
 
-  auto decode = [&]() {
-    r16_forward_chain<NT, false, false, W>(
-        a.dec, lds, lane, wv, 0, 0, false, [&](int k0) { return *(const f32x4*)(zt + m * ZP + k0); },
-        [&](int ot, f32x4 o) { *(f32x4*)(dt + m * ldD + 16 * ot + 4 * g) = o; });
-    __syncthreads();
+  // sampling noise of element e of the tile's imputations, noise set `tn`
+  auto tail_noise = [&](int tn, int e) {
+    const int64_t i = (int64_t)b0 * K * D + e;
+    return a.noise ? a.noise[(int64_t)tn * NX * D + i]
+                   : normal ? dmv_philox_normal(a.seed, a.off_tail[tn] + base + (uint64_t)i)
+                            : dmv_philox_uniform(a.seed, a.off_tail[tn] + base + (uint64_t)i);
   };
-  // new imputations of the tile's datapoints from the decoder rows pick[] names, noise set `tn`
-  auto tail = [&](const TailArgs& tt, int tn, bool write_buf) {
+  // The noise of an iteration does not depend on anything the iteration computes: the last threads of the workgroup
+  // draw it (into nzs) while the first ones are busy with the log-weights, so the tail finds it ready.
+  auto draw_tail_noise = [&](int tn) {
+    for (int e = 255 - tid; e < nx; e += 256) nzs[e] = tail_noise(tn, e);
+  };
+  // new imputations of the tile's datapoints from the decoder rows pick[] names; noise from nzs, or set `tn` drawn here
+  auto tail = [&](const TailArgs& tt, int tn, bool ready, bool write_out) {
     const int per_dp = K * D;
-    for (int e = tid; e < nb * per_dp; e += 256) {
+    for (int e = tid; e < nx; e += 256) {
       const int dp2 = e / per_dp, rem = e - dp2 * per_dp;
       const int k2 = rem / D, d = rem - k2 * D;
-      const int64_t n = (int64_t)(b0 + dp2) * K + k2;
-      const int64_t i = n * D + d;
       const float* dec = dt + pick[dp2 * K + k2] * ldD;
-      const float nz = a.noise ? a.noise[(int64_t)tn * NX * D + i]
-                               : normal ? dmv_philox_normal(a.seed, a.off_tail[tn] + base + (uint64_t)i)
-                                        : dmv_philox_uniform(a.seed, a.off_tail[tn] + base + (uint64_t)i);
-      const float out = tail_element(tt, dec, d, nz, a.X[i], a.M[i] != 0);
-      a.X[i] = out;
-      if (write_buf && a.buf) a.buf[a.idx_imp[n] * D + d] = out;
+      const float out = tail_element(tt, dec, d, ready ? nzs[e] : tail_noise(tn, e), xs[e], ms[e] != 0);
+      xs[e] = out;
+      if (write_out) {
+        const int64_t n = (int64_t)(b0 + dp2) * K + k2;
+        a.X[n * D + d] = out;
+        if (a.buf) a.buf[a.idx_imp[n] * D + d] = out;
+      }
     }
   };
   // inverse-CDF draw from softmax of P log-weights l(p), p = 0 .. P-1 (the order of dmv_categorical_draw)
@@ -1617,12 +1635,59 @@ __global__ __launch_bounds__(256, 1) void k_lair_rows16(LairArgs a) {
     return P - 1;
   };
 
-  for (int t = 0; t < a.T; ++t) {
-    // ---- encoder on the current imputations
-    r16_forward_chain<NT, false, false, W>(
-        a.enc, lds, lane, wv, er, er, false, [&](int k0) { return first_layer_input4(a.enc, er, k0); },
-        [&](int ot, f32x4 o) { *(f32x4*)(et + m * ldE + 16 * ot + 4 * g) = o; });
-    __syncthreads();
+  // Every network pass of the update - T encoder and T decoder passes, and the decoder pass of the final resampling -
+  // goes through the ONE call of the chain below (one copy of its code in the kernel instead of three).
+  const int n_pass = 2 * a.T + (a.final_resample ? 1 : 0);
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const int t = pass >> 1;
+    const bool fin = pass == 2 * a.T;              // the decoder pass of the final resampling
+    const bool is_dec = (pass & 1) || fin;
+    // (tuning build: phase stamps of the second iteration)
+#define LTRACE(i) do { if (t == 1) TRACE(i); } while (0)
+    if (fin) {
+      // ---- K latents per datapoint from the pooled T Kp proposals, decoded once more; no clamping (:657-666)
+      if (tid < nb * K) {
+        const int dp2 = tid / K, k2 = tid - dp2 * K;
+        const int64_t b2 = b0 + dp2;
+        int v;
+        if (a.final_draws) {
+          v = (int)a.final_draws[b2 * K + k2];
+        } else {
+          const float u = dmv_philox_uniform(a.seed, a.off_draw[a.T] + base + (uint64_t)(b2 * K + k2));
+          v = draw(a.T * Kp, u, [&](int p) { const int tt = p / Kp; return lwall[tt * 16 + dp2 * Kp + (p - tt * Kp)]; });
+        }
+        const int tt = v / Kp;
+        pick[tid] = tt * 16 + dp2 * Kp + (v - tt * Kp);
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 16 * ZP; idx += 256) {
+        const int mm = idx / ZP, j = idx - mm * ZP;
+        zt[mm * ZP + j] = (mm < nb * K && j < Zd) ? zall[(size_t)pick[mm] * Zd + j] : 0.f;
+      }
+      __syncthreads();
+      if (tid < 16) pick[tid] = tid;               // output row (dp, k) decodes in tile row dp K + k (the pass's barriers
+    }                                              // order this after the gather and before the tail)
+    if (!is_dec) LTRACE(0);
+    // ---- the encoder on the current imputations, or the decoder on the proposals
+    {
+      const FwdArgs& net = is_dec ? a.dec : a.enc;
+      float* orow = is_dec ? dt + m * ldD : et + m * ldE;
+      r16_forward_chain<NT, false, false, W>(
+          net, lds, lane, wv, 0, 0, false,
+          [&](int k0) {
+            return is_dec ? *(const f32x4*)(zt + m * ZP + k0) : first_layer_input4_of(a.enc, xs + er * D, ms + er * D, k0);
+          },
+          [&](int ot, f32x4 o) { *(f32x4*)(orow + 16 * ot + 4 * g) = o; });
+      __syncthreads();
+    }
+    if (fin) {
+      TailArgs tf = ta;
+      tf.clip_min = nullptr; tf.clip_max = nullptr; tf.clip_after_blend = 0;
+      tail(tf, a.T, false, true);
+      break;
+    }
+    if (!is_dec) {
+    LTRACE(1);
     // ---- proposals z = mu + sigma eps and the table of the components' Gaussians
     for (int idx = tid; idx < 16 * ZP; idx += 256) {
       const int mm = idx / ZP, j = idx - mm * ZP;
@@ -1644,103 +1709,99 @@ __global__ __launch_bounds__(256, 1) void k_lair_rows16(LairArgs a) {
       zt[mm * ZP + j] = z;
     }
     __syncthreads();
-    decode();
+    LTRACE(2);
+    continue;
+    }
+    LTRACE(3);
     if (!a.resample) {
-      tail(ta, t, t == a.T - 1);
+      tail(ta, t, false, t == a.T - 1);
       __syncthreads();
       continue;
     }
+    draw_tail_noise(t);
     // ---- DMIS log-weights: log p(x_o | z) + log p(z) - log (1 / Kp) sum_c q_c(z), the observed entries under the mask of
-    // the datapoint's first imputation (:407) and that imputation's values
-    if (tid < 16 * PW) {
-      const int p = tid / PW, c = tid - p * PW;
-      float v = 0.f;
+    // the datapoint's first imputation (:407) and that imputation's values.  A group of 16 lanes per proposal: the lanes
+    // share out the dimensions of every sum, so a wavefront runs one short instruction stream for its four proposals.
+    {
+      const int p = tid >> 4, l16 = tid & 15;
       if (p < live_rows) {
         const int dp2 = p / Kp;
         const float* z = zt + p * ZP;
-        if (c < Kp) {
+        float pr = 0.f;
+        for (int j = l16; j < Zd; j += 16) { const float zj = z[j]; pr += -(zj * zj) * 0.5f - LOG_SQRT_2PI; }
+        pr = gsum<16>(pr);
+        const int r0 = (dp2 < nb ? dp2 : 0) * K * D;
+        const float* x0 = xs + r0;
+        const uint8_t* m0 = ms + r0;
+        const float* dec = dt + p * ldD;
+        float gm = 0.f;
+        for (int d = l16; d < D; d += 16) {
+          const float x = x0[d];
+          float lp;
+          if (normal) lp = log_normal_r(x, dec[d], dmv_softplus(dec[D + d]) + geps);
+          else if (a.gen_dist == DMV_GEN_BERN) lp = log_bern(x, dec[d]);
+          else lp = log_bern((x + 1.f) * 0.5f, dec[d]);
+          gm += lp * (m0[d] ? 1.f : 0.f);          // (the product the reference forms: non-finite under a missing entry -> NaN)
+        }
+        gm = gsum<16>(gm);
+        float mx = -INFINITY, se = 0.f;
+        for (int c = 0; c < Kp; ++c) {
           const QEntry* q = qt + (dp2 * Kp + c) * Zd;
-          for (int j = 0; j < Zd; ++j) v += q_logp(q[j], z[j]);
-        } else if (c == Kp) {
-          const int64_t r0 = (int64_t)(b0 + (dp2 < nb ? dp2 : 0)) * K * D;
-          const float* x0 = a.X + r0;
-          const uint8_t* m0 = a.M + r0;
-          const float* dec = dt + p * ldD;
-          for (int d = 0; d < D; ++d) {
-            const float x = x0[d];
-            float lp;
-            if (normal) lp = log_normal_r(x, dec[d], dmv_softplus(dec[D + d]) + geps);
-            else if (a.gen_dist == DMV_GEN_BERN) lp = log_bern(x, dec[d]);
-            else lp = log_bern((x + 1.f) * 0.5f, dec[d]);
-            v += lp * (m0[d] ? 1.f : 0.f);       // (the product the reference forms: non-finite under a missing entry -> NaN)
-          }
-        } else {
-          for (int j = 0; j < Zd; ++j) { const float zj = z[j]; v += -(zj * zj) * 0.5f - LOG_SQRT_2PI; }
+          float v = 0.f;
+          for (int j = l16; j < Zd; j += 16) v += q_logp(q[j], z[j]);
+          v = gsum<16>(v);
+          const float nm = fmaxf(mx, v);
+          se = se * dmv_exp(mx - nm) + dmv_exp(v - nm);
+          mx = nm;
+        }
+        const float w = gm + pr - (mx + dmv_log(se) - dmv_log((float)Kp));
+        if (l16 == 0) {
+          lw[p] = w;
+          if (a.final_resample) lwall[t * 16 + p] = w;
+          if (a.lw_out && dp2 < nb) a.lw_out[((int64_t)t * a.B + b0 + dp2) * Kp + (p - dp2 * Kp)] = w;
         }
       }
-      part[p * PW + c] = v;
-    }
-    __syncthreads();
-    if (tid < live_rows) {
-      const float* pp = part + tid * PW;
-      float mx = -INFINITY, se = 0.f;
-      for (int c = 0; c < Kp; ++c) {
-        const float tt = pp[c], nm = fmaxf(mx, tt);
-        se = se * dmv_exp(mx - nm) + dmv_exp(tt - nm);
-        mx = nm;
+      // the resampling uniforms, by the last wavefront (whose proposals are the padding rows of most tiles)
+      if (tid >= 192 && tid - 192 < nb * K && !a.draws) {
+        const int o = tid - 192, dp2 = o / K;
+        us[o] = dmv_philox_uniform(a.seed, a.off_draw[t] + base + (uint64_t)((int64_t)(b0 + dp2) * Kp + (o - dp2 * K)));
       }
-      const float w = pp[Kp] + pp[Kp + 1] - (mx + dmv_log(se) - dmv_log((float)Kp));
-      lw[tid] = w;
-      if (a.final_resample) lwall[t * 16 + tid] = w;
-      const int dp2 = tid / Kp;
-      if (a.lw_out && dp2 < nb) a.lw_out[((int64_t)t * a.B + b0 + dp2) * Kp + (tid - dp2 * Kp)] = w;
     }
     __syncthreads();
-    // ---- resampling: of the Kp draws per datapoint the first K are kept (:521-524)
-    if (tid < nb * K) {
-      const int dp2 = tid / K, kd = tid - dp2 * K;
-      const int64_t b2 = b0 + dp2;
-      int pk;
-      if (a.draws) {
-        pk = (int)a.draws[((int64_t)t * a.B + b2) * Kp + kd];
-      } else {
-        const float u = dmv_philox_uniform(a.seed, a.off_draw[t] + base + (uint64_t)(b2 * Kp + kd));
-        const float* l = lw + dp2 * Kp;
-        pk = draw(Kp, u, [&](int p) { return l[p]; });
+    LTRACE(4);
+    LTRACE(5);
+    // ---- resampling: of the Kp draws per datapoint the first K are kept (:521-524).  A group of 16 lanes per draw: the
+    // lanes hold the proposals' probabilities, a prefix sum gives the distribution function
+    {
+      const int o = tid >> 4, l16 = tid & 15;
+      if (o < nb * K) {
+        const int dp2 = o / K, kd = o - dp2 * K;
+        int pk;
+        if (a.draws) {
+          pk = (int)a.draws[((int64_t)t * a.B + b0 + dp2) * Kp + kd];
+        } else {
+          const float lv = l16 < Kp ? lw[dp2 * Kp + l16] : -INFINITY;
+          const float mx = group_max<16>(lv);
+          float c = l16 < Kp ? expf(lv - mx) : 0.f;
+#pragma unroll
+          for (int off = 1; off < 16; off <<= 1) {
+            const float up = __shfl_up(c, off, 16);
+            if (l16 >= off) c += up;
+          }
+          const float target = us[o] * __shfl(c, 15, 16);
+          const unsigned long long hit = __ballot(l16 < Kp && c > target);
+          const unsigned mine = (unsigned)(hit >> (16 * (lane >> 4))) & 0xffffu;
+          pk = mine ? __ffs(mine) - 1 : Kp - 1;
+        }
+        if (l16 == 0) pick[o] = dp2 * Kp + pk;
       }
-      pick[tid] = dp2 * Kp + pk;
     }
     __syncthreads();
-    tail(ta, t, t == a.T - 1 && !a.final_resample);
+    LTRACE(6);
+    tail(ta, t, true, t == a.T - 1 && !a.final_resample);
     __syncthreads();                              // the next encoder pass reads the new imputations
-  }
-
-  if (a.final_resample) {
-    // ---- K latents per datapoint from the pooled T Kp proposals, decoded once more; no clamping (:657-666)
-    if (tid < nb * K) {
-      const int dp2 = tid / K, k2 = tid - dp2 * K;
-      const int64_t b2 = b0 + dp2;
-      int v;
-      if (a.final_draws) {
-        v = (int)a.final_draws[b2 * K + k2];
-      } else {
-        const float u = dmv_philox_uniform(a.seed, a.off_draw[a.T] + base + (uint64_t)(b2 * K + k2));
-        v = draw(a.T * Kp, u, [&](int p) { const int tt = p / Kp; return lwall[tt * 16 + dp2 * Kp + (p - tt * Kp)]; });
-      }
-      const int tt = v / Kp;
-      pick[tid] = tt * 16 + dp2 * Kp + (v - tt * Kp);
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 16 * ZP; idx += 256) {
-      const int mm = idx / ZP, j = idx - mm * ZP;
-      zt[mm * ZP + j] = (mm < nb * K && j < Zd) ? zall[(size_t)pick[mm] * Zd + j] : 0.f;
-    }
-    __syncthreads();
-    if (tid < 16) pick[tid] = tid;                // output row (dp, k) decodes in tile row dp K + k
-    decode();                                     // (its leading barriers order the pick update after the gather)
-    TailArgs tf = ta;
-    tf.clip_min = nullptr; tf.clip_max = nullptr; tf.clip_after_blend = 0;
-    tail(tf, a.T, true);
+    LTRACE(7);
+#undef LTRACE
   }
 }
 
@@ -2836,11 +2897,13 @@ static int launch_lair(const LairArgs& a, size_t dyn_bytes, hipStream_t st) {
   return DMV_OK;
 }
 
-static size_t lair_dyn_bytes(const DmvNet* enc, const DmvNet* dec, int Kp, int Zd, int T, int final_resample) {
+static size_t lair_dyn_bytes(const DmvNet* enc, const DmvNet* dec, int K, int Kp, int D, int Zd, int T, int final_resample) {
   const size_t ldE = (size_t)dmv_pad32(enc->out_dim), ldD = (size_t)dmv_pad32(dec->out_dim), ZP = 16 * (size_t)dmv_ceil_div(Zd, 16);
-  size_t fl = 16 * (ldE + ZP + ldD) + 16 * (size_t)Zd * 4 + ((16 * (size_t)(Kp + 2) + 3) & ~(size_t)3) + 16 + 16;
+  size_t fl = 16 * (ldE + ZP + ldD) + 16 * (size_t)Zd * 4 + 16 + 16;
   fl += 16 * (size_t)T;                                       // (the pooled log-weights' slot exists either way)
   if (final_resample) fl += 16 * (size_t)T * Zd;
+  const size_t rx = (size_t)(16 / Kp) * (size_t)K;            // imputation rows of a tile: values, noise, uniforms, masks
+  fl += 2 * rx * D + 16 + (rx * D + 3) / 4;
   return fl * sizeof(float);
 }
 
@@ -2852,7 +2915,7 @@ static bool lair_fits(const DmvNet* enc, const DmvNet* dec, int B, int K, int n_
   const int NTe = dmv_ceil_div(enc->hidden, 32), NTd = dmv_ceil_div(dec->hidden, 32);
   if (NTe != NTd || NTe > 8) return false;
   if (dec->in_dim != Zd || enc->out_dim < 2 * Zd || Zd > 256) return false;
-  return lair_dyn_bytes(enc, dec, K + n_prior, Zd, T, final_resample) + (size_t)NTe * 2048 + 64 <= 65536;
+  return lair_dyn_bytes(enc, dec, K, K + n_prior, D, Zd, T, final_resample) + (size_t)NTe * 2048 + 64 <= 65536;
 }
 
 #if DMV_PART(3)
@@ -2911,7 +2974,7 @@ static int sampler_update(int resample, const DmvNet* enc, const float* enc_pack
   a.eps = eps; a.draws = draws; a.final_draws = final_draws; a.noise = noise;
   a.M = M; a.X = X; a.clip_min = clip_min; a.clip_max = clip_max; a.buf = buf; a.idx_imp = idx_imp;
   a.lw_out = lw_out;
-  const size_t dyn = lair_dyn_bytes(enc, dec, Kp, Zd, T, final_resample);
+  const size_t dyn = lair_dyn_bytes(enc, dec, K, Kp, D, Zd, T, final_resample);
   return dmv_part_lair(a, dyn, (hipStream_t)stream);
 }
 
