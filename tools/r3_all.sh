@@ -21,4 +21,4 @@ tail -1 $O/runner_toy.log
 timeout -k 10 300 python tools/fuzz_samplers.py 100 11 > $O/fuzz_samplers.log 2>&1 || { grep -v " ok " $O/fuzz_samplers.log | tail; exit 1; }
 timeout -k 10 300 python tools/fuzz_one_launch.py 100 12 > $O/fuzz_one_launch.log 2>&1 || { grep -v " ok " $O/fuzz_one_launch.log | tail; exit 1; }
 timeout -k 10 300 python tools/fuzz_wide.py 16 13 > $O/fuzz_wide.log 2>&1 || { grep -v " ok " $O/fuzz_wide.log | tail; exit 1; }
-tail -1 $O/fuzz_samplers.log $O/fuzz_one_launch.log $O/fuzz_wide.log
+for f in $O/fuzz_samplers.log $O/fuzz_one_launch.log $O/fuzz_wide.log; do tail -n 1 $f; done
