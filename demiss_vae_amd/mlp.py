@@ -7,6 +7,7 @@ parameter's version counter or address moved (load_state_dict, manual in-place e
 row-major buffers; `ResidualMLPFunction` exposes one network call to autograd.
 """
 import ctypes as C
+import os
 import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
@@ -177,12 +178,34 @@ class PackedNet:
                 if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev or not t.is_cuda:
                     raise RuntimeError("network parameters must be contiguous fp32 CUDA tensors on one device")
             if self._packed is None or self._packed.device != dev:
-                self._packed = torch.empty(self._n_packed, dtype=torch.float32, device=dev)
+                self._packed = _image_storage(self._n_packed, dev)
             L.check(L.lib().dmv_mlp_pack(C.byref(self.c), L.ptr_array([w.detach() for w in self.weights]),
                                          L.ptr_array([b.detach() for b in self.biases]),
                                          L.ptr(self._packed), L.stream_ptr()))
             self._stamp = stamp
         return self._packed
+
+
+# Weight images come out of one slab per device (bump allocation, 4 KiB granules; images that no longer fit get a tensor
+# of their own).  Every workgroup of the small-batch kernels streams both networks' images from L2 over and over, and where
+# two separately allocated 2 MB images fall in memory decides whether they stay there: measured in the one-launch sampler,
+# the decoder's chain took 59 k cycles with the caching allocator's placement and 52.6 k - the encoder's time - with both
+# images in one large allocation, at any offsets within it.
+IMAGE_SLAB_BYTES = int(os.environ.get("DMV_IMAGE_SLAB_MB", "64")) << 20
+_image_slabs = {}
+
+
+def _image_storage(n_floats: int, dev) -> torch.Tensor:
+    nbytes = (4 * n_floats + 4095) & ~4095
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    slab = _image_slabs.get(key)
+    if slab is None and IMAGE_SLAB_BYTES > 0:
+        slab = _image_slabs[key] = [torch.empty(IMAGE_SLAB_BYTES, dtype=torch.uint8, device=dev), 0]
+    if slab is None or slab[1] + nbytes > slab[0].numel():
+        return torch.empty(n_floats, dtype=torch.float32, device=dev)
+    off = slab[1]
+    slab[1] = off + nbytes
+    return slab[0][off: off + 4 * n_floats].view(torch.float32)
 
 
 class GeneratedDropout:

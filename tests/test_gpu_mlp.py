@@ -491,3 +491,32 @@ def test_groups_keep_their_device_scalars_when_their_rates_part():
         for p, q in zip(mine, ref):
             torch.testing.assert_close(p, q, rtol=1e-5, atol=5e-7)
     assert float(a.state_dict()["state"][0]["step"]) == 6
+
+
+@pytest.mark.gpu
+def test_weight_images_share_a_slab_and_fall_back_when_it_is_full():
+    """The first weight images of a process are views of one allocation (4 KiB granules); one that no longer fits gets a
+    tensor of its own; either way the forward pass is the same."""
+    import demiss_vae_amd as dmv
+    from demiss_vae_amd import mlp, synth
+    dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev.type, dev.index)
+    saved, saved_bytes = mlp._image_slabs.pop(key, None), mlp.IMAGE_SLAB_BYTES
+    try:
+        mlp.IMAGE_SLAB_BYTES = 6 << 20
+        shape = synth.NetShape(16, 16, 2, 256)
+        nets = [synth.packed_net(shape, 3, "cuda", requires_grad=False) for _ in range(4)]
+        imgs = [n.packed() for n in nets]
+        slab = mlp._image_slabs[key][0]
+        lo, hi = slab.data_ptr(), slab.data_ptr() + slab.numel()
+        inside = [lo <= t.data_ptr() < hi for t in imgs]
+        assert inside[:2] == [True, True] and not inside[3], inside            # 2.2 MB each: two fit in 6 MB
+        assert all(t.data_ptr() % 4096 == 0 for t, ok in zip(imgs, inside) if ok)
+        x = torch.randn(100, 16, device="cuda")
+        ys = [dmv.mlp_forward(n, x, 16, 100)[0] for n in nets]
+        assert all(torch.equal(ys[0], y) for y in ys[1:])
+    finally:
+        mlp.IMAGE_SLAB_BYTES = saved_bytes
+        mlp._image_slabs.pop(key, None)
+        if saved is not None:
+            mlp._image_slabs[key] = saved

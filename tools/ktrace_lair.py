@@ -24,6 +24,11 @@ if os.environ.get("KT_PAD"):        # (experiment: another allocation between us
     _pad = torch.empty(int(os.environ["KT_PAD"]), dtype=torch.uint8, device="cuda")
     enc = synth.packed_net(synth.NetShape(D, 2 * Zd, 2, 256), 1, "cuda", requires_grad=False)
     dec = synth.packed_net(synth.NetShape(Zd, 2 * D, 2, 256), 2, "cuda", requires_grad=False)
+if os.environ.get("KT_AT"):         # (experiment: the two images at chosen byte offsets of one 64 MB arena)
+    oe, od = (int(v, 0) for v in os.environ["KT_AT"].split(","))
+    arena = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    for net, off in ((enc, oe), (dec, od)):
+        net._packed = arena[off: off + 4 * net._n_packed].view(torch.float32)
 print("weight images at", hex(enc.packed().data_ptr()), hex(dec.packed().data_ptr()), "bytes", enc.packed().numel() * 4)
 dims = dmv.ModelDims(D=D, Zd=Zd, gen_dist="normal_with_eps", q_dist="normal_with_eps", encoder_use_mis_mask=False)
 X1, M1 = (t.cuda() for t in synth.batch(3, B, D))
