@@ -96,6 +96,8 @@ SIGNATURES = {
     "dmv_vae_forward_fits": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), C.POINTER(DmvNet)]),
     "dmv_vae_forward": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), _P, _I32, _P, _P, C.POINTER(DmvNet), _P, _P, _U64, _U64,
                                   _P, _I32, _F, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "dmv_vae_forward_bound": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), _P, _I32, _P, _P, C.POINTER(DmvNet), _P, _P, _U64,
+                                        _U64, _P, _P, _P, _P, _I64, _P, _P, _P, C.POINTER(DmvObjFwd), _P]),
     "dmv_lair_update_fits": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
     "dmv_lair_update": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_float, _I32, _P, _P, _P,
                                   _P, _P, _P, _U64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -1441,6 +1441,15 @@ struct VaeFwdArgs {
   uint64_t seed, offset;
   const uint64_t* offset_base;
   int ZP;                     // latent width rounded up to 16: pitch of the latent tile in LDS
+  // The IWAE / VAE bound in the same launch (one Gaussian per datapoint, G = 1): tiles are then datapoint-major - the
+  // S = nz I samples of 16 / S datapoints - so the logsumexp over a datapoint's samples stays inside the workgroup.
+  int obj_on, S, nz, I, D, gen_dist, dreg;
+  float* log_w;               // nullable [N]
+  float* bound;               // [B]
+  float* wgt;                 // nullable [N]
+  float* zscale;              // nullable [N]
+  unsigned* ticket;           // nullable: with it the launch also forms the batch mean
+  float* mean; float* neg_mean;
 };
 
 template <int NT, bool SAVE>
@@ -1448,16 +1457,23 @@ __global__ __launch_bounds__(256, 1) void k_vae_fwd_rows16(VaeFwdArgs a) {
   constexpr int W = 4;
   __shared__ __attribute__((aligned(16))) float lds[Rows16<NT, W>::LDS_BYTES / 4];
   __shared__ int par_off[16];                                  // where a row's (mu | raw sigma) start inside its encoder row
+  __shared__ int nrow[16];                                     // sample row of a tile row, -1: none
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [16][ldE] encoder outputs, then [16][ZP] latents
-  const int ldE = (int)a.enc.ldy;
+  const int ldE = (int)a.enc.ldy, ldD = (int)a.dec.ldy;
   float* et = tile;
   float* zt = tile + 16 * ldE;
+  float* dt = zt + 16 * a.ZP;                                  // [16][ldD] decoder outputs (with the bound only)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 15, g = lane >> 4;
-  const int64_t n = (int64_t)blockIdx.x * 16 + m;
-  const bool live = n < a.N;
-  const int nl = (int)(live ? n : a.N - 1);                    // N <= 4096 rows here
+  int64_t n = (int64_t)blockIdx.x * 16 + m;
+  bool live = n < a.N;
+  if (a.obj_on) {                                              // tile row (q, s): sample s of the tile's q-th datapoint
+    const int Q = 16 / a.S, q = m / a.S, bq = (int)blockIdx.x * Q + q;
+    live = q < Q && bq < a.B;
+    n = live ? (int64_t)(m - q * a.S) * a.B + bq : 0;
+  }
+  const int nl = (int)(live ? n : (a.obj_on ? 0 : a.N - 1));   // N <= 4096 rows here
   const int BG = a.B * a.G;
   const int bg = nl % BG;
   const int b = bg / a.G, comp = bg - b * a.G;
@@ -1468,8 +1484,10 @@ __global__ __launch_bounds__(256, 1) void k_vae_fwd_rows16(VaeFwdArgs a) {
   const int orow = a.per_comp ? bg : b;
   // the first sample of an encoder row stores what the encoder pass saves and the row's outputs
   const bool owner = live && nl < BG && !prior && (a.per_comp || comp == 0);
-  if (wv == 0 && g == 0)
+  if (wv == 0 && g == 0) {
     par_off[m] = prior ? -1 : (int)((int64_t)b * a.q.sb + (int64_t)comp * a.q.sg - (int64_t)orow * ldE);
+    nrow[m] = live ? nl : -1;
+  }
 
   r16_forward_chain<NT, SAVE, false, W>(
       a.enc, lds, lane, wv, er, er, owner, [&](int k0) { return first_layer_input4(a.enc, er, k0); },
@@ -1485,7 +1503,7 @@ __global__ __launch_bounds__(256, 1) void k_vae_fwd_rows16(VaeFwdArgs a) {
     const int JW = a.ZP > (int)a.ldz ? a.ZP : (int)a.ldz;
     for (int idx = threadIdx.x; idx < 16 * JW; idx += 256) {
       const int mm = idx / JW, j = idx - mm * JW;
-      const int64_t n2 = (int64_t)blockIdx.x * 16 + mm;
+      const int64_t n2 = nrow[mm] >= 0 ? nrow[mm] : a.N;
       float z = 0.f, e = 0.f;
       if (j < a.Zd) {
         const int po = par_off[mm];
@@ -1505,9 +1523,101 @@ __global__ __launch_bounds__(256, 1) void k_vae_fwd_rows16(VaeFwdArgs a) {
   }
   __syncthreads();
 
+  if (!a.obj_on) {
+    r16_forward_chain<NT, SAVE, false, W>(
+        a.dec, lds, lane, wv, n, nl, true, [&](int k0) { return *(const f32x4*)(zt + m * a.ZP + k0); },
+        [&](int ot, f32x4 o) { if (live) *(f32x4*)(a.dec.y + n * a.dec.ldy + 16 * ot + 4 * g) = o; });
+    return;
+  }
   r16_forward_chain<NT, SAVE, false, W>(
-      a.dec, lds, lane, wv, n, nl, true, [&](int k0) { return *(const f32x4*)(zt + m * a.ZP + k0); },
-      [&](int ot, f32x4 o) { if (live) *(f32x4*)(a.dec.y + n * a.dec.ldy + 16 * ot + 4 * g) = o; });
+      a.dec, lds, lane, wv, nl, nl, live, [&](int k0) { return *(const f32x4*)(zt + m * a.ZP + k0); },
+      [&](int ot, f32x4 o) {
+        *(f32x4*)(dt + m * ldD + 16 * ot + 4 * g) = o;
+        if (live) *(f32x4*)(a.dec.y + n * a.dec.ldy + 16 * ot + 4 * g) = o;
+      });
+  __syncthreads();
+
+  // ---- the bound (vgiwae/shared/iwae.py:9-55 log-weights, vgiwae/models/iwae.py:70-123 logsumexp and mean): a group of
+  // 16 lanes per sample row shares out the dimensions of its three sums
+  __shared__ float lw[16], bz[16], sh[32];
+  __shared__ unsigned last;
+  const int tid = threadIdx.x;
+  {
+    const int p = tid >> 4, l16 = tid & 15;
+    const int np = nrow[p];
+    if (np >= 0) {
+      const int bb = np % a.B;
+      const float* z = zt + p * a.ZP;
+      const float* pe = et + p * ldE + par_off[p];
+      float pr = 0.f, qo = 0.f;
+      for (int j = l16; j < a.Zd; j += 16) {
+        const float zj = z[j];
+        pr += -(zj * zj) * 0.5f - LOG_SQRT_2PI;
+        const float sg = dmv_softplus(pe[a.q.raw_off + j]) + a.q.eps;
+        const float rs = __builtin_amdgcn_rcpf(sg);
+        qo += q_logp(QEntry{pe[j], 0.5f * rs * rs, dmv_log(sg) + LOG_SQRT_2PI, 0.f}, zj);
+      }
+      const float* x = a.enc.x + (int64_t)bb * a.enc.ldx;
+      const uint8_t* mk = a.enc.m + (int64_t)bb * a.enc.ldm;
+      const float* dec = dt + p * ldD;
+      const float geps = a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f;
+      float gm = 0.f;
+      for (int d = l16; d < a.D; d += 16) {
+        float lp;
+        if (a.gen_dist <= DMV_GEN_NORMAL_EPS) lp = log_normal_r(x[d], dec[d], dmv_softplus(dec[a.D + d]) + geps);
+        else if (a.gen_dist == DMV_GEN_BERN) lp = log_bern(x[d], dec[d]);
+        else lp = log_bern((x[d] + 1.f) * 0.5f, dec[d]);
+        gm += lp * (mk[d] ? 1.f : 0.f);          // (the product the reference forms: non-finite under a missing entry -> NaN)
+      }
+      const float w = gsum<16>(gm) + gsum<16>(pr) - gsum<16>(qo);
+      if (l16 == 0) {
+        lw[p] = w;
+        if (a.log_w) a.log_w[np] = w;
+      }
+    }
+  }
+  __syncthreads();
+  const int Q = 16 / a.S;
+  if (tid < Q * a.nz) {                           // logsumexp over the I samples of (datapoint, outer sample)
+    const int q = tid / a.nz, r0 = q * a.S + (tid - q * a.nz) * a.I;
+    if (nrow[r0] >= 0) {
+      float mx = -INFINITY;
+      for (int i = 0; i < a.I; ++i) mx = fmaxf(mx, lw[r0 + i]);
+      float se = 0.f;
+      for (int i = 0; i < a.I; ++i) se += expf(lw[r0 + i] - mx);
+      const float lse = mx + logf(se);
+      bz[tid] = lse - logf((float)a.I);
+      for (int i = 0; i < a.I; ++i) lw[r0 + i] = expf(lw[r0 + i] - lse);
+    }
+  }
+  __syncthreads();
+  const float inv_nz = 1.f / (float)a.nz;
+  if (tid < 16 && nrow[tid] >= 0) {
+    const float pw = lw[tid];
+    if (a.wgt) a.wgt[nrow[tid]] = pw * inv_nz;
+    if (a.zscale) a.zscale[nrow[tid]] = a.dreg ? pw : 1.f;
+  }
+  // The batch mean in this launch.  The usual way (make the workgroup's results visible, take a ticket) would cost a
+  // device-scope release here, i.e. a write-back of every dirty L2 line the forward pass has just produced (measured:
+  // +17 us).  Instead the few bounds of a tile go out as device-scope atomic exchanges, which are performed at the level
+  // all compute dies share; the ticket is taken only after their old values have come back (they are parked in LDS, so
+  // the barrier waits for them), and the workgroup that draws the last ticket reads the bounds after an acquire.
+  if (tid >= 64 && tid - 64 < Q && nrow[(tid - 64) * a.S] >= 0) {
+    const int q = tid - 64;
+    float acc = 0.f;
+    for (int zz = 0; zz < a.nz; ++zz) acc += bz[q * a.nz + zz];
+    float* dst = a.bound + nrow[q * a.S] % a.B;
+    if (a.ticket) bz[q * a.nz] = atomicExch(dst, acc * inv_nz);
+    else *dst = acc * inv_nz;
+  }
+  if (!a.ticket) return;
+  __syncthreads();
+  if (tid == 0) last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  block_mean2(sh, a.bound, nullptr, (int64_t)a.B, 1.f / (float)a.B, a.mean, nullptr, a.neg_mean);
+  if (tid == 0) *a.ticket = 0u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2803,7 +2913,7 @@ extern "C" int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t i
 // ---- encoder -> sample -> decoder in one launch
 template <int NT>
 static int launch_vae_fwd(const VaeFwdArgs& a, size_t dyn_bytes, hipStream_t st) {
-  const unsigned tiles = (unsigned)((a.N + 15) / 16);
+  const unsigned tiles = a.obj_on ? (unsigned)dmv_ceil_div(a.B, 16 / a.S) : (unsigned)((a.N + 15) / 16);
   if (a.dec.acts) hipLaunchKernelGGL((k_vae_fwd_rows16<NT, true>), dim3(tiles), dim3(256), dyn_bytes, st, a);
   else hipLaunchKernelGGL((k_vae_fwd_rows16<NT, false>), dim3(tiles), dim3(256), dyn_bytes, st, a);
   DMV_HIP_CHECK_LAUNCH();
@@ -2833,12 +2943,28 @@ extern "C" int dmv_vae_forward_fits(const DmvObjCfg* cfg, const DmvNet* enc, con
   return vae_forward_fits(cfg, enc, dec) ? 1 : 0;
 }
 
-extern "C" int dmv_vae_forward(const DmvObjCfg* cfg, const DmvNet* enc, const float* enc_packed, int32_t in_mode,
-                               const float* X, const uint8_t* M, const DmvNet* dec, const float* dec_packed,
-                               const float* eps, uint64_t seed, uint64_t offset, const uint64_t* offset_base,
-                               int32_t n_prior, float prior_raw, float* enc_out, float* enc_saved, float* Z, int64_t ldz,
-                               float* eps_out, float* dec_out, float* dec_saved, void* stream) {
+static int vae_forward_impl(const DmvObjCfg* cfg, const DmvNet* enc, const float* enc_packed, int32_t in_mode,
+                            const float* X, const uint8_t* M, const DmvNet* dec, const float* dec_packed,
+                            const float* eps, uint64_t seed, uint64_t offset, const uint64_t* offset_base,
+                            int32_t n_prior, float prior_raw, float* enc_out, float* enc_saved, float* Z, int64_t ldz,
+                            float* eps_out, float* dec_out, float* dec_saved, const DmvObjFwd* obj, void* stream) {
   if (!vae_forward_fits(cfg, enc, dec)) return DMV_E_UNSUPPORTED;
+  if (obj) {
+    // the bound in the same launch: one Gaussian per datapoint, logsumexp bound, a datapoint's samples in one tile
+    const int S = cfg->nz * cfg->I;
+    if (cfg->G != 1 || cfg->x_per_component || n_prior != 0 || S > 16) return DMV_E_UNSUPPORTED;
+    if (obj->q_kind != DMV_Q_OWN || obj->kind != DMV_BOUND_LSE || obj->use_logpi || obj->terms || obj->comp_lp || obj->dlogit ||
+        obj->objA || obj->objB)
+      return DMV_E_UNSUPPORTED;
+    if (!obj->bound || !M) return DMV_E_BADARG;
+    if (cfg->gen_dist < DMV_GEN_NORMAL || cfg->gen_dist > DMV_GEN_BERN_M1P1) return DMV_E_UNSUPPORTED;
+    if (dec->out_dim != (cfg->gen_dist <= DMV_GEN_NORMAL_EPS ? 2 * cfg->D : cfg->D)) return DMV_E_BADARG;
+    const bool want_means = obj->mean_out || obj->neg_mean_out;
+    if (want_means && (!obj->ticket || dmv_ceil_div(cfg->B, 16 / S) > 256)) return DMV_E_UNSUPPORTED;
+    const size_t dyn = sizeof(float) * 16 * ((size_t)dmv_pad32(enc->out_dim) + 16 * (size_t)dmv_ceil_div(cfg->Zd, 16) +
+                                              (size_t)dmv_pad32(dec->out_dim));
+    if (dyn + (size_t)dmv_ceil_div(enc->hidden, 32) * 2048 + 512 > 65536) return DMV_E_UNSUPPORTED;
+  }
   if (n_prior < 0 || (n_prior > 0 && (!cfg->x_per_component || n_prior >= cfg->G))) return DMV_E_BADARG;
   if (!enc_packed || !dec_packed || !X || !enc_out || !Z || !dec_out || ldz < cfg->Zd) return DMV_E_BADARG;
   if (in_mode < DMV_IN_PLAIN || in_mode > DMV_IN_CONCAT_MASKED) return DMV_E_UNSUPPORTED;
@@ -2882,8 +3008,38 @@ extern "C" int dmv_vae_forward(const DmvObjCfg* cfg, const DmvNet* enc, const fl
   a.q.eps = cfg->q_eps ? DMV_EPSILON : 0.f;
   a.eps = eps; a.eps_out = eps_out; a.Z = Z; a.ldz = ldz; a.seed = seed; a.offset = offset; a.offset_base = offset_base;
   a.ZP = 16 * dmv_ceil_div(cfg->Zd, 16);
-  const size_t dyn = sizeof(float) * 16 * ((size_t)ldE + (size_t)a.ZP);
+  size_t dyn = sizeof(float) * 16 * ((size_t)ldE + (size_t)a.ZP);
+  a.obj_on = obj ? 1 : 0;
+  a.S = cfg->nz * cfg->I; a.nz = cfg->nz; a.I = cfg->I; a.D = cfg->D; a.gen_dist = cfg->gen_dist;
+  a.dreg = 0; a.log_w = nullptr; a.bound = nullptr; a.wgt = nullptr; a.zscale = nullptr; a.ticket = nullptr;
+  a.mean = nullptr; a.neg_mean = nullptr;
+  if (obj) {
+    a.dreg = obj->dreg; a.log_w = obj->log_w; a.bound = obj->bound; a.wgt = obj->wgt; a.zscale = obj->zscale;
+    const bool want_means = obj->mean_out || obj->neg_mean_out;
+    a.ticket = want_means ? (unsigned*)obj->ticket : nullptr;
+    a.mean = obj->mean_out; a.neg_mean = obj->neg_mean_out;
+    dyn += sizeof(float) * 16 * (size_t)dmv_pad32(dec->out_dim);
+  }
   return dmv_part_vae_fwd(a, dyn, (hipStream_t)stream);
+}
+
+extern "C" int dmv_vae_forward(const DmvObjCfg* cfg, const DmvNet* enc, const float* enc_packed, int32_t in_mode,
+                               const float* X, const uint8_t* M, const DmvNet* dec, const float* dec_packed,
+                               const float* eps, uint64_t seed, uint64_t offset, const uint64_t* offset_base,
+                               int32_t n_prior, float prior_raw, float* enc_out, float* enc_saved, float* Z, int64_t ldz,
+                               float* eps_out, float* dec_out, float* dec_saved, void* stream) {
+  return vae_forward_impl(cfg, enc, enc_packed, in_mode, X, M, dec, dec_packed, eps, seed, offset, offset_base, n_prior,
+                          prior_raw, enc_out, enc_saved, Z, ldz, eps_out, dec_out, dec_saved, nullptr, stream);
+}
+
+extern "C" int dmv_vae_forward_bound(const DmvObjCfg* cfg, const DmvNet* enc, const float* enc_packed, int32_t in_mode,
+                                     const float* X, const uint8_t* M, const DmvNet* dec, const float* dec_packed,
+                                     const float* eps, uint64_t seed, uint64_t offset, const uint64_t* offset_base,
+                                     float* enc_out, float* enc_saved, float* Z, int64_t ldz, float* eps_out, float* dec_out,
+                                     float* dec_saved, const DmvObjFwd* obj, void* stream) {
+  if (!obj) return DMV_E_BADARG;
+  return vae_forward_impl(cfg, enc, enc_packed, in_mode, X, M, dec, dec_packed, eps, seed, offset, offset_base, 0, 0.f,
+                          enc_out, enc_saved, Z, ldz, eps_out, dec_out, dec_saved, obj, stream);
 }
 #endif
 

@@ -73,3 +73,58 @@ __device__ __forceinline__ float q_logp(const QEntry& e, float z) {
   return -(d * d) * e.inv2s2 - e.lnorm;
 }
 
+
+// Sum of an array over the threads of a workgroup, thread t taking elements t, t + nthr, ... (16-byte loads, four in
+// flight per thread): fixed summation order for a given workgroup size, so results are reproducible bit for bit.
+__device__ __forceinline__ float sum_strided(const float* __restrict__ v, int64_t n) {
+  float s = 0.f;
+  if (!v) return s;
+  const int64_t tid = threadIdx.x, nt = blockDim.x;
+  if ((((uintptr_t)v) & 15) == 0) {
+    const f32x4* __restrict__ v4 = (const f32x4*)v;
+    const int64_t n4 = n >> 2;
+    int64_t i = tid;
+    for (; i + 3 * nt < n4; i += 4 * nt) {
+      const f32x4 a = v4[i], b = v4[i + nt], c = v4[i + 2 * nt], d = v4[i + 3 * nt];
+      s += ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3])) + ((c[0] + c[1]) + (c[2] + c[3])) +
+           ((d[0] + d[1]) + (d[2] + d[3]));
+    }
+    for (; i < n4; i += nt) { const f32x4 a = v4[i]; s += (a[0] + a[1]) + (a[2] + a[3]); }
+    for (int64_t k = (n4 << 2) + tid; k < n; k += nt) s += v[k];
+  } else {
+    for (int64_t i = tid; i < n; i += nt) s += v[i];
+  }
+  return s;
+}
+
+// means of one or two arrays by the calling workgroup (every thread calls; sh: 32 floats of LDS)
+__device__ __forceinline__ void block_mean2(float* sh, const float* __restrict__ v1, const float* __restrict__ v2, int64_t n,
+                                            float scale, float* __restrict__ o1, float* __restrict__ o2,
+                                            float* __restrict__ o1_neg) {
+  const float s1 = gsum<64>(sum_strided(v1, n)), s2 = gsum<64>(sum_strided(v2, n));
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s1; sh[16 + (threadIdx.x >> 6)] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) { t1 += sh[w]; t2 += sh[16 + w]; }
+    if (o1) o1[0] = t1 * scale;
+    if (o1_neg) o1_neg[0] = -(t1 * scale);
+    if (o2) o2[0] = t2 * scale;
+  }
+}
+
+// The batch mean of per-datapoint bounds inside the launch that produced them: every workgroup makes its results
+// visible and takes a ticket; the one that draws the last sums all bounds in a fixed order and leaves the counter at
+// zero for the next launch.  Every thread of every workgroup must call it (sh: 32 floats of LDS).
+__device__ __forceinline__ void ticket_mean(unsigned* ticket, float* sh, unsigned* last, const float* bound, int64_t n,
+                                            float* mean, float* neg_mean) {
+  if (!ticket) return;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) *last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!*last) return;
+  __threadfence();
+  block_mean2(sh, bound, nullptr, n, 1.f / (float)n, mean, nullptr, neg_mean);
+  if (threadIdx.x == 0) *ticket = 0u;
+}

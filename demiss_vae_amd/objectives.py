@@ -77,14 +77,18 @@ class _Ctx:
 
 
 FUSE_SMALL_FORWARD = True      # tests switch it off to compare with the three separate launches
+FUSE_SMALL_BOUND = True        # ... and this one to compare with forward and objective as two launches
+bound_launches = 0             # how many forward passes formed their bound in the same launch (tests look at it)
 
 
 def fused_forward(cfg, enc: PackedNet, dec: PackedNet, in_mode, X2, M2, eps2, save: bool, keep_eps: bool, n_prior: int = 0,
-                  prior_raw: float = 0.0, enc_out=None, Z=None):
+                  prior_raw: float = 0.0, enc_out=None, Z=None, defer: bool = False):
     """Encoder -> z = mu + sigma eps -> decoder in one launch (dmv_vae_forward) when the shapes allow it, else None.
     X2 / M2 [enc_rows, D]; eps2 [N, Zd] or None (device Philox).  Returns (enc_out, enc_saved, Z, eps_used, dec_out,
     dec_saved) exactly as the separate launches leave them.  n_prior / prior_raw: see dmv_vae_forward (the caller
-    passes enc_out [B, G, ld] with the prior rows filled in).  enc_out / Z: buffers to write into."""
+    passes enc_out [B, G, ld] with the prior rows filled in).  enc_out / Z: buffers to write into.
+    defer: do not launch yet; a seventh element `launch(obj)` is returned, to be called once with a DmvObjFwd (the bound
+    in the same launch, dmv_vae_forward_bound; returns False if the shapes do not allow that and nothing ran) or None."""
     lib = L.lib()
     if not FUSE_SMALL_FORWARD or not lib.dmv_vae_forward_fits(C.byref(cfg), C.byref(enc.c), C.byref(dec.c)):
         return None
@@ -109,16 +113,33 @@ def fused_forward(cfg, enc: PackedNet, dec: PackedNet, in_mode, X2, M2, eps2, sa
         eps_used = new(N, Zd) if keep_eps else None
         seed, off = rng.next_offset(N * Zd)
         base = rng.base_ptr()
-    L.check(lib.dmv_vae_forward(C.byref(cfg), C.byref(enc.c), L.ptr(enc.packed()), in_mode, L.ptr(X2), L.ptr(M2), C.byref(dec.c),
-                                L.ptr(dec.packed()), L.ptr(eps2), seed, off, base, n_prior, prior_raw, L.ptr(enc_out),
-                                L.ptr(enc_saved), L.ptr(Z),
-                                Zd, L.ptr(eps_used) if eps2 is None else None, L.ptr(dec_out), L.ptr(dec_saved), L.stream_ptr()))
+    def launch(obj=None):
+        eo = L.ptr(eps_used) if eps2 is None else None
+        if obj is not None:
+            rc = lib.dmv_vae_forward_bound(C.byref(cfg), C.byref(enc.c), L.ptr(enc.packed()), in_mode, L.ptr(X2), L.ptr(M2),
+                                           C.byref(dec.c), L.ptr(dec.packed()), L.ptr(eps2), seed, off, base, L.ptr(enc_out),
+                                           L.ptr(enc_saved), L.ptr(Z), Zd, eo, L.ptr(dec_out), L.ptr(dec_saved), C.byref(obj),
+                                           L.stream_ptr())
+            if rc == L.E_UNSUPPORTED:
+                return False
+            L.check(rc)
+            return True
+        L.check(lib.dmv_vae_forward(C.byref(cfg), C.byref(enc.c), L.ptr(enc.packed()), in_mode, L.ptr(X2), L.ptr(M2), C.byref(dec.c),
+                                    L.ptr(dec.packed()), L.ptr(eps2), seed, off, base, n_prior, prior_raw, L.ptr(enc_out),
+                                    L.ptr(enc_saved), L.ptr(Z), Zd, eo, L.ptr(dec_out), L.ptr(dec_saved), L.stream_ptr()))
+        return True
+
+    if defer:
+        return enc_out, enc_saved, Z, eps_used, dec_out, dec_saved, launch
+    launch()
     return enc_out, enc_saved, Z, eps_used, dec_out, dec_saved
 
 
 def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, X, M, eps, enc_keep, dec_keep,
-                  training: bool, comp_idx=None):
-    """Runs the forward pipeline; returns a context holding every buffer the backward needs."""
+                  training: bool, comp_idx=None, bound_follows: bool = False):
+    """Runs the forward pipeline; returns a context holding every buffer the backward needs.
+    bound_follows: the caller goes straight on to _objective_forward with a logsumexp bound; the one-launch forward is
+    then left pending (c.pending_forward) so that the bound can be formed in the same launch."""
     lib = L.lib()
     st = L.stream_ptr()
     dev = X.device
@@ -158,10 +179,14 @@ def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, 
     fused = None
     if not dims.q_is_reparam and comp_idx is None and enc_keep is None and dec_keep is None:
         # small batches: encoder, sampling and decoder in one launch
+        defer = bound_follows and FUSE_SMALL_BOUND and not demiss and G == 1
         fused = fused_forward(cfg, enc, dec, in_mode, Xc.reshape(enc_rows, D), Mu.reshape(enc_rows, D),
-                              eps.reshape(N, Zd).contiguous().float() if eps is not None else None, training, training)
+                              eps.reshape(N, Zd).contiguous().float() if eps is not None else None, training, training,
+                              defer=defer)
+    c.pending_forward = None
     if fused is not None:
-        enc_out, enc_saved, Z, eps_used, dec_out, dec_saved = fused
+        enc_out, enc_saved, Z, eps_used, dec_out, dec_saved = fused[:6]
+        c.pending_forward = fused[6] if len(fused) > 6 else None
     else:
         enc_out, enc_saved = mlp_forward(enc, Xc, D, enc_rows, in_mode=in_mode, D=D, m=Mu, ldm=D, save=training,
                                          drop_keep=enc_keep)
@@ -241,6 +266,14 @@ def _objective_forward(c, plan: _Plan, training: bool, *, kind, use_logpi=False,
         f.objA, f.objB, f.meanA_out, f.meanB_out = L.addr(objA), L.addr(objB), L.addr(mA), L.addr(mB)
         out = (objA, objB, mA, mB)
     f.ticket = L.ticket_ptr()
+    pending, c.pending_forward = getattr(c, "pending_forward", None), None
+    if pending is not None:
+        # the forward has not run yet: with the bound in its launch if the shapes allow, else by itself
+        if kind == L.BOUND_LSE and c.q_kind == L.Q_OWN and not use_logpi and pending(f):
+            global bound_launches
+            bound_launches += 1
+            return out
+        pending(None)
     rc = lib.dmv_obj_forward(C.byref(c.cfg), C.byref(f), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
                              L.ptr(c.Z), c.Z.shape[1], L.ptr(c.enc_out), st)
     if rc == L.E_UNSUPPORTED and c.cfg.nz * c.cfg.I * c.G > 1024:
@@ -446,7 +479,8 @@ class _FusedObjective(torch.autograd.Function):
         if dims.q_is_reparam:
             assert plan.kind == "iwae" and not plan.DREG, "reparametrised mixtures: ELBO (MC KL) and IWAE bounds only"
             assert plan.STL or not training, "reparametrised mixtures are trained with var_latent_STL (as every config does)"
-        c = _forward_core(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, training, comp_idx=comp_idx)
+        c = _forward_core(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, training, comp_idx=comp_idx,
+                          bound_follows=plan.kind in ("iwae", "miwae") and not plan.looser)
         ctx.c, ctx.dims, ctx.plan, ctx.enc, ctx.dec = c, dims, plan, enc, dec
         ctx.set_materialize_grads(False)
         k = plan.kind

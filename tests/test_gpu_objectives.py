@@ -665,3 +665,63 @@ def test_batch_means_formed_by_the_last_workgroup():
     torch.cuda.synchronize()
     slots, _ = L._TICKETS[torch.cuda.current_device()]
     assert int(slots.abs().sum()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["iwae_stl", "iwae_dreg", "iwae_plain_nz2", "vae_mc", "iwae_I16", "iwae_bern", "iwae_eval",
+                                  "iwae_ragged"])
+def test_forward_with_bound_equals_two_launches(case):
+    """dmv_vae_forward_bound (encoder, sampling, decoder and the logsumexp bound in one launch, datapoint-major tiles)
+    against dmv_vae_forward + dmv_obj_forward on the same noise: bounds and their mean to 2e-6 (other summation order
+    over a row's dimensions), parameter gradients to 1e-5 of each tensor's largest entry."""
+    import demiss_vae_amd as dmv
+    from demiss_vae_amd import objectives as O
+    from demiss_vae_amd import rng, synth
+    shapes = {          # B, D, Zd, nz, I, hidden, gen, kwargs, training
+        "iwae_stl": (512, 8, 16, 1, 5, 256, "normal_with_eps", dict(STL=True), True),
+        "iwae_dreg": (100, 8, 16, 1, 5, 256, "normal_with_eps", dict(DREG=True), True),
+        "iwae_plain_nz2": (37, 5, 2, 2, 3, 200, "normal", dict(), True),
+        "vae_mc": (64, 8, 16, 3, 1, 64, "normal_with_eps", dict(), True),
+        "iwae_I16": (33, 8, 16, 1, 16, 64, "normal", dict(STL=True), True),
+        "iwae_bern": (50, 20, 5, 1, 4, 96, "bern", dict(STL=True), True),
+        "iwae_eval": (200, 8, 16, 1, 5, 256, "normal_with_eps", dict(), False),
+        "iwae_ragged": (1, 3, 2, 1, 7, 32, "normal", dict(STL=True), True),
+    }
+    B, D, Zd, nz, I, hidden, gen, kw, training = shapes[case]
+    normal = gen.startswith("normal")
+    dims = dmv.ModelDims(D=D, Zd=Zd, gen_dist=gen, q_dist="normal_with_eps", encoder_use_mis_mask=True)
+    g = torch.Generator().manual_seed(17)
+    X = torch.randn(B, D, generator=g)
+    if not normal:
+        X = (X > 0.2).float()
+    X, M = X.cuda(), (torch.rand(B, D, generator=g) < 0.6).cuda()
+
+    def run(fused):
+        enc = synth.packed_net(synth.NetShape(2 * D, 2 * Zd, 2, hidden), 1, "cuda", requires_grad=training)
+        dec = synth.packed_net(synth.NetShape(Zd, 2 * D if normal else D, 2, hidden), 2, "cuda", requires_grad=training)
+        rng.set_seed(23)
+        O.FUSE_SMALL_BOUND, before = fused, O.bound_launches
+        try:
+            with torch.set_grad_enabled(training):
+                mean, per_b, neg = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=nz, num_importance_samples=I,
+                                                       with_loss=True, **kw)
+                if training:
+                    neg.backward()
+        finally:
+            O.FUSE_SMALL_BOUND = True
+        torch.cuda.synchronize()
+        assert (O.bound_launches - before == 1) == fused
+        grads = [t.grad.clone() for t in enc.params() + dec.params()] if training else []
+        return mean.detach().clone(), per_b.detach().clone(), neg.detach().clone(), grads
+
+    one, two = run(True), run(False)
+    torch.testing.assert_close(one[1], two[1], rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(one[0], two[0], rtol=2e-6, atol=2e-6)
+    assert float(one[2]) == -float(one[0])
+    # the mean is formed by whichever workgroup finishes last, from bounds the others published: again and again
+    for _ in range(30 if case in ("iwae_eval", "iwae_stl") else 2):
+        mean, per_b, _, _ = run(True)
+        np.testing.assert_allclose(mean.item(), per_b.double().mean().item(), rtol=3e-6)
+    for a, b in zip(one[3], two[3]):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, (case, float((a - b).abs().max()), float(b.abs().max()))
