@@ -24,6 +24,8 @@ What changed in the steps since `profiles/r2_training_steps.md`, kernel by kerne
   stays in the workgroup); the two networks' weight-gradient GEMMs follow side by side on two streams;
 - `k_mean2` -> the last workgroup of the objective forward forms the batch mean and the loss (ticket counter; launches of
   at most 256 workgroups);
+- one Gaussian per datapoint (IWAE / VAE): `k_obj_fwd*` -> an epilogue of `k_vae_fwd_rows16` (datapoint-major tiles; the
+  bounds are published with atomic exchanges so that the mean needs no device-scope release);
 - stratified / imputation mixtures: `k_obj_bwd_latent` -> `k_obj_bwd_latent_mix` (parameters, samples and
   responsibilities of a datapoint in LDS; `profiles/r3_latent_mixture_kernel.md`);
 - LAIR update: per iteration encoder + two `cat` + sample + decoder + objective + draw + row map + tail (9 launches), then
