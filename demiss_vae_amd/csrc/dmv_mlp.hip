@@ -2715,7 +2715,8 @@ static int launch_bwd(const BwdArgs& a0, hipStream_t st) {
 }
 
 // hidden widths above 256 (9..16 tiles of 32): two activation sets no longer fit one wave's registers as 32-row
-// tiles; the 16-row kernels hold them (a quarter of Hp floats per lane and set) at every batch size
+// tiles.  Up to 4096 rows the 16-row kernels (a quarter of Hp floats per lane and set); beyond that rounds of four-wave
+// 32-row tiles (one full layer input + the wave's own slice of the residual stream) and a last round of 16-row tiles
 template <int NT>
 static int launch_fwd_wide(const FwdArgs& a0, hipStream_t st) {
   FwdArgs a = a0;

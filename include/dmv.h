@@ -70,7 +70,7 @@ enum {
 typedef struct DmvNet {
   int32_t in_dim;
   int32_t out_dim;
-  int32_t hidden;   /* 1..512; above 256: relu without dropout only */
+  int32_t hidden;   /* 1..512; above 256: relu only */
   int32_t nb;       /* residual blocks, 0..8 */
   int32_t act;      /* DMV_ACT_* */
   float dropout_p;  /* 0 = none */
