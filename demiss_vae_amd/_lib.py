@@ -122,7 +122,7 @@ SIGNATURES = {
     "dmv_obj_backward_latent_terms": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _I32, _P, _P, _P, _I64, _P, _I64,
                                                 _P, _P, _P, _P, _P, _P, _P, _P]),
     "dmv_obj_implicit_ws_floats": (_SZ, [C.POINTER(DmvObjCfg), _I32]),
-    "dmv_obj_backward_latent_implicit": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _P, _P, _I64, _P, _I64, _P, _F, _F, _P, _P, _P]),
+    "dmv_obj_backward_latent_implicit": (C.c_int, [C.POINTER(DmvObjCfg), _I32, _P, _P, _I64, _P, _I64, _P, _F, _F, _I32, _P, _P, _P]),
     "dmv_grid_marginal_ws_floats": (_SZ, [_I64, _I32]),
     "dmv_grid_marginal": (C.c_int, [_I32, _I32, _I64, _P, _I64, _P, _I32, _P, _P, _P, _P, _P, _P]),
     "dmv_opt_ws_floats": (_SZ, [_I32, _P]),

@@ -812,6 +812,7 @@ struct BwdImplicitArgs {
   int B, S, Zd, K;
   QAddr q;
   float base_prior, base_qmix;
+  int mix_live;         // also differentiate log q_mix(z) in q's parameters at fixed z
   const float* enc;
   const float* Z;
   int64_t ldz;
@@ -854,6 +855,18 @@ __global__ void k_obj_bwd_latent_implicit(BwdImplicitArgs a) {
     float tz = 0.f;
     for (int k = 0; k < K; ++k) tz += expf(enc[a.q.logit_off + k] + pre[k * (Zd + 1) + Zd] - tm);
     for (int k = 0; k < K; ++k) A[k] = 0.f;
+    // at fixed z: d log q_mix / d logit_k = r_k - pi_k, and r_k d log N_k / d(mu, sigma) inside the loop over j
+    const float live = a.mix_live ? w_n * a.base_qmix : 0.f;
+    if (a.mix_live) {
+      float lm = -INFINITY;
+      for (int k = 0; k < K; ++k) lm = fmaxf(lm, enc[a.q.logit_off + k]);
+      float lz = 0.f;
+      for (int k = 0; k < K; ++k) lz += expf(enc[a.q.logit_off + k] - lm);
+      for (int k = 0; k < K; ++k) {
+        const float r = expf(enc[a.q.logit_off + k] + pre[k * (Zd + 1) + Zd] - tm) / tz;
+        out[a.q.logit_off + k] += live * (r - expf(enc[a.q.logit_off + k] - lm) / lz);
+      }
+    }
     for (int j = Zd - 1; j >= 0; --j) {
       float wm = -INFINITY;
       for (int k = 0; k < K; ++k) wm = fmaxf(wm, enc[a.q.logit_off + k] + pre[k * (Zd + 1) + j]);
@@ -882,8 +895,9 @@ __global__ void k_obj_bwd_latent_implicit(BwdImplicitArgs a) {
         const float cdf = 0.5f * (1.f + erff(al * 0.70710678118654752f));
         const float pdf = expf(-0.5f * al * al) * 0.3989422804014327f / sg;
         const float d = -al / sg;
-        out[k * a.q.sg + j] += u * w * pdf + A[k] * d;
-        const float gs = u * w * pdf * al - A[k] * (al * al / sg - 1.f / sg);
+        const float rl = a.mix_live ? live * expf(enc[a.q.logit_off + k] + pre[k * (Zd + 1) + Zd] - tm) / tz : 0.f;
+        out[k * a.q.sg + j] += u * w * pdf + (A[k] - rl) * d;
+        const float gs = u * w * pdf * al - (A[k] - rl) * (al * al / sg - 1.f / sg);
         out[k * a.q.sg + a.q.raw_off + j] += gs * (raw > 20.f ? 1.f : dmv_sigmoid(raw));
         const float e = u * w * (cdf - T);
         out[a.q.logit_off + k] -= e;
@@ -1293,7 +1307,8 @@ extern "C" size_t dmv_obj_implicit_ws_floats(const DmvObjCfg* cfg, int32_t mix_C
 
 extern "C" int dmv_obj_backward_latent_implicit(const DmvObjCfg* cfg, int32_t mix_C, const float* enc, const float* Z,
                                                 int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
-                                                float base_prior, float base_qmix, float* ws, float* d_enc, void* stream) {
+                                                float base_prior, float base_qmix, int32_t mix_live, float* ws, float* d_enc,
+                                                void* stream) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (!enc || !Z || !ws || !d_enc || ldz < cfg->Zd || (dZ && ld_dz < cfg->Zd)) return DMV_E_BADARG;
@@ -1301,7 +1316,7 @@ extern "C" int dmv_obj_backward_latent_implicit(const DmvObjCfg* cfg, int32_t mi
   if (mix_C < 1 || mix_C > 64) return DMV_E_UNSUPPORTED;
   BwdImplicitArgs a;
   a.B = cfg->B; a.S = cfg->nz * cfg->I; a.Zd = cfg->Zd; a.K = mix_C; a.q = qaddr(cfg);
-  a.base_prior = base_prior; a.base_qmix = base_qmix;
+  a.base_prior = base_prior; a.base_qmix = base_qmix; a.mix_live = mix_live != 0;
   a.enc = enc; a.Z = Z; a.ldz = ldz; a.dZ = dZ; a.ld_dz = ld_dz; a.wgt = wgt; a.ws = ws; a.d_enc = d_enc;
   hipLaunchKernelGGL(k_obj_bwd_latent_implicit, dim3((unsigned)((cfg->B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
   DMV_HIP_CHECK_LAUNCH();

@@ -72,7 +72,6 @@ class _Sample(torch.autograd.Function):
         enc = enc_out.detach().contiguous().float()
         Z = torch.empty((N, Zd), dtype=torch.float32, device=enc.device)
         if c.reparam:
-            assert c.plan.STL or not enc_out.requires_grad, "reparametrised mixtures are trained with var_latent_STL"
             comp_idx, eps = reparam_components(c.dims, c.cfg, enc, comp_idx, eps)
         if eps is not None:
             used = eps.reshape(N, Zd).contiguous().float()
@@ -172,7 +171,7 @@ class _Objective(torch.autograd.Function):
             wt = (c.wgt.reshape(S, B, G) * g_b.reshape(1, B, 1)).reshape(-1).contiguous()
             dec_part(wt, 1.0, 0.0)
             if c.reparam:
-                return None, d_dec, _implicit_d_enc(c, None, wt, 1.0, -1.0)
+                return None, d_dec, _implicit_d_enc(c, None, wt, 1.0, -1.0, live=not plan.STL)
             mixture = c.q_kind == L.Q_STRATIFIED
             dl = (c.dlogit * g_b.reshape(B, 1)).contiguous() if mixture else None
             if mixture:

@@ -442,15 +442,16 @@ def _one_launch_backward(c, enc: PackedNet, dec: PackedNet, p: L.DmvLatentBwd, w
     return g_dec, g_enc
 
 
-def _implicit_d_enc(c, dZ, wgt, base_prior, base_qmix):
-    """Encoder-output gradient through ancestrally sampled mixture latents (implicit reparameterisation)."""
+def _implicit_d_enc(c, dZ, wgt, base_prior, base_qmix, live=False):
+    """Encoder-output gradient through ancestrally sampled mixture latents (implicit reparameterisation); live: also
+    the score of q in its own parameters at fixed z (bounds without "sticking the landing")."""
     lib, st = L.lib(), L.stream_ptr()
     Cn = c.mix_C
     ws = torch.empty(lib.dmv_obj_implicit_ws_floats(C.byref(c.cfg), Cn), dtype=torch.float32, device=c.enc_out.device)
     d_enc = torch.zeros_like(c.enc_out)
     L.check(lib.dmv_obj_backward_latent_implicit(C.byref(c.cfg), Cn, L.ptr(c.enc_out), L.ptr(c.Z), c.Z.shape[1], L.ptr(dZ),
                                                  dZ.shape[1] if dZ is not None else 0, L.ptr(wgt), base_prior, base_qmix,
-                                                 L.ptr(ws), L.ptr(d_enc), st))
+                                                 int(live), L.ptr(ws), L.ptr(d_enc), st))
     return d_enc
 
 
@@ -478,7 +479,6 @@ class _FusedObjective(torch.autograd.Function):
         training = plan.grad and any(ctx.needs_input_grad[10:])
         if dims.q_is_reparam:
             assert plan.kind == "iwae" and not plan.DREG, "reparametrised mixtures: ELBO (MC KL) and IWAE bounds only"
-            assert plan.STL or not training, "reparametrised mixtures are trained with var_latent_STL (as every config does)"
         c = _forward_core(dims, plan, enc, dec, X, M, eps, enc_keep, dec_keep, training, comp_idx=comp_idx,
                           bound_follows=plan.kind in ("iwae", "miwae") and not plan.looser)
         ctx.c, ctx.dims, ctx.plan, ctx.enc, ctx.dec = c, dims, plan, enc, dec
@@ -562,7 +562,7 @@ class _FusedObjective(torch.autograd.Function):
             dZ, g_dec_params = _dec_side(c, dec, c.wgt, f, 0.0, True, True, overlap=pending, gb=gb, gscale=gs, complete=True)
             if c.reparam:
                 wt = c.wgt * (gs * f) if gb is None else (c.wgt.reshape(S, B) * gb.reshape(1, B)).reshape(-1)
-                d_enc = _implicit_d_enc(c, dZ, wt.contiguous(), 1.0, -1.0)
+                d_enc = _implicit_d_enc(c, dZ, wt.contiguous(), 1.0, -1.0, live=not plan.STL)
                 _, g_enc_params = mlp_backward(enc, c.enc_saved, d_enc, c.enc_rows, need_dx=False, need_param_grads=True,
                                                drop_keep=c.enc_keep)
                 _join(pending)

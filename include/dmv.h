@@ -351,12 +351,15 @@ int dmv_obj_backward_latent_terms(const DmvObjCfg* cfg, int32_t mix_kind, int32_
  * encoder output addressed like a stratified mixture of mix_C components.  Computes the gradient, w.r.t. the
  * encoder output (all components' mu, raw sigma and the logits), of
  *   sum_n <g_n, z_n>,  g_n = dZ[n] + wgt[n] * (base_prior * d log p(z)/dz + base_qmix * d log q_mix(z)/dz)
- * through z only (the "sticking the landing" form: q's own parameters are not differentiated directly).
+ * through z only with mix_live 0 (the "sticking the landing" form: q's own parameters are not differentiated
+ * directly); with mix_live 1 the term sum_n wgt[n] * base_qmix * d log q_mix(z_n; theta)/d theta at fixed z_n is
+ * added (vgiwae/models/iwae.py:104-106: the score is taken on the live distribution unless STL or DREG is set).
  * ws: dmv_obj_implicit_ws_floats(cfg, mix_C) floats.  d_enc: written for every addressed entry. */
 size_t dmv_obj_implicit_ws_floats(const DmvObjCfg* cfg, int32_t mix_C);
 int dmv_obj_backward_latent_implicit(const DmvObjCfg* cfg, int32_t mix_C, const float* enc, const float* Z,
                                      int64_t ldz, const float* dZ, int64_t ld_dz, const float* wgt,
-                                     float base_prior, float base_qmix, float* ws, float* d_enc, void* stream);
+                                     float base_prior, float base_qmix, int32_t mix_live, float* ws, float* d_enc,
+                                     void* stream);
 
 /* Marginal log-probability of incomplete (and complete) datapoints by numerical integration over a latent grid
  * (vgiwae/shared/vae_marginal_logprob.py:194-307, get_marginal_logprob_for_Zgrid): dec [Nz][ld_dec] are the decoder

@@ -134,7 +134,8 @@ def test_philox_noise_statistics():
 @pytest.mark.parametrize("name", gu.names("reparam_"))
 def test_reparametrised_mixture(name, engine):
     """Mixture encoder sampled ancestrally with implicit reparameterisation gradients (the reparametrised_mixture*
-    families; vgiwae/shared/reparametrized_mixture_same_family.py), STL, through both engines: the fused residual
+    families; vgiwae/shared/reparametrized_mixture_same_family.py), with STL and (the *_live fixtures) without, through
+    both engines: the fused residual
     MLP pipeline and the caller-network one (here the same networks as plain torch functions).  Encoder-side
     tolerance as in the oracle test: the reference's fp32 triangular solve is itself only good to ~1e-3."""
     import dataclasses
@@ -149,6 +150,7 @@ def test_reparametrised_mixture(name, engine):
     X, M = (t.cuda() for t in gu.batch_of(g))
     eps, comp = torch.from_numpy(g["eps"]).cuda(), torch.from_numpy(g["comp_idx"]).cuda()
     nz, I, is_vae = int(g["nz"]), int(g["I"]), str(g["cls"]) == "VAE"
+    stl = bool(g.get("STL", True))
     if engine == "fused":
         enc, dec = G.packed_net(spec.enc, enc_p), G.packed_net(spec.dec, dec_p)
         fn, a, b = dmv, enc, dec
@@ -159,9 +161,9 @@ def test_reparametrised_mixture(name, engine):
         a = lambda X2, M2: core.mlp_forward(ep, torch.cat([X2, M2.to(X2.dtype)], -1), spec.enc)
         b = lambda Z: core.mlp_forward(dp, Z, spec.dec)
     if is_vae:
-        bound, _ = fn.estimate_elbo(dims, a, b, X, M, num_latent_samples=nz, kl_analytic=False, STL=True, eps=eps, comp_idx=comp)
+        bound, _ = fn.estimate_elbo(dims, a, b, X, M, num_latent_samples=nz, kl_analytic=False, STL=stl, eps=eps, comp_idx=comp)
     else:
-        bound, _ = fn.estimate_iwelbo(dims, a, b, X, M, num_latent_samples=nz, num_importance_samples=I, STL=True, eps=eps,
+        bound, _ = fn.estimate_iwelbo(dims, a, b, X, M, num_latent_samples=nz, num_importance_samples=I, STL=stl, eps=eps,
                                       comp_idx=comp)
     (-bound).backward()
     np.testing.assert_allclose(bound.item(), float(g["bound"]), rtol=RT_B)

@@ -591,9 +591,10 @@ def cases_trajectory(out):
     save(out, "trajectory_iwae", **arrays)
 
 
-def _reparam(out, name, *, cls, D, Zd, C, B, I, nz, seed, with_eps=True):
+def _reparam(out, name, *, cls, D, Zd, C, B, I, nz, seed, with_eps=True, stl=True):
     """VAE / IWAE whose encoder is a mixture sampled ancestrally with implicit reparameterisation gradients
-    (the reparametrised_mixture* families), STL as in every shipped config."""
+    (the reparametrised_mixture* families); stl: "sticking the landing" as in every shipped config, else the score of
+    q is taken on the live distribution as well."""
     from vgiwae.shared.vae_enums import DISTRIBUTION
     from vgiwae.models.iwae import estimate_iwelbo
     from vgiwae.models.vae import estimate_elbo
@@ -605,7 +606,7 @@ def _reparam(out, name, *, cls, D, Zd, C, B, I, nz, seed, with_eps=True):
     model = getattr(models, cls)(generator_network=ref_net(dec_spec, dec_p), generator_distribution=dist_enum("normal_with_eps"),
                                  var_latent_network=ref_net(enc_spec, enc_p), var_latent_distribution=qd,
                                  num_latent_samples=nz, lr_generator=1e-3, lr_latent=1e-3, encoder_use_mis_mask=True,
-                                 var_latent_STL=True, **kw)
+                                 var_latent_STL=stl, **kw)
     model.train()
     X, M = make_batch(seed + 2, B, D)
     shape = (nz, I, B, C, Zd) if cls == "IWAE" else (nz, B, C, Zd)
@@ -614,12 +615,12 @@ def _reparam(out, name, *, cls, D, Zd, C, B, I, nz, seed, with_eps=True):
     noise.normal = [eps.clone()]
     with injected(noise):
         if cls == "IWAE":
-            bound = estimate_iwelbo(model, (X, M), var_latent_STL=True, num_latent_samples=nz, num_importance_samples=I)
+            bound = estimate_iwelbo(model, (X, M), var_latent_STL=stl, num_latent_samples=nz, num_importance_samples=I)
         else:
-            bound = estimate_elbo(model, (X, M), kl_analytic=False, var_latent_STL=True, num_latent_samples=nz)
+            bound = estimate_elbo(model, (X, M), kl_analytic=False, var_latent_STL=stl, num_latent_samples=nz)
     (-bound).backward()
     arrays = dict(seed=seed, B=B, I=I, nz=nz, D=D, Zd=Zd, C=C, with_eps=with_eps, cls=cls, bound=bound, X=X, M=M, eps=eps,
-                  comp_idx=noise.cat_draws[0],
+                  comp_idx=noise.cat_draws[0], STL=stl,
                   enc_spec=np.array([enc_spec.in_dim, enc_spec.out_dim, enc_spec.nb, enc_spec.hidden]),
                   dec_spec=np.array([dec_spec.in_dim, dec_spec.out_dim, dec_spec.nb, dec_spec.hidden]))
     arrays.update(params_to_dict("enc", enc_p))
@@ -633,6 +634,10 @@ def cases_reparam(out):
     _reparam(out, "reparam_iwae_C5", cls="IWAE", D=8, Zd=6, C=5, B=10, I=3, nz=1, seed=8000)
     _reparam(out, "reparam_vae_C5", cls="VAE", D=8, Zd=6, C=5, B=10, I=1, nz=2, seed=8100)
     _reparam(out, "reparam_iwae_C15_noeps", cls="IWAE", D=5, Zd=3, C=15, B=7, I=4, nz=2, seed=8200, with_eps=False)
+    _reparam(out, "reparam_iwae_C5_live", cls="IWAE", D=8, Zd=6, C=5, B=10, I=3, nz=1, seed=8300, stl=False)
+    _reparam(out, "reparam_vae_C5_live", cls="VAE", D=8, Zd=6, C=5, B=10, I=1, nz=2, seed=8400, stl=False)
+    _reparam(out, "reparam_iwae_C15_noeps_live", cls="IWAE", D=5, Zd=3, C=15, B=7, I=4, nz=2, seed=8500, with_eps=False,
+             stl=False)
 
 
 def cases_marginal(out):
