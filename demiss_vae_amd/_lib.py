@@ -92,6 +92,8 @@ SIGNATURES = {
     "dmv_mlp_backward": (C.c_int, [C.POINTER(DmvNet), _P, _P, _P, _P, _I64, _I64, _P, _I64,
                                    C.POINTER(_P), C.POINTER(_P), _F, _P, _SZ, _P]),
     "dmv_mlp_backward_wgrad": (C.c_int, [C.POINTER(DmvNet), _P, _P, _I64, _I64, _P, _P, _F, _P, _SZ, _P]),
+    "dmv_mlp_backward_wgrad_pair": (C.c_int, [C.POINTER(DmvNet), _P, _P, _I64, _I64, _P, _P, _P, _SZ,
+                                              C.POINTER(DmvNet), _P, _P, _I64, _I64, _P, _P, _P, _SZ, _F, _P]),
     "dmv_latent_sample": (C.c_int, [C.POINTER(DmvObjCfg), _P, _P, _U64, _U64, _P, _I64, _P, _P, _P, _P]),
     "dmv_vae_forward_fits": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), C.POINTER(DmvNet)]),
     "dmv_vae_forward": (C.c_int, [C.POINTER(DmvObjCfg), C.POINTER(DmvNet), _P, _I32, _P, _P, C.POINTER(DmvNet), _P, _P, _U64, _U64,

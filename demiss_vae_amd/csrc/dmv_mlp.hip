@@ -2359,14 +2359,17 @@ struct WgradLayer {
   int wave0;           // first wave of this layer; a layer owns nblk*kblk*splits consecutive waves
   int64_t slab_w, slab_b;  // offsets (floats) of this layer's split-0 image inside the slab
   int64_t slab_stride;     // floats per split of this layer
+  int64_t rows;            // rows of this layer's network
+  float* slab;             // ... and its slab
 };
 
+// One launch takes the layers of one network or of two (an encoder and a decoder whose chains ran in one launch):
+// every layer carries its own operands, row count and slab.
+#define DMV_WGRAD_MAX_LAYERS 24
 struct WgradArgs {
-  WgradLayer ly[DMV_MAX_LAYERS];
+  WgradLayer ly[DMV_WGRAD_MAX_LAYERS];
   int nl;
   int total_waves;
-  int64_t rows;
-  float* slab;
 };
 
 // One block of TN x TK tiles over rows [r_begin, r_end).  Compile-time tile counts keep the loop free of
@@ -2484,8 +2487,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(WgradArgs a) {
   const int nb0 = (bi / Ly.kblk) * Ly.bt, kb0 = (bi % Ly.kblk) * Ly.bt;
   const int tn = min(Ly.bt, Ly.nt - nb0), tk = min(Ly.bt, Ly.kt - kb0);
   const int64_t r_begin = (int64_t)split * Ly.rows_per_split;
-  const int64_t r_end = min(a.rows, r_begin + Ly.rows_per_split);
-  float* slab = a.slab + (int64_t)split * Ly.slab_stride;
+  const int64_t r_end = min(Ly.rows, r_begin + Ly.rows_per_split);
+  float* slab = Ly.slab + (int64_t)split * Ly.slab_stride;
   TRACE(0);
   TRACE_REAL(13);
 #ifdef DMV_TRACE
@@ -2505,14 +2508,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(WgradArgs a) {
 
 struct ReduceArgs {
   int nl;
-  int N[DMV_MAX_LAYERS], K[DMV_MAX_LAYERS], Kp[DMV_MAX_LAYERS];
-  int64_t slab_w[DMV_MAX_LAYERS], slab_b[DMV_MAX_LAYERS];
-  int64_t first[DMV_MAX_LAYERS + 1];  // prefix sums of N*K + N
-  float* gw[DMV_MAX_LAYERS];
-  float* gb[DMV_MAX_LAYERS];
-  int splits[DMV_MAX_LAYERS];
-  int64_t slab_stride[DMV_MAX_LAYERS];
-  const float* slab;
+  int N[DMV_WGRAD_MAX_LAYERS], K[DMV_WGRAD_MAX_LAYERS], Kp[DMV_WGRAD_MAX_LAYERS];
+  int64_t slab_w[DMV_WGRAD_MAX_LAYERS], slab_b[DMV_WGRAD_MAX_LAYERS];
+  int64_t first[DMV_WGRAD_MAX_LAYERS + 1];  // prefix sums of N*K + N
+  float* gw[DMV_WGRAD_MAX_LAYERS];
+  float* gb[DMV_WGRAD_MAX_LAYERS];
+  int splits[DMV_WGRAD_MAX_LAYERS];
+  int64_t slab_stride[DMV_WGRAD_MAX_LAYERS];
+  const float* slab[DMV_WGRAD_MAX_LAYERS];
   float beta;
 };
 
@@ -2536,7 +2539,7 @@ __global__ void k_wgrad_reduce(ReduceArgs a) {
     }
     // the splits are added in order (bitwise reproducible), their loads requested four at a time
     float s = 0.f;
-    const float* __restrict__ sp = a.slab + src;
+    const float* __restrict__ sp = a.slab[l] + src;
     const int64_t ss = a.slab_stride[l];
     const int ns = a.splits[l];
     int p = 0;
@@ -3174,13 +3177,15 @@ extern "C" int dmv_pgibbs_update(const DmvNet* enc, const float* enc_packed, int
 // reduction (at 2560 rows and hidden 256: 15 slices instead of 40, 33 MB instead of 88 MB each way; 30 us instead
 // of 47 us for both kernels).  Measured crossover: 12 k rows at hidden 200; at hidden 256 the 2x2 blocks still win at
 // 20480 rows (127 us against 149 us) and lose at 28672 (196 us against 186 us).
-static int64_t wgrad_plan(const DmvNet* net, int64_t rows, WgradArgs* wa, ReduceArgs* ra) {
+// Fills the layers l0 .. l0 + nl - 1 of wa (and ra): l0 > 0 appends a second network to a planned first one.
+static int64_t wgrad_plan(const DmvNet* net, int64_t rows, WgradArgs* wa, ReduceArgs* ra, int l0 = 0, double slots = 1024.0,
+                          double* weight_out = nullptr) {
   DmvLayout L = dmv_layout(net);
   const int bt = rows <= (L.NT >= 8 ? 24576 : 16384) ? 2 : 4, full = bt * bt;
   double weight = 0.0;   // waves per unit of slices, in units of a full block
   int cost[DMV_MAX_LAYERS];
   for (int l = 0; l < L.nl; ++l) {
-    WgradLayer& y = wa->ly[l];
+    WgradLayer& y = wa->ly[l0 + l];
     y.nt = (L.N[l] + 31) / 32;
     y.kt = (L.K[l] + 31) / 32;
     y.bt = bt;
@@ -3190,15 +3195,16 @@ static int64_t wgrad_plan(const DmvNet* net, int64_t rows, WgradArgs* wa, Reduce
     if (cost[l] < full / 2) cost[l] = full / 2;   // a small block is bound by load latency, not MFMA issue: at most 2x longer slices
     weight += (double)y.nblk * y.kblk * cost[l] / full;
   }
-  int64_t base_splits = (int64_t)(1024.0 / weight);
+  if (weight_out) *weight_out = weight;
+  int64_t base_splits = (int64_t)(slots / weight);
   if (base_splits < 1) base_splits = 1;
   const int64_t max_splits = (rows + 63) / 64;
   if (base_splits > max_splits) base_splits = max_splits;
   int64_t base_rps = (rows + base_splits - 1) / base_splits;
-  int wave0 = 0;
+  int wave0 = l0 ? wa->total_waves : 0;
   int64_t slab = 0;
   for (int l = 0; l < L.nl; ++l) {
-    WgradLayer& y = wa->ly[l];
+    WgradLayer& y = wa->ly[l0 + l];
     int64_t rps = base_rps * full / cost[l];
     rps = (rps + 15) / 16 * 16;
     y.rows_per_split = rps;
@@ -3208,22 +3214,23 @@ static int64_t wgrad_plan(const DmvNet* net, int64_t rows, WgradArgs* wa, Reduce
     y.slab_stride = (int64_t)y.nt * 32 * y.kt * 32 + (int64_t)y.nt * 32;
     y.slab_w = slab;
     y.slab_b = slab + (int64_t)y.nt * 32 * y.kt * 32;
+    y.rows = rows;
     slab += y.slab_stride * y.splits;
   }
-  wa->nl = L.nl;
+  wa->nl = l0 + L.nl;
   wa->total_waves = wave0;
-  wa->rows = rows;
   if (ra) {
-    ra->nl = L.nl;
-    int64_t first = 0;
+    ra->nl = l0 + L.nl;
+    int64_t first = l0 ? ra->first[l0] : 0;
     for (int l = 0; l < L.nl; ++l) {
-      ra->N[l] = L.N[l]; ra->K[l] = L.K[l]; ra->Kp[l] = wa->ly[l].kt * 32;
-      ra->slab_w[l] = wa->ly[l].slab_w; ra->slab_b[l] = wa->ly[l].slab_b;
-      ra->splits[l] = wa->ly[l].splits; ra->slab_stride[l] = wa->ly[l].slab_stride;
-      ra->first[l] = first;
+      const int m = l0 + l;
+      ra->N[m] = L.N[l]; ra->K[m] = L.K[l]; ra->Kp[m] = wa->ly[m].kt * 32;
+      ra->slab_w[m] = wa->ly[m].slab_w; ra->slab_b[m] = wa->ly[m].slab_b;
+      ra->splits[m] = wa->ly[m].splits; ra->slab_stride[m] = wa->ly[m].slab_stride;
+      ra->first[m] = first;
       first += (int64_t)L.N[l] * L.K[l] + L.N[l];
     }
-    ra->first[L.nl] = first;
+    ra->first[l0 + L.nl] = first;
   }
   return slab;
 }
@@ -3237,6 +3244,45 @@ extern "C" size_t dmv_mlp_backward_ws_bytes(const DmvNet* net, int64_t rows) {
   const int64_t Hp = dmv_pad32(net->hidden);
   const int64_t dacts = (2 * net->nb + 1) * ((rows + 31) & ~(int64_t)31) * Hp;
   return (size_t)(dacts + slab_floats) * sizeof(float);
+}
+
+// Plans a network's weight-gradient GEMMs into the layers l0 .. of wa / ra and points them at what its input-gradient
+// chain left in ws.
+static int wgrad_bind(const DmvNet* net, const float* saved, const float* gy, int64_t ldgy, int64_t rows,
+                      float* const* grad_w, float* const* grad_b, void* ws, size_t ws_bytes, WgradArgs* wa, ReduceArgs* ra,
+                      int l0, double slots = 1024.0) {
+  const int64_t Hp = dmv_pad32(net->hidden), Ip = dmv_pad32(net->in_dim);
+  const int64_t rp = (rows + 31) & ~(int64_t)31;
+  const float* xs = saved;
+  const float* acts = saved + rp * Ip;
+  float* dacts = (float*)ws;
+  float* slab = dacts + (2 * net->nb + 1) * rp * Hp;
+  const int64_t slab_floats = wgrad_plan(net, rows, wa, ra, l0, slots);
+  if (((2 * net->nb + 1) * rp * Hp + slab_floats) * (int64_t)sizeof(float) > (int64_t)ws_bytes) return DMV_E_WORKSPACE;
+  const int nl = wa->nl - l0;
+  for (int l = 0; l < nl; ++l) {
+    if (!grad_w[l] || !grad_b[l]) return DMV_E_BADARG;
+    WgradLayer& y = wa->ly[l0 + l];
+    if (l == 0) { y.X = xs; y.ldx = Ip; } else { y.X = acts + (int64_t)(l - 1) * rp * Hp; y.ldx = Hp; }
+    if (l == nl - 1) { y.dY = gy; y.ldy = ldgy; } else { y.dY = dacts + (int64_t)l * rp * Hp; y.ldy = Hp; }
+    y.slab = slab;
+    ra->slab[l0 + l] = slab;
+    ra->gw[l0 + l] = grad_w[l];
+    ra->gb[l0 + l] = grad_b[l];
+  }
+  return DMV_OK;
+}
+
+static int wgrad_launch(const WgradArgs& wa, ReduceArgs& ra, float beta, hipStream_t st) {
+  ra.beta = beta;
+  hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)((wa.total_waves + 3) / 4)), dim3(256), 0, st, wa);
+  DMV_HIP_CHECK_LAUNCH();
+  const int64_t total = ra.first[ra.nl];
+  unsigned rgrid = (unsigned)((total + 255) / 256);
+  if (rgrid > 4096) rgrid = 4096;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(rgrid), dim3(256), 0, st, ra);
+  DMV_HIP_CHECK_LAUNCH();
+  return DMV_OK;
 }
 
 // run_chain: the input-gradient chain (fills the per-layer gradients in ws); grad_w != NULL: the weight-gradient GEMMs
@@ -3259,10 +3305,8 @@ static int mlp_backward_impl(const DmvNet* net, const float* packed, const float
   hipStream_t st = (hipStream_t)stream;
   const int64_t Hp = dmv_pad32(net->hidden), Ip = dmv_pad32(net->in_dim);
   const int64_t rp = (rows + 31) & ~(int64_t)31;
-  const float* xs = saved;
   const float* acts = saved + rp * Ip;
   float* dacts = (float*)ws;
-  float* slab = dacts + (2 * net->nb + 1) * rp * Hp;
 
   BwdArgs b;
   b.L = dmv_layout(net);
@@ -3292,27 +3336,9 @@ static int mlp_backward_impl(const DmvNet* net, const float* packed, const float
 
   WgradArgs wa;
   ReduceArgs ra;
-  wgrad_plan(net, rows, &wa, &ra);
-  const int nl = wa.nl;
-  for (int l = 0; l < nl; ++l) {
-    if (!grad_w[l] || !grad_b[l]) return DMV_E_BADARG;
-    WgradLayer& y = wa.ly[l];
-    if (l == 0) { y.X = xs; y.ldx = Ip; } else { y.X = acts + (int64_t)(l - 1) * rp * Hp; y.ldx = Hp; }
-    if (l == nl - 1) { y.dY = gy; y.ldy = ldgy; } else { y.dY = dacts + (int64_t)l * rp * Hp; y.ldy = Hp; }
-    ra.gw[l] = grad_w[l];
-    ra.gb[l] = grad_b[l];
-  }
-  wa.slab = slab;
-  ra.slab = slab;
-  ra.beta = beta;
-  hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)((wa.total_waves + 3) / 4)), dim3(256), 0, st, wa);
-  DMV_HIP_CHECK_LAUNCH();
-  const int64_t total = ra.first[nl];
-  unsigned rgrid = (unsigned)((total + 255) / 256);
-  if (rgrid > 4096) rgrid = 4096;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(rgrid), dim3(256), 0, st, ra);
-  DMV_HIP_CHECK_LAUNCH();
-  return DMV_OK;
+  rc = wgrad_bind(net, saved, gy, ldgy, rows, grad_w, grad_b, ws, ws_bytes, &wa, &ra, 0);
+  if (rc) return rc;
+  return wgrad_launch(wa, ra, beta, st);
 }
 
 extern "C" int dmv_mlp_backward(const DmvNet* net, const float* packed, const float* saved, const uint8_t* drop_keep,
@@ -3329,6 +3355,43 @@ extern "C" int dmv_mlp_backward_wgrad(const DmvNet* net, const float* saved, con
   if (!grad_w || !grad_b) return DMV_E_BADARG;
   return mlp_backward_impl(net, nullptr, saved, nullptr, gy, ldgy, rows, nullptr, 0, grad_w, grad_b, beta, ws, ws_bytes,
                            stream, false);
+}
+
+static int wgrad_operands_ok(const DmvNet* net, const float* saved, const float* gy, int64_t ldgy, int64_t rows,
+                             float* const* grad_w, float* const* grad_b, void* ws, size_t ws_bytes) {
+  int rc = dmv_check_net(net);
+  if (rc) return rc;
+  if (!saved || !gy || rows <= 0 || !ws || !grad_w || !grad_b) return DMV_E_BADARG;
+  if (ldgy < dmv_pad32(net->out_dim) || (ldgy & 3) || ((uintptr_t)gy & 15) || ((uintptr_t)ws & 15)) return DMV_E_BADARG;
+  if (ws_bytes < dmv_mlp_backward_ws_bytes(net, rows)) return DMV_E_WORKSPACE;
+  return DMV_OK;
+}
+
+extern "C" int dmv_mlp_backward_wgrad_pair(const DmvNet* net_a, const float* saved_a, const float* gy_a, int64_t ldgy_a,
+                                           int64_t rows_a, float* const* grad_w_a, float* const* grad_b_a, void* ws_a,
+                                           size_t ws_bytes_a, const DmvNet* net_b, const float* saved_b, const float* gy_b,
+                                           int64_t ldgy_b, int64_t rows_b, float* const* grad_w_b, float* const* grad_b_b,
+                                           void* ws_b, size_t ws_bytes_b, float beta, void* stream) {
+  int rc = wgrad_operands_ok(net_a, saved_a, gy_a, ldgy_a, rows_a, grad_w_a, grad_b_a, ws_a, ws_bytes_a);
+  if (rc) return rc;
+  rc = wgrad_operands_ok(net_b, saved_b, gy_b, ldgy_b, rows_b, grad_w_b, grad_b_b, ws_b, ws_bytes_b);
+  if (rc) return rc;
+  const int nl_a = 2 * net_a->nb + 2, nl_b = 2 * net_b->nb + 2;
+  if (nl_a + nl_b > DMV_WGRAD_MAX_LAYERS) return DMV_E_UNSUPPORTED;
+  WgradArgs wa;
+  ReduceArgs ra;
+  // the two networks share one round of wave slots in proportion to their MFMA work (two full rounds would queue one
+  // behind the other): fewer, longer row slices than in two separate calls, hence sums in a different (fixed) order
+  double wt_a = 0, wt_b = 0;
+  wgrad_plan(net_a, rows_a, &wa, nullptr, 0, 1024.0, &wt_a);
+  wgrad_plan(net_b, rows_b, &wa, nullptr, 0, 1024.0, &wt_b);
+  const double ta = wt_a * (double)rows_a, tb = wt_b * (double)rows_b;
+  const double sa = 1024.0 * ta / (ta + tb), sb = 1024.0 * tb / (ta + tb);
+  rc = wgrad_bind(net_a, saved_a, gy_a, ldgy_a, rows_a, grad_w_a, grad_b_a, ws_a, ws_bytes_a, &wa, &ra, 0, sa);
+  if (rc) return rc;
+  rc = wgrad_bind(net_b, saved_b, gy_b, ldgy_b, rows_b, grad_w_b, grad_b_b, ws_b, ws_bytes_b, &wa, &ra, nl_a, sb);
+  if (rc) return rc;
+  return wgrad_launch(wa, ra, beta, (hipStream_t)stream);
 }
 
 // ---- decoder chain -> latent-side gradient -> encoder chain in one launch

@@ -366,6 +366,33 @@ def mlp_wgrad(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: int, 
     return grads
 
 
+def mlp_wgrad_pair(net_a: PackedNet, saved_a, gy_a, rows_a: int, ws_a, nbytes_a: int, net_b: PackedNet, saved_b, gy_b,
+                   rows_b: int, ws_b, nbytes_b: int, *, complete_a: bool = False, complete_b: bool = False):
+    """mlp_wgrad for two networks whose input-gradient chains are done, as one pair of launches on the current stream
+    (dmv_mlp_backward_wgrad_pair): (gradients of a, gradients of b), or None when the library does not take the pair."""
+    out = []
+    for net in (net_a, net_b):
+        net.refuse_pass_during_exchange()
+        views = net.grad_views() if net.flat_grads else None
+        if views is not None:
+            out.append((views[0::2], views[1::2], True))
+        else:
+            out.append(([torch.empty_like(w) for w in net.weights], [torch.empty_like(b) for b in net.biases], False))
+    (gwa, gba, slab_a), (gwb, gbb, slab_b) = out
+    rc = L.lib().dmv_mlp_backward_wgrad_pair(
+        C.byref(net_a.c), L.ptr(saved_a), L.ptr(gy_a), gy_a.shape[1], rows_a, L.ptr_array(gwa), L.ptr_array(gba), L.ptr(ws_a),
+        nbytes_a, C.byref(net_b.c), L.ptr(saved_b), L.ptr(gy_b), gy_b.shape[1], rows_b, L.ptr_array(gwb), L.ptr_array(gbb),
+        L.ptr(ws_b), nbytes_b, 0.0, L.stream_ptr())
+    if rc == L.E_UNSUPPORTED:
+        return None
+    L.check(rc)
+    for net, complete, in_slab in ((net_a, complete_a, slab_a), (net_b, complete_b, slab_b)):
+        if complete and in_slab and net.on_grads_ready is not None:
+            net.on_grads_ready(net)
+    flat = lambda ws_, bs_: [t for pair in zip(ws_, bs_) for t in pair]
+    return flat(gwa, gba), flat(gwb, gbb)
+
+
 def make_keep_masks(dims: NetDims, rows: int, device, generator: Optional[torch.Generator] = None):
     """Bernoulli(1-p) keep masks [nb, rows, hidden] uint8 for the blocks' dropout layers."""
     if dims.dropout <= 0 or dims.nb == 0:

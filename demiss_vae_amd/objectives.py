@@ -23,7 +23,8 @@ import torch
 
 from . import _lib as L
 from . import rng
-from .mlp import PackedNet, GeneratedDropout, mlp_forward, mlp_backward, mlp_wgrad, pad32, side_stream, overlap_pays
+from .mlp import (PackedNet, GeneratedDropout, mlp_forward, mlp_backward, mlp_wgrad, mlp_wgrad_pair, pad32, side_stream,
+                  overlap_pays)
 
 
 @dataclass(frozen=True)
@@ -395,6 +396,7 @@ def _enc_side(c, enc: PackedNet, p: L.DmvLatentBwd, dZ, wgt, zscale, dlogit, kl_
 
 
 FUSE_SMALL_BACKWARD = True     # tests switch it off to compare with the separate launches
+PAIR_WGRAD = True              # ... and this one to compare with the two networks' weight gradients on two streams
 
 
 def _one_launch_backward(c, enc: PackedNet, dec: PackedNet, p: L.DmvLatentBwd, wgt_dec, base_m, base_f, wgt, zscale, kl_wgt,
@@ -432,6 +434,11 @@ def _one_launch_backward(c, enc: PackedNet, dec: PackedNet, p: L.DmvLatentBwd, w
         L.ptr(dlogit), L.ptr(gscale), st))
     g_dec = None
     side = None
+    if dec_param_grads and PAIR_WGRAD:
+        pair = mlp_wgrad_pair(dec, c.dec_saved, d_dec, c.N, ws_dec, nb_dec, enc, c.enc_saved, d_enc, c.enc_rows, ws_enc, nb_enc,
+                              complete_a=complete)
+        if pair is not None:
+            return pair
     if dec_param_grads:
         side = side_stream(dev)
         side.wait_stream(torch.cuda.current_stream())

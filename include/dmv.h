@@ -140,6 +140,19 @@ int dmv_mlp_backward_wgrad(const DmvNet* net, const float* saved, const float* g
                            float* const* grad_w, float* const* grad_b, float beta, void* ws, size_t ws_bytes,
                            void* stream);
 
+/* The same for two networks in one pair of launches (the encoder and the decoder of a step whose input-gradient chains
+ * are done, e.g. after dmv_vae_backward): the weight gradients that autograd forms for both networks' nn.Linear layers
+ * in the reference (vgiwae/shared/neural_nets.py:101-133 under loss.backward()).  Every argument as in
+ * dmv_mlp_backward_wgrad, once per network.  The two networks share one round of the GPU's wave slots, so the row
+ * slices are longer than in two separate calls: the same sums in another fixed order (reproducible run to run, equal to
+ * the separate calls to rounding).  Networks with more than 24 layers between them: DMV_E_UNSUPPORTED (call
+ * dmv_mlp_backward_wgrad twice). */
+int dmv_mlp_backward_wgrad_pair(const DmvNet* net_a, const float* saved_a, const float* gy_a, int64_t ldgy_a, int64_t rows_a,
+                                float* const* grad_w_a, float* const* grad_b_a, void* ws_a, size_t ws_bytes_a,
+                                const DmvNet* net_b, const float* saved_b, const float* gy_b, int64_t ldgy_b, int64_t rows_b,
+                                float* const* grad_w_b, float* const* grad_b_b, void* ws_b, size_t ws_bytes_b, float beta,
+                                void* stream);
+
 /* ----- objective --------------------------------------------------------------------------
  * Sample rows are ordered n = (s*B + b)*G + g with s = z*I + i  (reference tensor shapes
  * [nz, I, B, (G,) .]).  Encoder-output addressing (in floats, per datapoint b and component g):

@@ -520,3 +520,41 @@ def test_weight_images_share_a_slab_and_fall_back_when_it_is_full():
         mlp._image_slabs.pop(key, None)
         if saved is not None:
             mlp._image_slabs[key] = saved
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shapes", [((16, 32, 2, 256), 512, (16, 16, 2, 256), 2560),
+                                    ((86, 325, 5, 256), 1024, (32, 86, 2, 256), 5120),
+                                    ((10, 4, 3, 200), 320, (2, 10, 3, 200), 64),
+                                    ((16, 32, 8, 64), 100, (16, 16, 3, 64), 500)])
+def test_weight_gradients_of_two_networks_in_one_launch(shapes):
+    """dmv_mlp_backward_wgrad_pair forms both networks' weight gradients as two dmv_mlp_backward_wgrad calls do (to
+    rounding: the pair cuts the rows into fewer slices), the same bits call after call; networks with more than 24 layers
+    between them are declined (the last case) and the caller makes the two calls."""
+    import ctypes as C
+    import demiss_vae_amd as dmv
+    import gpu_util as G
+    from demiss_vae_amd import _lib as L
+    from demiss_vae_amd.mlp import mlp_forward, mlp_wgrad, mlp_wgrad_pair, pad32
+    sa, ra, sb, rb = shapes
+    done = []
+    for k, (shape, rows) in enumerate(((sa, ra), (sb, rb))):
+        spec = NetSpec(*shape)
+        net = G.packed_net(spec, make_params(spec, 70 + k))
+        x = make_noise(80 + k, rows, pad32(spec.in_dim)).cuda()
+        _, saved = mlp_forward(net, x, x.shape[1], rows, save=True)
+        gy = make_noise(90 + k, rows, pad32(spec.out_dim)).cuda()
+        nbytes = L.lib().dmv_mlp_backward_ws_bytes(C.byref(net.c), rows)
+        ws = torch.empty((nbytes + 3) // 4, device="cuda")
+        L.check(L.lib().dmv_mlp_backward(C.byref(net.c), L.ptr(net.packed()), L.ptr(saved), None, L.ptr(gy), gy.shape[1], rows,
+                                         None, 0, None, None, 0.0, L.ptr(ws), nbytes, L.stream_ptr()))
+        done.append((net, saved, gy, rows, ws, nbytes))
+    one = [mlp_wgrad(*d) for d in done]
+    pair = mlp_wgrad_pair(*done[0], *done[1])
+    if 2 * (sa[2] + sb[2]) + 4 > 24:
+        assert pair is None
+        return
+    again = mlp_wgrad_pair(*done[0], *done[1])
+    for a, b, c in zip(one[0] + one[1], pair[0] + pair[1], again[0] + again[1]):
+        assert a.shape == b.shape and torch.equal(b, c) and float(a.abs().max()) > 0
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())

@@ -727,3 +727,36 @@ def test_forward_with_bound_equals_two_launches(case):
     for a, b in zip(one[3], two[3]):
         assert torch.isfinite(a).all()
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, (case, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_step_with_paired_weight_gradients_equals_two_streams():
+    """After the one-launch backward the weight gradients of encoder and decoder are formed by one pair of launches
+    (dmv_mlp_backward_wgrad_pair) instead of side by side on two streams: equal to rounding (the pair cuts the rows into
+    fewer slices), with and without a permanent gradient buffer."""
+    import demiss_vae_amd as dmv
+    from demiss_vae_amd import objectives as O, rng, synth
+    dims = dmv.ModelDims(D=8, Zd=16, encoder_use_mis_mask=True)
+    gen = torch.Generator().manual_seed(21)
+    X = torch.randn(512, 8, generator=gen).cuda()
+    M = (torch.rand(512, 8, generator=gen) < 0.5).cuda()
+
+    def run(pair, flat):
+        enc = synth.packed_net(synth.NetShape(16, 32, 2, 256), 1, "cuda")
+        dec = synth.packed_net(synth.NetShape(16, 16, 2, 256), 2, "cuda")
+        if flat:
+            enc.use_flat_grads()
+            dec.use_flat_grads()
+        rng.set_seed(9)
+        O.PAIR_WGRAD = pair
+        try:
+            bound, _ = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=1, num_importance_samples=5, STL=True)
+            (-bound).backward()
+        finally:
+            O.PAIR_WGRAD = True
+        torch.cuda.synchronize()
+        return [t.grad.clone() for t in enc.params() + dec.params()]
+
+    for flat in (False, True):
+        a, b = run(True, flat), run(False, flat)
+        for x, y in zip(a, b):
+            assert float(y.abs().max()) > 0 and float((x - y).abs().max()) <= 1e-5 * float(y.abs().max())
