@@ -45,19 +45,29 @@ struct FwdArgs {
   float* mean1; float* mean2; float* neg1;
 };
 
-// End of an objective-forward workgroup when the launch also forms the batch means: make this workgroup's results
-// visible, take a ticket, and if it was the last one, sum what all workgroups wrote (then leave the counter at zero for
-// the next launch).  Every thread of the workgroup must call it.
-__device__ __forceinline__ void finish_means(const FwdArgs& a) {
+// Batch means in the launch that forms the per-datapoint results: every workgroup takes a ticket when its results are
+// out, and the one that draws the last ticket sums what all of them wrote (then leaves the counter at zero for the next
+// launch).  Making ordinary stores visible to that workgroup would take a device-scope release, i.e. a write-back of every
+// dirty L2 line the kernels before this one have left on this multi-die part (10 us in a small batch's step).  The few
+// results that are summed therefore go out as device-scope atomic exchanges, which are performed at the level all compute
+// dies share; their old values come back into `parked`, and finish_means uses `parked` before the barrier in front of the
+// ticket, so every exchange of the workgroup has been performed by then.
+__device__ __forceinline__ void put_result(const FwdArgs& a, float* dst, float v, float& parked) {
+  if (a.ticket) parked += atomicExch(dst, v);
+  else *dst = v;
+}
+
+// Every thread of the workgroup must call it.
+__device__ __forceinline__ void finish_means(const FwdArgs& a, float parked) {
   if (!a.ticket) return;
   __shared__ float sh[32];
   __shared__ unsigned last;
-  __threadfence();
+  sh[threadIdx.x & 31] = parked;            // (waits for the exchanges; the values are never read)
   __syncthreads();
   if (threadIdx.x == 0) last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
   if (!last) return;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (a.kind == DMV_BOUND_PER_COMPONENT) {
     const int64_t pairs = (int64_t)a.B * a.G;
     block_mean2(sh, a.objA, a.objB, pairs, 1.f / (float)pairs, a.mean1, a.mean2, nullptr);
@@ -145,7 +155,7 @@ __device__ __forceinline__ void row_terms(const FwdArgs& a, int r, int64_t n, in
 }
 
 __device__ __forceinline__ void bound_phases(const FwdArgs& a, float* lw, float* aux, int tid, int nthr, int b0, int nb, int Qn,
-                                             int Q, int64_t BG, int64_t row0);
+                                             int Q, int64_t BG, int64_t row0, float& parked);
 
 __device__ __forceinline__ float tsum(float v, int T) {
   for (int o = T >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -219,14 +229,15 @@ __global__ void __launch_bounds__(256) k_obj_fwd(FwdArgs a) {
     }
   }
   if (a.kind < 0) return;
-  bound_phases(a, lw, aux, tid, nthr, b0, nb, Qn, Q, BG, row0);
-  finish_means(a);
+  float parked = 0.f;
+  bound_phases(a, lw, aux, tid, nthr, b0, nb, Qn, Q, BG, row0, parked);
+  finish_means(a, parked);
 }
 
 // Everything after the log-weights of a workgroup's rows are in LDS: bounds by logsumexp over (i, g), weights of the
 // backward, mixture-logit gradients, per-component objectives.  lw [S][Q], aux as laid out by the kernels.
 __device__ __forceinline__ void bound_phases(const FwdArgs& a, float* lw, float* aux, int tid, int nthr, int b0, int nb, int Qn,
-                                             int Q, int64_t BG, int64_t row0) {
+                                             int Q, int64_t BG, int64_t row0, float& parked) {
   const bool per_comp = a.kind == DMV_BOUND_PER_COMPONENT;
   // ---- normalised log mixture weights of the block's datapoints
   const bool need_pi = !per_comp && (a.use_logpi || a.kind == DMV_BOUND_WEIGHTED);
@@ -251,8 +262,8 @@ __device__ __forceinline__ void bound_phases(const FwdArgs& a, float* lw, float*
     for (int q = tid; q < Qn; q += nthr) {
       float sA = 0.f, sB = 0.f;
       for (int s = 0; s < a.S; ++s) { sA += lw[s * Q + q]; sB += aux[s * Q + q]; }
-      if (a.objA) a.objA[row0 + q] = sA / (float)a.nz;
-      if (a.objB) a.objB[row0 + q] = sB / (float)a.nz;
+      if (a.objA) put_result(a, a.objA + row0 + q, sA / (float)a.nz, parked);
+      if (a.objB) put_result(a, a.objB + row0 + q, sB / (float)a.nz, parked);
     }
     return;
   }
@@ -287,7 +298,7 @@ __device__ __forceinline__ void bound_phases(const FwdArgs& a, float* lw, float*
           }
         }
       }
-      if (lt == 0) a.bound[b0 + bl] = bacc * inv_nz;
+      if (lt == 0) put_result(a, a.bound + b0 + bl, bacc * inv_nz, parked);
     }
   } else {
     // sum_g pi_g (logsumexp_i log_w - log I): one thread per datapoint (G and I are small here)
@@ -316,7 +327,7 @@ __device__ __forceinline__ void bound_phases(const FwdArgs& a, float* lw, float*
         bacc += tot;
         for (int g = 0; g < a.G; ++g) dl[bl * a.G + g] += expf(lpi[bl * a.G + g]) * (Lg[bl * a.G + g] - tot) * inv_nz;
       }
-      a.bound[b0 + bl] = bacc * inv_nz;
+      put_result(a, a.bound + b0 + bl, bacc * inv_nz, parked);
     }
   }
   if (!need_w) return;
@@ -471,8 +482,9 @@ __global__ void __launch_bounds__(256) k_obj_fwd_rows4(FwdArgs a) {
     }
   }
   if (a.kind < 0) return;
-  bound_phases(a, lw, aux, tid, nthr, b0, nb, Qn, Q, BG, row0);
-  finish_means(a);
+  float parked = 0.f;
+  bound_phases(a, lw, aux, tid, nthr, b0, nb, Qn, Q, BG, row0, parked);
+  finish_means(a, parked);
 }
 
 // the same means as a launch of their own (callers that bring no ticket counter): one workgroup of 1024 threads
@@ -521,8 +533,9 @@ extern "C" int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const f
   const int64_t pairs = (int64_t)cfg->B * cfg->G;
   hipStream_t st = (hipStream_t)stream;
   const bool want_means = f->mean_out || f->meanA_out || f->meanB_out || f->neg_mean_out;
-  // (decided per launch below: a ticket costs every workgroup a device-scope release - an L2 write-back on this
-  // multi-die part - which pays for itself only in the short launches of small batches)
+  // (decided per launch below: the ticket's last workgroup sums the whole batch on its own, 6 us at 512 workgroups of 64
+  // threads against 5 us for k_mean2 in a launch of its own: it pays for itself only in the short launches of small
+  // batches)
   a.ticket = nullptr;
   auto use_ticket = [&](unsigned workgroups) {
     a.ticket = (want_means && kind >= 0 && workgroups <= 256) ? (unsigned*)f->ticket : nullptr;
@@ -602,6 +615,11 @@ extern "C" int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const f
       if (NG / x <= 64) DPB = NG / x;
     }
   }
+  // ... unless the batch is too small to fill the chip anyway (as on the four-dimensions-per-lane path above): a
+  // workgroup's time is then its chain of rounds, which shortens with the datapoints it holds, so a mixture posterior's
+  // datapoints are spread over up to 512 workgroups (hepmass shapes at B = 512, 5 components: 8 datapoints = 5 rounds per
+  // workgroup on 64 workgroups took 44 us, one datapoint per workgroup 14 us + 5 us for the mean in a launch of its own)
+  if (nthr == 64 && f->q_kind != DMV_Q_OWN) { const int want = (cfg->B + 511) / 512; if (DPB > want) DPB = want; }
   // LDS: the q table (16 bytes per (datapoint, component, dimension)), S*Q log-weights (twice for the two objectives of
   // the per-component kind) and 3*Q floats of mixture bookkeeping
   auto lds_bytes = [&](int dpb, int nC) {

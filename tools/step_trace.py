@@ -52,12 +52,14 @@ elif what == "wide":
         opt.zero_grad(set_to_none=True)
         loss.backward(unit_gradient(loss))
         opt.step()
-elif what in ("hepmass", "miniboone"):
+elif what in ("hepmass", "miniboone", "hepmass512", "miniboone1024"):
     # MissSIWAE (stratified mixture of 5, one sample per component): configs/uci_hepmass, configs/uci_miniboone shapes
     from demiss_vae_amd import synth
     from demiss_vae_amd.imputation import _keep as keep_for
-    B, D, Zd, es, ds, p = (4096, 21, 16, (42, 165, 2, 256), (16, 42, 2, 256), 0.0) if what == "hepmass" else \
+    B, D, Zd, es, ds, p = (4096, 21, 16, (42, 165, 2, 256), (16, 42, 2, 256), 0.0) if what.startswith("hepmass") else \
         (8192, 43, 32, (86, 325, 5, 256), (32, 86, 2, 256), 0.5)
+    if what in ("hepmass512", "miniboone1024"):      # the batch sizes of the configs themselves
+        B = int(what[-4:].lstrip("s"))
     enc = synth.packed_net(synth.NetShape(*es, dropout=p), 1, "cuda")
     dec = synth.packed_net(synth.NetShape(*ds, dropout=p), 2, "cuda")
     dims = dmv.ModelDims(D=D, Zd=Zd, q_dist="stratified_with_eps", C=5, encoder_use_mis_mask=True)
