@@ -2510,7 +2510,7 @@ struct ReduceArgs {
   int nl;
   int N[DMV_WGRAD_MAX_LAYERS], K[DMV_WGRAD_MAX_LAYERS], Kp[DMV_WGRAD_MAX_LAYERS];
   int64_t slab_w[DMV_WGRAD_MAX_LAYERS], slab_b[DMV_WGRAD_MAX_LAYERS];
-  int64_t first[DMV_WGRAD_MAX_LAYERS + 1];  // prefix sums of N*K + N
+  int64_t first[DMV_WGRAD_MAX_LAYERS + 1];  // prefix sums of N*K + N, each rounded up to a multiple of four
   float* gw[DMV_WGRAD_MAX_LAYERS];
   float* gb[DMV_WGRAD_MAX_LAYERS];
   int splits[DMV_WGRAD_MAX_LAYERS];
@@ -2520,36 +2520,86 @@ struct ReduceArgs {
 };
 
 #if DMV_PART(1)
+// One element of a layer's gradient: the splits are added in order (bitwise reproducible), their loads requested
+// eight at a time.
+__device__ __forceinline__ float reduce_one(const float* __restrict__ sp, int64_t ss, int ns) {
+  float s = 0.f;
+  int p = 0;
+  for (; p + 8 <= ns; p += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = sp[(int64_t)(p + u) * ss];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; p < ns; ++p) s += sp[(int64_t)p * ss];
+  return s;
+}
+
+// A thread folds four consecutive elements (the index space gives every layer a multiple of four slots: first[]): with
+// 16-byte loads and one 16-byte store where the layer's rows and the buffers allow it (input width a multiple of four,
+// aligned gradient tensors), else element by element.  Either way every element is the sum of its splits in order.
 __global__ void k_wgrad_reduce(ReduceArgs a) {
-  const int64_t total = a.first[a.nl];
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t total4 = a.first[a.nl] >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = q << 2;
     int l = 0;
     while (i >= a.first[l + 1]) ++l;
     const int64_t e = i - a.first[l];
     const int64_t nk = (int64_t)a.N[l] * a.K[l];
-    int64_t src;
-    float* dst;
-    if (e < nk) {
-      const int n = (int)(e / a.K[l]), k = (int)(e % a.K[l]);
-      src = a.slab_w[l] + (int64_t)n * a.Kp[l] + k;
-      dst = a.gw[l] + e;
-    } else {
-      src = a.slab_b[l] + (e - nk);
-      dst = a.gb[l] + (e - nk);
-    }
-    // the splits are added in order (bitwise reproducible), their loads requested four at a time
-    float s = 0.f;
-    const float* __restrict__ sp = a.slab[l] + src;
+    const int64_t left = nk + a.N[l] - e;          // elements of this layer from e on (<= 0: padding slots)
+    if (left <= 0) continue;
     const int64_t ss = a.slab_stride[l];
     const int ns = a.splits[l];
-    int p = 0;
-    for (; p + 4 <= ns; p += 4) {
-      const float v0 = sp[(int64_t)p * ss], v1 = sp[(int64_t)(p + 1) * ss], v2 = sp[(int64_t)(p + 2) * ss],
-                  v3 = sp[(int64_t)(p + 3) * ss];
-      s += v0; s += v1; s += v2; s += v3;
+    const bool in_w = e < nk;
+    bool vec = left >= 4 && (a.K[l] & 3) == 0;
+    int64_t src;
+    float* dst;
+    if (vec) {
+      if (in_w) {
+        const int n = (int)(e / a.K[l]), k = (int)(e % a.K[l]);
+        src = a.slab_w[l] + (int64_t)n * a.Kp[l] + k;
+        dst = a.gw[l] + e;
+      } else {
+        src = a.slab_b[l] + (e - nk);
+        dst = a.gb[l] + (e - nk);
+      }
+      vec = ((((uintptr_t)dst) | ((uintptr_t)(a.slab[l] + src)) | ((uintptr_t)ss * 4u)) & 15) == 0;
     }
-    for (; p < ns; ++p) s += sp[(int64_t)p * ss];
-    *dst = (a.beta != 0.f) ? a.beta * (*dst) + s : s;
+    if (vec) {
+      const float* __restrict__ sp = a.slab[l] + src;
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      int p = 0;
+      for (; p + 8 <= ns; p += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(sp + (int64_t)(p + u) * ss);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; p < ns; ++p) s += *(const f32x4*)(sp + (int64_t)p * ss);
+      if (a.beta != 0.f) {
+        const f32x4 old = *(const f32x4*)dst;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] = a.beta * old[c] + s[c];
+      }
+      *(f32x4*)dst = s;
+      continue;
+    }
+    const int cnt = left < 4 ? (int)left : 4;
+    for (int c = 0; c < cnt; ++c) {
+      const int64_t ec = e + c;
+      if (ec < nk) {
+        const int n = (int)(ec / a.K[l]), k = (int)(ec % a.K[l]);
+        src = a.slab_w[l] + (int64_t)n * a.Kp[l] + k;
+        dst = a.gw[l] + ec;
+      } else {
+        src = a.slab_b[l] + (ec - nk);
+        dst = a.gb[l] + (ec - nk);
+      }
+      const float sc = reduce_one(a.slab[l] + src, ss, ns);
+      *dst = (a.beta != 0.f) ? a.beta * (*dst) + sc : sc;
+    }
   }
 }
 
@@ -3228,7 +3278,7 @@ static int64_t wgrad_plan(const DmvNet* net, int64_t rows, WgradArgs* wa, Reduce
       ra->slab_w[m] = wa->ly[m].slab_w; ra->slab_b[m] = wa->ly[m].slab_b;
       ra->splits[m] = wa->ly[m].splits; ra->slab_stride[m] = wa->ly[m].slab_stride;
       ra->first[m] = first;
-      first += (int64_t)L.N[l] * L.K[l] + L.N[l];
+      first += ((int64_t)L.N[l] * L.K[l] + L.N[l] + 3) & ~(int64_t)3;   // (k_wgrad_reduce: four slots per thread)
     }
     ra->first[l0 + L.nl] = first;
   }
@@ -3277,7 +3327,7 @@ static int wgrad_launch(const WgradArgs& wa, ReduceArgs& ra, float beta, hipStre
   ra.beta = beta;
   hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)((wa.total_waves + 3) / 4)), dim3(256), 0, st, wa);
   DMV_HIP_CHECK_LAUNCH();
-  const int64_t total = ra.first[ra.nl];
+  const int64_t total = ra.first[ra.nl] >> 2;
   unsigned rgrid = (unsigned)((total + 255) / 256);
   if (rgrid > 4096) rgrid = 4096;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(rgrid), dim3(256), 0, st, ra);
