@@ -2461,9 +2461,14 @@ __device__ __forceinline__ void wgrad_block(const WgradLayer& Ly, int nb0, int k
   }
 }
 
-template <int TN>
+template <int TN, int MAXB>
 __device__ __forceinline__ void wgrad_dispatch_k(int tk, const WgradLayer& Ly, int nb0, int kb0, int64_t r0, int64_t r1,
                                                  float* slab, int lane) {
+  if (MAXB <= 2) {
+    if (tk == 1) wgrad_block<TN, 1>(Ly, nb0, kb0, r0, r1, slab, lane);
+    else wgrad_block<TN, 2>(Ly, nb0, kb0, r0, r1, slab, lane);
+    return;
+  }
   switch (tk) {
     case 1: wgrad_block<TN, 1>(Ly, nb0, kb0, r0, r1, slab, lane); break;
     case 2: wgrad_block<TN, 2>(Ly, nb0, kb0, r0, r1, slab, lane); break;
@@ -2472,8 +2477,10 @@ __device__ __forceinline__ void wgrad_dispatch_k(int tk, const WgradLayer& Ly, i
   }
 }
 
-#if DMV_PART(1)
-__global__ __launch_bounds__(256, 1) void k_mlp_wgrad(WgradArgs a) {
+// One wave of the weight-gradient grid: finds its layer, block and row slice.  MAXB: the largest block edge the launch
+// holds (4, or 2 when every layer was planned with 2x2 blocks: a quarter of the accumulators, so two waves fit a SIMD).
+template <int MAXB>
+__device__ __forceinline__ void wgrad_wave(const WgradArgs& a) {
   const int lane = threadIdx.x & 63;
   // wave-uniform by construction; readfirstlane lets the compiler keep the whole work decomposition scalar
   const int wid = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2494,16 +2501,24 @@ __global__ __launch_bounds__(256, 1) void k_mlp_wgrad(WgradArgs a) {
 #ifdef DMV_TRACE
   if (lane == 0 && wid < 8192) dmv_trace_buf[16 * wid + 1] = l * 100 + tn * 10 + tk;
 #endif
-  switch (tn) {
-    case 1: wgrad_dispatch_k<1>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
-    case 2: wgrad_dispatch_k<2>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
-    case 3: wgrad_dispatch_k<3>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
-    default: wgrad_dispatch_k<4>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
+  if (MAXB <= 2) {
+    if (tn == 1) wgrad_dispatch_k<1, MAXB>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane);
+    else wgrad_dispatch_k<2, MAXB>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane);
+  } else {
+    switch (tn) {
+      case 1: wgrad_dispatch_k<1, MAXB>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
+      case 2: wgrad_dispatch_k<2, MAXB>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
+      case 3: wgrad_dispatch_k<3, MAXB>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
+      default: wgrad_dispatch_k<4, MAXB>(tk, Ly, nb0, kb0, r_begin, r_end, slab, lane); break;
+    }
   }
   TRACE(15);
   TRACE_REAL(14);
 }
 
+#if DMV_PART(1)
+__global__ __launch_bounds__(256, 1) void k_mlp_wgrad(WgradArgs a) { wgrad_wave<4>(a); }
+__global__ __launch_bounds__(256, 2) void k_mlp_wgrad_small(WgradArgs a) { wgrad_wave<2>(a); }
 #endif
 
 struct ReduceArgs {
@@ -3325,7 +3340,12 @@ static int wgrad_bind(const DmvNet* net, const float* saved, const float* gy, in
 
 static int wgrad_launch(const WgradArgs& wa, ReduceArgs& ra, float beta, hipStream_t st) {
   ra.beta = beta;
-  hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)((wa.total_waves + 3) / 4)), dim3(256), 0, st, wa);
+  // 2x2 blocks only: the kernel built for them (a quarter of the accumulator registers; gas step at B = 4096
+  // 0.497 -> 0.485 ms, other steps unchanged; a second wave per SIMD - 2048 wave slots - was measured and gains nothing)
+  bool small = true;
+  for (int l = 0; l < wa.nl; ++l) small = small && wa.ly[l].bt == 2;
+  if (small) hipLaunchKernelGGL(k_mlp_wgrad_small, dim3((unsigned)((wa.total_waves + 3) / 4)), dim3(256), 0, st, wa);
+  else hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)((wa.total_waves + 3) / 4)), dim3(256), 0, st, wa);
   DMV_HIP_CHECK_LAUNCH();
   const int64_t total = ra.first[ra.nl] >> 2;
   unsigned rgrid = (unsigned)((total + 255) / 256);
