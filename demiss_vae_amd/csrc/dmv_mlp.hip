@@ -1450,9 +1450,16 @@ struct VaeFwdArgs {
   float* zscale;              // nullable [N]
   unsigned* ticket;           // nullable: with it the launch also forms the batch mean
   float* mean; float* neg_mean;
+  // ... or a stratified mixture of mix_C = G Gaussians per datapoint, one sample row per component (MissSIWAE, the tight
+  // bound: logsumexp over (i, g) of log w + log pi_g): tiles of 16 / (S G) datapoints
+  int mix_C;                  // 0: one Gaussian per datapoint
+  float* terms;               // nullable [5][N]: masked / full generator term, prior, own component, mixture
+  float* comp_lp;             // nullable [N][mix_C]
+  float* dlogit;              // nullable [B][G]
 };
 
-template <int NT, bool SAVE>
+// MIX: the mixture bound's epilogue is compiled in (a.mix_C != 0); without it the component count is known to be one
+template <int NT, bool SAVE, bool MIX>
 __global__ __launch_bounds__(256, 1) void k_vae_fwd_rows16(VaeFwdArgs a) {
   constexpr int W = 4;
   __shared__ __attribute__((aligned(16))) float lds[Rows16<NT, W>::LDS_BYTES / 4];
@@ -1468,10 +1475,12 @@ __global__ __launch_bounds__(256, 1) void k_vae_fwd_rows16(VaeFwdArgs a) {
   const int m = lane & 15, g = lane >> 4;
   int64_t n = (int64_t)blockIdx.x * 16 + m;
   bool live = n < a.N;
-  if (a.obj_on) {                                              // tile row (q, s): sample s of the tile's q-th datapoint
-    const int Q = 16 / a.S, q = m / a.S, bq = (int)blockIdx.x * Q + q;
+  if (a.obj_on) {                          // tile row (q, s, g): sample s, component g of the tile's q-th datapoint
+    const int G1 = MIX ? a.G : 1;
+    const int SG = a.S * G1, Q = 16 / SG, q = m / SG, bq = (int)blockIdx.x * Q + q;
+    const int rem = m - q * SG, s = rem / G1;
     live = q < Q && bq < a.B;
-    n = live ? (int64_t)(m - q * a.S) * a.B + bq : 0;
+    n = live ? ((int64_t)s * a.B + bq) * G1 + (rem - s * G1) : 0;
   }
   const int nl = (int)(live ? n : (a.obj_on ? 0 : a.N - 1));   // N <= 4096 rows here
   const int BG = a.B * a.G;
@@ -1539,14 +1548,15 @@ __global__ __launch_bounds__(256, 1) void k_vae_fwd_rows16(VaeFwdArgs a) {
 
   // ---- the bound (vgiwae/shared/iwae.py:9-55 log-weights, vgiwae/models/iwae.py:70-123 logsumexp and mean): a group of
   // 16 lanes per sample row shares out the dimensions of its three sums
-  __shared__ float lw[16], bz[16], sh[32];
+  __shared__ float lw[16], lpi[16], bz[16], sh[32];
   __shared__ unsigned last;
   const int tid = threadIdx.x;
+  const int G1 = MIX ? a.G : 1;
   {
     const int p = tid >> 4, l16 = tid & 15;
     const int np = nrow[p];
     if (np >= 0) {
-      const int bb = np % a.B;
+      const int bb = (np / G1) % a.B;
       const float* z = zt + p * a.ZP;
       const float* pe = et + p * ldE + par_off[p];
       float pr = 0.f, qo = 0.f;
@@ -1561,33 +1571,70 @@ __global__ __launch_bounds__(256, 1) void k_vae_fwd_rows16(VaeFwdArgs a) {
       const uint8_t* mk = a.enc.m + (int64_t)bb * a.enc.ldm;
       const float* dec = dt + p * ldD;
       const float geps = a.gen_dist == DMV_GEN_NORMAL_EPS ? DMV_EPSILON : 0.f;
-      float gm = 0.f;
+      float gm = 0.f, gf = 0.f;
       for (int d = l16; d < a.D; d += 16) {
         float lp;
         if (a.gen_dist <= DMV_GEN_NORMAL_EPS) lp = log_normal_r(x[d], dec[d], dmv_softplus(dec[a.D + d]) + geps);
         else if (a.gen_dist == DMV_GEN_BERN) lp = log_bern(x[d], dec[d]);
         else lp = log_bern((x[d] + 1.f) * 0.5f, dec[d]);
+        if (MIX) gf += lp;
         gm += lp * (mk[d] ? 1.f : 0.f);          // (the product the reference forms: non-finite under a missing entry -> NaN)
       }
-      const float w = gsum<16>(gm) + gsum<16>(pr) - gsum<16>(qo);
+      gm = gsum<16>(gm); pr = gsum<16>(pr); qo = gsum<16>(qo);
+      if (MIX) gf = gsum<16>(gf);
+      float qm = qo;
+      if (MIX) lpi[p] = 0.f;
+      if (MIX && a.mix_C) {
+        // log q of the whole mixture at z (vgiwae/models/multiple_iwae.py:124-199): the datapoint's encoder row holds
+        // every component's parameters and the logits
+        const float* row = et + p * ldE;
+        const float* lg = row + a.q.logit_off;
+        float lm = -INFINITY;
+        for (int c = 0; c < a.mix_C; ++c) lm = fmaxf(lm, lg[c]);
+        float ss = 0.f;
+        for (int c = 0; c < a.mix_C; ++c) ss += dmv_exp(lg[c] - lm);
+        const float lse_logit = lm + dmv_log(ss);
+        float mx = -INFINITY, se = 0.f;
+        for (int c = 0; c < a.mix_C; ++c) {
+          const float* pc = row + (int64_t)c * a.q.sg;
+          float lp = 0.f;
+          for (int j = l16; j < a.Zd; j += 16)
+            lp += log_normal_r(z[j], pc[j], dmv_softplus(pc[a.q.raw_off + j]) + a.q.eps);
+          lp = gsum<16>(lp);
+          if (a.comp_lp && l16 == 0) a.comp_lp[(int64_t)np * a.mix_C + c] = lp;
+          const float t = lp + lg[c] - lse_logit;
+          const float nm = fmaxf(mx, t);
+          se = se * dmv_exp(mx - nm) + dmv_exp(t - nm);
+          mx = nm;
+        }
+        qm = mx + dmv_log(se);
+        lpi[p] = lg[np % G1] - lse_logit;
+      }
+      const float w = gm + pr - qm;
       if (l16 == 0) {
         lw[p] = w;
         if (a.log_w) a.log_w[np] = w;
+        if (MIX && a.terms) {
+          a.terms[np] = gm; a.terms[a.N + np] = gf; a.terms[2 * a.N + np] = pr; a.terms[3 * a.N + np] = qo;
+          a.terms[4 * a.N + np] = qm;
+        }
       }
     }
   }
   __syncthreads();
-  const int Q = 16 / a.S;
-  if (tid < Q * a.nz) {                           // logsumexp over the I samples of (datapoint, outer sample)
-    const int q = tid / a.nz, r0 = q * a.S + (tid - q * a.nz) * a.I;
+  const int IG = a.I * G1, Q = 16 / (a.S * G1);
+  if (tid < Q * a.nz) {                           // logsumexp over the I G rows of (datapoint, outer sample)
+    const int q = tid / a.nz, r0 = q * a.S * G1 + (tid - q * a.nz) * IG;
     if (nrow[r0] >= 0) {
+      if (MIX)
+        for (int i = 0; i < IG; ++i) lw[r0 + i] += lpi[r0 + i];
       float mx = -INFINITY;
-      for (int i = 0; i < a.I; ++i) mx = fmaxf(mx, lw[r0 + i]);
+      for (int i = 0; i < IG; ++i) mx = fmaxf(mx, lw[r0 + i]);
       float se = 0.f;
-      for (int i = 0; i < a.I; ++i) se += expf(lw[r0 + i] - mx);
+      for (int i = 0; i < IG; ++i) se += expf(lw[r0 + i] - mx);
       const float lse = mx + logf(se);
       bz[tid] = lse - logf((float)a.I);
-      for (int i = 0; i < a.I; ++i) lw[r0 + i] = expf(lw[r0 + i] - lse);
+      for (int i = 0; i < IG; ++i) lw[r0 + i] = expf(lw[r0 + i] - lse);
     }
   }
   __syncthreads();
@@ -1597,16 +1644,25 @@ __global__ __launch_bounds__(256, 1) void k_vae_fwd_rows16(VaeFwdArgs a) {
     if (a.wgt) a.wgt[nrow[tid]] = pw * inv_nz;
     if (a.zscale) a.zscale[nrow[tid]] = a.dreg ? pw : 1.f;
   }
+  if (MIX && a.dlogit && tid >= 32 && tid - 32 < Q * G1) {
+    // d/d logit_c of sum_n p_n log pi_{g(n)} = (sum_{n: g(n) = c} p_n) - pi_c per outer sample
+    const int q = (tid - 32) / G1, gg = (tid - 32) - q * G1, r0 = q * a.S * G1;
+    if (nrow[r0] >= 0) {
+      float acc = 0.f;
+      for (int s = 0; s < a.S; ++s) acc += lw[r0 + s * G1 + gg];
+      a.dlogit[(int64_t)((nrow[r0] / G1) % a.B) * G1 + gg] = (acc - (float)a.nz * expf(lpi[r0 + gg])) * inv_nz;
+    }
+  }
   // The batch mean in this launch.  The usual way (make the workgroup's results visible, take a ticket) would cost a
   // device-scope release here, i.e. a write-back of every dirty L2 line the forward pass has just produced (measured:
   // +17 us).  Instead the few bounds of a tile go out as device-scope atomic exchanges, which are performed at the level
   // all compute dies share; the ticket is taken only after their old values have come back (they are parked in LDS, so
   // the barrier waits for them), and the workgroup that draws the last ticket reads the bounds after an acquire.
-  if (tid >= 64 && tid - 64 < Q && nrow[(tid - 64) * a.S] >= 0) {
+  if (tid >= 64 && tid - 64 < Q && nrow[(tid - 64) * a.S * G1] >= 0) {
     const int q = tid - 64;
     float acc = 0.f;
     for (int zz = 0; zz < a.nz; ++zz) acc += bz[q * a.nz + zz];
-    float* dst = a.bound + nrow[q * a.S] % a.B;
+    float* dst = a.bound + (nrow[q * a.S * G1] / G1) % a.B;
     if (a.ticket) bz[q * a.nz] = atomicExch(dst, acc * inv_nz);
     else *dst = acc * inv_nz;
   }
@@ -2982,9 +3038,12 @@ extern "C" int dmv_mlp_forward(const DmvNet* net, const float* packed, int32_t i
 // ---- encoder -> sample -> decoder in one launch
 template <int NT>
 static int launch_vae_fwd(const VaeFwdArgs& a, size_t dyn_bytes, hipStream_t st) {
-  const unsigned tiles = a.obj_on ? (unsigned)dmv_ceil_div(a.B, 16 / a.S) : (unsigned)((a.N + 15) / 16);
-  if (a.dec.acts) hipLaunchKernelGGL((k_vae_fwd_rows16<NT, true>), dim3(tiles), dim3(256), dyn_bytes, st, a);
-  else hipLaunchKernelGGL((k_vae_fwd_rows16<NT, false>), dim3(tiles), dim3(256), dyn_bytes, st, a);
+  const unsigned tiles = a.obj_on ? (unsigned)dmv_ceil_div(a.B, 16 / (a.S * a.G)) : (unsigned)((a.N + 15) / 16);
+  if (a.mix_C) {
+    if (a.dec.acts) hipLaunchKernelGGL((k_vae_fwd_rows16<NT, true, true>), dim3(tiles), dim3(256), dyn_bytes, st, a);
+    else hipLaunchKernelGGL((k_vae_fwd_rows16<NT, false, true>), dim3(tiles), dim3(256), dyn_bytes, st, a);
+  } else if (a.dec.acts) hipLaunchKernelGGL((k_vae_fwd_rows16<NT, true, false>), dim3(tiles), dim3(256), dyn_bytes, st, a);
+  else hipLaunchKernelGGL((k_vae_fwd_rows16<NT, false, false>), dim3(tiles), dim3(256), dyn_bytes, st, a);
   DMV_HIP_CHECK_LAUNCH();
   return DMV_OK;
 }
@@ -3019,20 +3078,22 @@ static int vae_forward_impl(const DmvObjCfg* cfg, const DmvNet* enc, const float
                             float* eps_out, float* dec_out, float* dec_saved, const DmvObjFwd* obj, void* stream) {
   if (!vae_forward_fits(cfg, enc, dec)) return DMV_E_UNSUPPORTED;
   if (obj) {
-    // the bound in the same launch: one Gaussian per datapoint, logsumexp bound, a datapoint's samples in one tile
-    const int S = cfg->nz * cfg->I;
-    if (cfg->G != 1 || cfg->x_per_component || n_prior != 0 || S > 16) return DMV_E_UNSUPPORTED;
-    if (obj->q_kind != DMV_Q_OWN || obj->kind != DMV_BOUND_LSE || obj->use_logpi || obj->terms || obj->comp_lp || obj->dlogit ||
-        obj->objA || obj->objB)
-      return DMV_E_UNSUPPORTED;
+    // the bound in the same launch: a logsumexp bound over one Gaussian per datapoint, or over a stratified mixture with
+    // its log mixture weights (one sample row per component); a datapoint's rows in one tile
+    const int SG = cfg->nz * cfg->I * cfg->G;
+    const bool own = cfg->G == 1 && obj->q_kind == DMV_Q_OWN && !obj->use_logpi && !obj->terms && !obj->comp_lp && !obj->dlogit;
+    const bool strat = cfg->G > 1 && obj->q_kind == DMV_Q_STRATIFIED && obj->use_logpi && obj->mix_C == cfg->G && !obj->dreg &&
+                       cfg->logit_off + cfg->G <= dmv_pad32(enc->out_dim);
+    if (cfg->x_per_component || n_prior != 0 || SG > 16 || !(own || strat)) return DMV_E_UNSUPPORTED;
+    if (obj->kind != DMV_BOUND_LSE || obj->objA || obj->objB) return DMV_E_UNSUPPORTED;
     if (!obj->bound || !M) return DMV_E_BADARG;
     if (cfg->gen_dist < DMV_GEN_NORMAL || cfg->gen_dist > DMV_GEN_BERN_M1P1) return DMV_E_UNSUPPORTED;
     if (dec->out_dim != (cfg->gen_dist <= DMV_GEN_NORMAL_EPS ? 2 * cfg->D : cfg->D)) return DMV_E_BADARG;
     const bool want_means = obj->mean_out || obj->neg_mean_out;
-    if (want_means && (!obj->ticket || dmv_ceil_div(cfg->B, 16 / S) > 256)) return DMV_E_UNSUPPORTED;
+    if (want_means && (!obj->ticket || dmv_ceil_div(cfg->B, 16 / SG) > 256)) return DMV_E_UNSUPPORTED;
     const size_t dyn = sizeof(float) * 16 * ((size_t)dmv_pad32(enc->out_dim) + 16 * (size_t)dmv_ceil_div(cfg->Zd, 16) +
                                               (size_t)dmv_pad32(dec->out_dim));
-    if (dyn + (size_t)dmv_ceil_div(enc->hidden, 32) * 2048 + 512 > 65536) return DMV_E_UNSUPPORTED;
+    if (dyn + (size_t)dmv_ceil_div(enc->hidden, 32) * 2048 + 640 > 65536) return DMV_E_UNSUPPORTED;
   }
   if (n_prior < 0 || (n_prior > 0 && (!cfg->x_per_component || n_prior >= cfg->G))) return DMV_E_BADARG;
   if (!enc_packed || !dec_packed || !X || !enc_out || !Z || !dec_out || ldz < cfg->Zd) return DMV_E_BADARG;
@@ -3082,8 +3143,10 @@ static int vae_forward_impl(const DmvObjCfg* cfg, const DmvNet* enc, const float
   a.S = cfg->nz * cfg->I; a.nz = cfg->nz; a.I = cfg->I; a.D = cfg->D; a.gen_dist = cfg->gen_dist;
   a.dreg = 0; a.log_w = nullptr; a.bound = nullptr; a.wgt = nullptr; a.zscale = nullptr; a.ticket = nullptr;
   a.mean = nullptr; a.neg_mean = nullptr;
+  a.mix_C = 0; a.terms = nullptr; a.comp_lp = nullptr; a.dlogit = nullptr;
   if (obj) {
     a.dreg = obj->dreg; a.log_w = obj->log_w; a.bound = obj->bound; a.wgt = obj->wgt; a.zscale = obj->zscale;
+    if (obj->q_kind == DMV_Q_STRATIFIED) { a.mix_C = obj->mix_C; a.terms = obj->terms; a.comp_lp = obj->comp_lp; a.dlogit = obj->dlogit; }
     const bool want_means = obj->mean_out || obj->neg_mean_out;
     a.ticket = want_means ? (unsigned*)obj->ticket : nullptr;
     a.mean = obj->mean_out; a.neg_mean = obj->neg_mean_out;

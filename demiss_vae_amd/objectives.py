@@ -180,7 +180,7 @@ def _forward_core(dims: ModelDims, plan: _Plan, enc: PackedNet, dec: PackedNet, 
     fused = None
     if not dims.q_is_reparam and comp_idx is None and enc_keep is None and dec_keep is None:
         # small batches: encoder, sampling and decoder in one launch
-        defer = bound_follows and FUSE_SMALL_BOUND and not demiss and G == 1
+        defer = bound_follows and FUSE_SMALL_BOUND and not demiss
         fused = fused_forward(cfg, enc, dec, in_mode, Xc.reshape(enc_rows, D), Mu.reshape(enc_rows, D),
                               eps.reshape(N, Zd).contiguous().float() if eps is not None else None, training, training,
                               defer=defer)
@@ -270,7 +270,8 @@ def _objective_forward(c, plan: _Plan, training: bool, *, kind, use_logpi=False,
     pending, c.pending_forward = getattr(c, "pending_forward", None), None
     if pending is not None:
         # the forward has not run yet: with the bound in its launch if the shapes allow, else by itself
-        if kind == L.BOUND_LSE and c.q_kind == L.Q_OWN and not use_logpi and pending(f):
+        if kind == L.BOUND_LSE and ((c.q_kind == L.Q_OWN and not use_logpi) or (c.q_kind == L.Q_STRATIFIED and use_logpi)) \
+                and pending(f):
             global bound_launches
             bound_launches += 1
             return out

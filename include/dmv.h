@@ -248,14 +248,18 @@ typedef struct DmvObjFwd {
 int dmv_obj_forward(const DmvObjCfg* cfg, const DmvObjFwd* f, const float* dec, int64_t ld_dec, const float* X,
                     const uint8_t* M, const float* Z, int64_t ldz, const float* enc, void* stream);
 
-/* dmv_vae_forward and the bound of dmv_obj_forward in ONE launch, for posteriors with one Gaussian per datapoint
- * (vgiwae/models/vae.py:285-318 vae_forward, then vgiwae/shared/iwae.py:9-55 and vgiwae/models/iwae.py:70-123: the
- * IWAE / ELBO-by-samples bound with its logsumexp over the importance samples and mean over the outer ones).  Tiles are
- * datapoint-major - the nz*I samples of 16 / (nz*I) datapoints - so a datapoint's logsumexp stays inside a workgroup.
- * Every buffer of dmv_vae_forward is written with the same values; of obj: q_kind = DMV_Q_OWN, kind = DMV_BOUND_LSE,
- * bound [B], optional log_w / wgt / zscale [N], mean_out / neg_mean_out (these need `ticket` and at most 256 tiles).
- * X, M are the objective's data as well as the encoder's input.  DMV_E_UNSUPPORTED for anything else (mixtures, G > 1,
- * nz*I > 16, terms / comp_lp / dlogit / objA / objB requested, means without a ticket): then call dmv_vae_forward and
+/* dmv_vae_forward and the bound of dmv_obj_forward in ONE launch (vgiwae/models/vae.py:285-318 vae_forward, then
+ * vgiwae/shared/iwae.py:9-55 and vgiwae/models/iwae.py:70-123: the IWAE / ELBO-by-samples bound with its logsumexp over
+ * the importance samples and mean over the outer ones; vgiwae/models/multiple_iwae.py:124-199: the tight MissSIWAE bound
+ * of a stratified mixture posterior, logsumexp over (i, g) of log w + log pi_g).  Tiles are datapoint-major - the
+ * nz*I*G sample rows of 16 / (nz*I*G) datapoints - so a datapoint's logsumexp stays inside a workgroup.  Every buffer of
+ * dmv_vae_forward is written with the same values.  Of obj: kind = DMV_BOUND_LSE, bound [B], optional log_w / wgt /
+ * zscale [N], mean_out / neg_mean_out (these need `ticket` and at most 256 tiles), and either
+ *   q_kind = DMV_Q_OWN with cfg->G == 1 and use_logpi = 0, or
+ *   q_kind = DMV_Q_STRATIFIED with mix_C = cfg->G > 1, use_logpi = 1, dreg = 0; then also the optional terms [5][N],
+ *   comp_lp [N][mix_C] and dlogit [B][G] as dmv_obj_forward leaves them.
+ * X, M are the objective's data as well as the encoder's input.  DMV_E_UNSUPPORTED for anything else (imputation
+ * mixtures, the looser bound, nz*I*G > 16, objA / objB requested, means without a ticket): then call dmv_vae_forward and
  * dmv_obj_forward. */
 int dmv_vae_forward_bound(const DmvObjCfg* cfg, const DmvNet* enc, const float* enc_packed, int32_t in_mode, const float* X,
                           const uint8_t* M, const DmvNet* dec, const float* dec_packed, const float* eps, uint64_t seed,

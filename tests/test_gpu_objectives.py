@@ -671,11 +671,13 @@ def test_batch_means_formed_by_the_last_workgroup():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["iwae_stl", "iwae_dreg", "iwae_plain_nz2", "vae_mc", "iwae_I16", "iwae_bern", "iwae_eval",
-                                  "iwae_ragged"])
+                                  "iwae_ragged", "miwae_stl", "miwae_plain_i2", "miwae_nz2_c3", "miwae_eval", "miwae_bern_c16"])
 def test_forward_with_bound_equals_two_launches(case):
     """dmv_vae_forward_bound (encoder, sampling, decoder and the logsumexp bound in one launch, datapoint-major tiles)
     against dmv_vae_forward + dmv_obj_forward on the same noise: bounds and their mean to 2e-6 (other summation order
-    over a row's dimensions), parameter gradients to 1e-5 of each tensor's largest entry."""
+    over a row's dimensions), parameter gradients to 1e-5 of each tensor's largest entry.  The miwae cases: a stratified
+    mixture posterior, one sample row per component, the tight MissSIWAE bound (with and without "sticking the landing":
+    without it the backward also reads the component densities and the mixture term the launch leaves)."""
     import demiss_vae_amd as dmv
     from demiss_vae_amd import objectives as O
     from demiss_vae_amd import rng, synth
@@ -688,10 +690,17 @@ def test_forward_with_bound_equals_two_launches(case):
         "iwae_bern": (50, 20, 5, 1, 4, 96, "bern", dict(STL=True), True),
         "iwae_eval": (200, 8, 16, 1, 5, 256, "normal_with_eps", dict(), False),
         "iwae_ragged": (1, 3, 2, 1, 7, 32, "normal", dict(STL=True), True),
+        "miwae_stl": (512, 21, 16, 1, 1, 256, "normal_with_eps", dict(STL=True), True),
+        "miwae_plain_i2": (41, 21, 16, 1, 2, 64, "normal_with_eps", dict(), True),
+        "miwae_nz2_c3": (37, 5, 2, 2, 2, 200, "normal", dict(STL=True), True),
+        "miwae_eval": (200, 21, 16, 1, 1, 256, "normal_with_eps", dict(), False),
+        "miwae_bern_c16": (9, 20, 5, 1, 1, 96, "bern", dict(STL=True), True),
     }
     B, D, Zd, nz, I, hidden, gen, kw, training = shapes[case]
     normal = gen.startswith("normal")
-    dims = dmv.ModelDims(D=D, Zd=Zd, gen_dist=gen, q_dist="normal_with_eps", encoder_use_mis_mask=True)
+    Cn = 0 if not case.startswith("miwae") else 3 if case == "miwae_nz2_c3" else 16 if case == "miwae_bern_c16" else 5
+    dims = dmv.ModelDims(D=D, Zd=Zd, gen_dist=gen, q_dist="stratified_with_eps" if Cn else "normal_with_eps", C=max(Cn, 1),
+                         encoder_use_mis_mask=True)
     g = torch.Generator().manual_seed(17)
     X = torch.randn(B, D, generator=g)
     if not normal:
@@ -699,14 +708,20 @@ def test_forward_with_bound_equals_two_launches(case):
     X, M = X.cuda(), (torch.rand(B, D, generator=g) < 0.6).cuda()
 
     def run(fused):
-        enc = synth.packed_net(synth.NetShape(2 * D, 2 * Zd, 2, hidden), 1, "cuda", requires_grad=training)
+        enc = synth.packed_net(synth.NetShape(2 * D, 2 * Cn * Zd + Cn if Cn else 2 * Zd, 2, hidden), 1, "cuda",
+                               requires_grad=training)
         dec = synth.packed_net(synth.NetShape(Zd, 2 * D if normal else D, 2, hidden), 2, "cuda", requires_grad=training)
         rng.set_seed(23)
         O.FUSE_SMALL_BOUND, before = fused, O.bound_launches
         try:
             with torch.set_grad_enabled(training):
-                mean, per_b, neg = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=nz, num_importance_samples=I,
-                                                       with_loss=True, **kw)
+                if Cn:
+                    mean, per_b, neg = dmv.estimate_multiple_iwelbo(dims, enc, dec, X, M, num_latent_samples=nz,
+                                                                    num_importance_samples_for_each_component=I,
+                                                                    with_loss=True, **kw)
+                else:
+                    mean, per_b, neg = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=nz,
+                                                           num_importance_samples=I, with_loss=True, **kw)
                 if training:
                     neg.backward()
         finally:
@@ -721,7 +736,7 @@ def test_forward_with_bound_equals_two_launches(case):
     torch.testing.assert_close(one[0], two[0], rtol=2e-6, atol=2e-6)
     assert float(one[2]) == -float(one[0])
     # the mean is formed by whichever workgroup finishes last, from bounds the others published: again and again
-    for _ in range(30 if case in ("iwae_eval", "iwae_stl") else 2):
+    for _ in range(30 if case in ("iwae_eval", "iwae_stl", "miwae_stl") else 2):
         mean, per_b, _, _ = run(True)
         np.testing.assert_allclose(mean.item(), per_b.double().mean().item(), rtol=3e-6)
     for a, b in zip(one[3], two[3]):
