@@ -339,6 +339,22 @@ def mlp_backward(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: in
     return dx, grads
 
 
+def mlp_backward_chain(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: int, *, need_dx: bool, drop_keep=None):
+    """The input-gradient half of a backward pass on its own (dmv_mlp_backward with grad_w = NULL): (dx or None, ws,
+    nbytes); ws holds the per-layer gradients that mlp_wgrad / mlp_wgrad_pair turn into weight gradients."""
+    d = net.dims
+    dev = gy.device
+    assert rows > 0 and gy.shape == (rows, pad32(d.out_dim)) and gy.is_contiguous()
+    keep_ptr = L.DROP_GENERATED if isinstance(drop_keep, GeneratedDropout) else L.ptr(drop_keep)
+    dx = torch.empty((rows, pad32(d.in_dim)), dtype=torch.float32, device=dev) if need_dx else None
+    nbytes = L.lib().dmv_mlp_backward_ws_bytes(C.byref(net.c), rows)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+    L.check(L.lib().dmv_mlp_backward(C.byref(net.c), L.ptr(net.packed()), L.ptr(saved), keep_ptr, L.ptr(gy), gy.shape[1], rows,
+                                     L.ptr(dx), dx.shape[1] if need_dx else 0, None, None, 0.0, L.ptr(ws), nbytes,
+                                     L.stream_ptr()))
+    return dx, ws, nbytes
+
+
 def mlp_wgrad(net: PackedNet, saved: torch.Tensor, gy: torch.Tensor, rows: int, ws: torch.Tensor, nbytes: int, *,
               stream: Optional[torch.cuda.Stream] = None, complete: bool = False):
     """The weight-gradient half of a backward pass whose input-gradient chain already left the per-layer gradients in

@@ -23,8 +23,8 @@ import torch
 
 from . import _lib as L
 from . import rng
-from .mlp import (PackedNet, GeneratedDropout, mlp_forward, mlp_backward, mlp_wgrad, mlp_wgrad_pair, pad32, side_stream,
-                  overlap_pays)
+from .mlp import (PackedNet, GeneratedDropout, mlp_forward, mlp_backward, mlp_backward_chain, mlp_wgrad, mlp_wgrad_pair, pad32,
+                  side_stream, overlap_pays)
 
 
 @dataclass(frozen=True)
@@ -397,6 +397,41 @@ def _enc_side(c, enc: PackedNet, p: L.DmvLatentBwd, dZ, wgt, zscale, dlogit, kl_
 
 
 FUSE_SMALL_BACKWARD = True     # tests switch it off to compare with the separate launches
+PAIR_ROWS_MAX = 8192           # up to this many decoder rows the separate launches also end in one pair of weight-gradient launches
+
+
+def _paired_backward(c, enc: PackedNet, dec: PackedNet, p: L.DmvLatentBwd, wgt_dec, base_m, base_f, wgt, zscale, dlogit,
+                     kl_wgt, gb, gscale, complete):
+    """_dec_side + _enc_side with the weight gradients of both networks last, as one pair of launches: on a batch that
+    leaves the weight-gradient GEMMs less than one round of waves each, the decoder's - launched beside the latent-side
+    kernel and the encoder's chain on a second stream - delay those (their workgroups wait for a free compute unit), and
+    two launches queue two rounds.  Returns (decoder gradients, encoder gradients), or None: the caller takes the two
+    streams."""
+    if not PAIR_WGRAD or not (0 < c.N <= PAIR_ROWS_MAX) or c.enc_rows <= 0:
+        return None
+    if 2 * (enc.dims.nb + dec.dims.nb) + 4 > 24:
+        return None
+    # an encoder deeper than the decoder: its long chain on few compute units is the window the decoder's weight
+    # gradients fill on the second stream (miniboone, 5 blocks against 2, B = 1024: the pair is 2 % slower; equal depths,
+    # gas and hepmass at B = 1024: 4 - 5 % faster)
+    if enc.dims.nb > dec.dims.nb:
+        return None
+    lib, st = L.lib(), L.stream_ptr()
+    d_dec = torch.empty_like(c.dec_out)
+    L.check(lib.dmv_obj_backward_dec(C.byref(c.cfg), L.ptr(c.dec_out), c.dec_out.shape[1], L.ptr(c.Xc), L.ptr(c.Mu),
+                                     L.ptr(wgt_dec), L.ptr(gb), L.ptr(gscale), base_m, base_f, L.ptr(d_dec), d_dec.shape[1], st))
+    dZ, ws_dec, nb_dec = mlp_backward_chain(dec, c.dec_saved, d_dec, c.N, need_dx=True, drop_keep=c.dec_keep)
+    d_enc = torch.empty_like(c.enc_out)          # the kernel writes every entry, padding included
+    need_mix = p.base_qmix != 0.0
+    L.check(lib.dmv_obj_backward_latent(
+        C.byref(c.cfg), C.byref(p), L.ptr(c.enc_out), L.ptr(c.Z), L.ptr(c.eps), c.Z.shape[1], L.ptr(dZ), dZ.shape[1], L.ptr(wgt),
+        L.ptr(gb), L.ptr(zscale), L.ptr(c.comp_lp) if need_mix else None, L.ptr(c.terms[4]) if need_mix else None,
+        L.ptr(dlogit), L.ptr(kl_wgt), L.ptr(gscale), L.ptr(d_enc), st))
+    _, ws_enc, nb_enc = mlp_backward_chain(enc, c.enc_saved, d_enc, c.enc_rows, need_dx=False, drop_keep=c.enc_keep)
+    pair = mlp_wgrad_pair(dec, c.dec_saved, d_dec, c.N, ws_dec, nb_dec, enc, c.enc_saved, d_enc, c.enc_rows, ws_enc, nb_enc,
+                          complete_a=complete)
+    assert pair is not None
+    return pair
 PAIR_WGRAD = True              # ... and this one to compare with the two networks' weight gradients on two streams
 
 
@@ -565,6 +600,10 @@ class _FusedObjective(torch.autograd.Function):
                                            dlogit=c.dlogit)
                 if one is not None:
                     return (None,) * 10 + tuple(one[1]) + tuple(one[0])
+            if not c.reparam:
+                two = _paired_backward(c, enc, dec, p, c.wgt, f, 0.0, c.wgt, c.zscale, c.dlogit, None, gb, gs, True)
+                if two is not None:
+                    return (None,) * 10 + tuple(two[1]) + tuple(two[0])
             pending = []
             # (the decoder's gradients are whole here: one backward pass per step for these objectives)
             dZ, g_dec_params = _dec_side(c, dec, c.wgt, f, 0.0, True, True, overlap=pending, gb=gb, gscale=gs, complete=True)

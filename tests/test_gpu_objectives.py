@@ -747,31 +747,42 @@ def test_forward_with_bound_equals_two_launches(case):
 def test_step_with_paired_weight_gradients_equals_two_streams():
     """After the one-launch backward the weight gradients of encoder and decoder are formed by one pair of launches
     (dmv_mlp_backward_wgrad_pair) instead of side by side on two streams: equal to rounding (the pair cuts the rows into
-    fewer slices), with and without a permanent gradient buffer."""
+    fewer slices), with and without a permanent gradient buffer.  The same for a batch just beyond the one-launch kernels
+    (separate launches for the chains, then the pair), with a mixture posterior and dropout drawn in the kernels."""
     import demiss_vae_amd as dmv
     from demiss_vae_amd import objectives as O, rng, synth
-    dims = dmv.ModelDims(D=8, Zd=16, encoder_use_mis_mask=True)
+    from demiss_vae_amd.imputation import _keep
     gen = torch.Generator().manual_seed(21)
-    X = torch.randn(512, 8, generator=gen).cuda()
-    M = (torch.rand(512, 8, generator=gen) < 0.5).cuda()
 
-    def run(pair, flat):
-        enc = synth.packed_net(synth.NetShape(16, 32, 2, 256), 1, "cuda")
-        dec = synth.packed_net(synth.NetShape(16, 16, 2, 256), 2, "cuda")
+    def run(pair, flat, B, mixture):
+        D, Zd, Cn = (21, 16, 5) if mixture else (8, 16, 1)
+        drop = 0.5 if mixture else 0.0
+        dims = dmv.ModelDims(D=D, Zd=Zd, q_dist="stratified_with_eps" if mixture else "normal_with_eps", C=Cn,
+                             encoder_use_mis_mask=True)
+        g2 = torch.Generator().manual_seed(22)
+        X = torch.randn(B, D, generator=g2).cuda()
+        M = (torch.rand(B, D, generator=g2) < 0.5).cuda()
+        enc = synth.packed_net(synth.NetShape(2 * D, 2 * Cn * Zd + Cn if mixture else 2 * Zd, 2, 256, dropout=drop), 1, "cuda")
+        dec = synth.packed_net(synth.NetShape(Zd, 2 * D, 2, 256, dropout=drop), 2, "cuda")
         if flat:
             enc.use_flat_grads()
             dec.use_flat_grads()
         rng.set_seed(9)
         O.PAIR_WGRAD = pair
         try:
-            bound, _ = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=1, num_importance_samples=5, STL=True)
+            if mixture:
+                ek, dk = _keep(enc, B, True, "cuda"), _keep(dec, B * Cn, True, "cuda")
+                bound, _ = dmv.estimate_multiple_iwelbo(dims, enc, dec, X, M, num_importance_samples_for_each_component=1,
+                                                        STL=True, enc_keep=ek, dec_keep=dk)
+            else:
+                bound, _ = dmv.estimate_iwelbo(dims, enc, dec, X, M, num_latent_samples=1, num_importance_samples=5, STL=True)
             (-bound).backward()
         finally:
             O.PAIR_WGRAD = True
         torch.cuda.synchronize()
         return [t.grad.clone() for t in enc.params() + dec.params()]
 
-    for flat in (False, True):
-        a, b = run(True, flat), run(False, flat)
+    for flat, B, mixture in ((False, 512, False), (True, 512, False), (False, 1200, False), (True, 1024, True)):
+        a, b = run(True, flat, B, mixture), run(False, flat, B, mixture)
         for x, y in zip(a, b):
             assert float(y.abs().max()) > 0 and float((x - y).abs().max()) <= 1e-5 * float(y.abs().max())

@@ -19,6 +19,8 @@ def main():
         "hepmass B=512": lambda: E.missiwae_step(dev, "UCI-hepmass", 512, 21, 16, (42, 165, 2, 256), (16, 42, 2, 256)),
         "miniboone B=1024": lambda: E.missiwae_step(dev, "UCI-miniboone", 1024, 43, 32, (86, 325, 5, 256), (32, 86, 2, 256),
                                                     dropout=0.5),
+        "gas B=1024 graph": lambda: E.iwae_step(dev, 1024, graph=True),
+        "hepmass B=1024": lambda: E.missiwae_step(dev, "UCI-hepmass", 1024, 21, 16, (42, 165, 2, 256), (16, 42, 2, 256)),
         "toy B=64 K=5": lambda: E.demiss_toy_step(dev, 64, 5),
         "uci demiss": lambda: E.demiss_toy_step(dev, 512, 5, uci=True),
     }
